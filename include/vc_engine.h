@@ -1,0 +1,161 @@
+/*
+ * vc_engine.h — C ABI of libvcengine.so, the MI355X (gfx950) engine for the
+ * VoiceCraft token-infilling decode path.
+ *
+ * The reference (jasonppy/VoiceCraft) has no FFI: its boundary for this path is
+ * three Python methods on an nn.Module plus two tokenizer methods.
+ * Each entry point below names the reference interface it replaces; the Python
+ * mirror of that interface lives in voicecraft_amd/engine.py and is the only
+ * in-tree caller (ctypes).  INTEGRATION.md shows the reference-side stub.
+ *
+ * Conventions
+ *   - plain C types only; every function returns 0 on success or a negative
+ *     VC_E* code, with a human-readable message available from vc_last_error().
+ *   - `*_dev` pointers are device (HBM) pointers owned by the caller; the engine
+ *     owns everything it allocates itself and frees it in vc_destroy().
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream).
+ *   - token tensors are int64, matching the reference's LongTensors.
+ *   - one engine per (process, GPU); not thread-safe (the reference is neither:
+ *     inference_tts_scale.py:42 runs single-threaded under torch.no_grad()).
+ */
+#ifndef VC_ENGINE_H
+#define VC_ENGINE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VC_OK 0
+#define VC_EINVAL (-1)   /* bad argument / shape (the reference would AssertionError) */
+#define VC_ESTATE (-2)   /* call order (e.g. decode before vc_finalize_weights)       */
+#define VC_EHIP (-3)     /* a HIP runtime call failed                                 */
+#define VC_ECAP (-4)     /* a capacity given at vc_create / by the caller is too small */
+#define VC_EMISSING (-5) /* a required weight tensor was never loaded                 */
+
+#define VC_DTYPE_F32 0
+#define VC_DTYPE_BF16 1
+#define VC_DTYPE_I64 2
+
+#define VC_MAX_CODEBOOKS 8
+#define VC_MAX_SPANS 8
+#define VC_MAX_SILENCE 8
+
+typedef struct vc_engine vc_engine;
+
+/* Model hyper-parameters = the fields of the reference's pickled `args` Namespace that
+ * the inference path reads (models/voicecraft.py:105-185, config.py:55-84), plus the
+ * capacities the engine sizes its HBM arenas with. */
+typedef struct vc_model_cfg {
+  int32_t d_model;          /* args.d_model                                   */
+  int32_t nhead;            /* args.nhead                                     */
+  int32_t num_layers;       /* args.num_decoder_layers                        */
+  int32_t n_codebooks;      /* args.n_codebooks (K)                           */
+  int32_t audio_vocab_size; /* args.audio_vocab_size (2048)                   */
+  int32_t n_special;        /* args.n_special; V = audio_vocab_size+n_special */
+  int32_t text_rows;        /* args.text_vocab_size + 1 (voicecraft.py:129)   */
+  int32_t head_hidden;      /* audio_vocab_size // 2   (voicecraft.py:183)    */
+  int32_t empty_token;      /* args.empty_token                               */
+  int32_t eog;              /* args.eog                                       */
+  int32_t audio_pad_token;  /* args.audio_pad_token                           */
+  int32_t eos;              /* args.eos, or -1 when the checkpoint has none   */
+  int32_t reduced_eog;      /* args.reduced_eog (voicecraft.py:240)           */
+  int32_t encodec_sr;       /* args.encodec_sr (50)                           */
+  int32_t max_n_spans;      /* args.max_n_spans: rows of mask_embedding       */
+  int32_t max_seqs;         /* capacity: concurrent sequences (KV slots)      */
+  int32_t max_positions;    /* capacity: cached positions per sequence        */
+} vc_model_cfg;
+
+/* Decode controls = the keyword arguments of inference_tts / inference
+ * (models/voicecraft.py:908-920, :561-573). */
+typedef struct vc_sample_cfg {
+  int32_t top_k;            /* <=0: no top-k filter (reference default -100)  */
+  float top_p;              /* >=1: no nucleus filter                         */
+  float temperature;        /* 1.0: untouched                                 */
+  int32_t stop_repetition;  /* <=0: silence-run penalty off                   */
+  int32_t n_silence;        /* number of entries used in silence_tokens       */
+  int32_t silence_tokens[VC_MAX_SILENCE];
+  uint64_t seed;            /* Philox key; stream = (seed, sequence, step, codebook) */
+  int32_t use_graph;        /* 1: replay the decode step as a captured hipGraph */
+  int32_t poll_every;       /* host polls the done flag every N steps (0 = default 16) */
+} vc_sample_cfg;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int vc_create(const vc_model_cfg* cfg, int hip_device, vc_engine** out);
+void vc_destroy(vc_engine* e);
+const char* vc_last_error(const vc_engine* e); /* e may be NULL: last vc_create error */
+const char* vc_version(void);
+
+/* ---- weights: replaces get_model()/load_state_dict (inference_tts_scale.py:107-125).
+ * `key` is the reference state_dict key; data is fp32 (or int64 for
+ * eog/eos, ignored).  `on_device` tells whether `data` is a host or device pointer.
+ * Unknown keys (e.g. accuracy_metrics.*) are ignored and return VC_OK. */
+int vc_load_tensor(vc_engine* e, const char* key, const void* data, int on_device,
+                   int dtype, const int64_t* shape, int ndim);
+/* Packs everything into the MFMA fragment layout in `compute_dtype`
+ * (VC_DTYPE_BF16, or VC_DTYPE_F32 for the exact mode), builds the sinusoidal
+ * position tables (models/modules/embedding.py:69-92) and frees the staging copies. */
+int vc_finalize_weights(vc_engine* e, int compute_dtype);
+
+/* ---- TTS: VoiceCraft.inference_tts (models/voicecraft.py:908-1153) and, with
+ * n_samples > 1, VoiceCraft.inference_tts_batch (:1156-1439, best-of-N: the sample
+ * whose first codebook terminates first is kept).
+ *   x_dev      int64 [Lx]            phoneme ids
+ *   y_dev      int64 [T][K]          prompt codes, time-major exactly as the caller's y[0]
+ *   forced_dev int64 [n_forced][K]   optional teacher-forcing trajectory (parity hook): the
+ *                                    step's final tokens are replaced by these; NULL = sample
+ *   res_dev    int64 [K][res_cap]    out: prompt followed by generated frames (row stride res_cap)
+ *   gen_len    out (host): number of generated frames Tg; res holds T+Tg columns
+ *   logits_dev float [logit_steps][K][V] optional: raw head outputs of the first steps
+ *   n_steps    out (host, optional): decode steps taken (Tg + K)                       */
+int vc_tts(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, int T,
+           const vc_sample_cfg* sc, int n_samples, const int64_t* forced_dev, int n_forced,
+           int64_t* res_dev, int res_cap, int* gen_len, float* logits_dev, int logit_steps,
+           int* n_steps, void* stream);
+
+/* ---- multi-utterance TTS (SURVEY.md §8f-1 / BASELINE config 5): B independent
+ * (x, y) pairs decoded as one batch; each row follows inference_tts exactly.
+ *   x_dev int64 [sum Lx], y_dev int64 [sum T][K] concatenated; *_off host arrays [B+1].
+ *   res_dev int64 [B][K][res_cap]; gen_len host [B]. */
+int vc_tts_multi(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_off,
+                 const int64_t* y_dev, const int32_t* y_off, const vc_sample_cfg* sc,
+                 int64_t* res_dev, int res_cap, int* gen_len, int* n_steps, void* stream);
+
+/* ---- speech editing: VoiceCraft.inference (models/voicecraft.py:561-906).
+ *   mask_intervals host int32 [M][2] (codec-frame units, as mask_interval[0])
+ *   mask_values    host int32 [2M]   the reference's mask_value list (insert_mask, :264-288)
+ *   res_dev int64 [K][res_cap]; res_len out (host): T' (voicecraft.py:900)            */
+int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, int T,
+            const int32_t* mask_intervals, int M, const int32_t* mask_values,
+            const vc_sample_cfg* sc, const int64_t* forced_dev, int n_forced,
+            int64_t* res_dev, int res_cap, int* res_len, float* logits_dev, int logit_steps,
+            int* n_steps, void* stream);
+
+/* ---- delayed-codebook pattern (models/codebooks_patterns.py:151-176, :222-245 and
+ * the un-shift at models/voicecraft.py:1125-1139).  Integer, bit-exact.  No engine needed.
+ *   shift : z [B][K][T]  -> out [B][K][T+K]   out[q][s] = z[q][s-1-q] or `special`
+ *   revert: s [B][K][S]  -> out [B][K][T]     out[q][t] = s[q][t+1+q] if t+1+q < S else `special`
+ *   unshift: span [N][K] (step-major) -> out [K][N-K]  out[j][t] = span[j+t][j]         */
+int vc_pattern_shift(const int64_t* z_dev, int B, int K, int T, int64_t special,
+                     int64_t* out_dev, void* stream);
+int vc_pattern_revert(const int64_t* s_dev, int B, int K, int S, int T, int64_t special,
+                      int64_t* out_dev, void* stream);
+int vc_pattern_unshift(const int64_t* span_dev, int N, int K, int64_t* out_dev, void* stream);
+
+/* ---- parity/debug hooks (tests only) ------------------------------------ */
+/* Copies a named internal device buffer to host memory. */
+int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int64_t nbytes);
+/* Timing of the last vc_tts/vc_edit call, measured with HIP events on `stream`:
+ * ms[0] = prompt build + prefill, ms[1] = decode loop, ms[2] = whole call. */
+int vc_last_timing(const vc_engine* e, float ms[3]);
+/* Average duration in ms of the dominant decode kernel (FFN up-projection rows-GEMM)
+ * measured with HIP events over `iters` back-to-back launches on `stream`, and the
+ * algorithmic bytes one launch moves.  Used by bench.py for the roofline object. */
+int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int iters, float* avg_ms,
+                    double* alg_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VC_ENGINE_H */

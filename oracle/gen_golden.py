@@ -1,0 +1,157 @@
+"""Generates tests/golden/*.npz by running the REAL reference.  TEST INFRASTRUCTURE ONLY.
+
+Run in the build container (needs /root/reference):   python -m oracle.gen_golden
+Every fixture stores the inputs, the reference's outputs and (for model runs) the raw head logits
+of every decode step, sub-sampled, plus the first steps in full.  Checkpoints are not stored: they
+are regenerated from (preset, seed) by voicecraft_amd.synth, which uses a frozen RNG stream.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from oracle import ref_loader  # noqa: E402
+from voicecraft_amd import synth  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+FULL_STEPS = 3       # steps whose [K,V] logits are stored in full
+STRIDE = 61          # sub-sampling stride over V for all steps
+
+# name -> spec.  `arg_kw` feeds synth.make_args, `knobs` the reference call.
+MODEL_CASES = {
+    "tts_greedy": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(6, 21, 11), mode="tts",
+                       knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1)),
+    "tts_greedy_nokv": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(6, 21, 11), mode="tts",
+                            knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=0)),
+    "tts_greedy_hd128": dict(preset="tiny128", arg_kw={}, wseed=5, prompt=(5, 17, 12), mode="tts",
+                             knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
+    "tts_sampled": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(7, 30, 13), mode="tts", tseed=1234,
+                        knobs=dict(top_k=40, top_p=0.9, temperature=0.8, stop_repetition=2, kvcache=1)),
+    "tts_oldscheme": dict(preset="tiny", arg_kw=dict(eos=-1, n_special=3, reduced_eog=0), wseed=4,
+                          prompt=(6, 19, 14), mode="tts",
+                          knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1)),
+    "tts_batch_greedy": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(6, 21, 11), mode="tts_batch",
+                             knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1, batch_size=3)),
+    "tts_early_stop": dict(preset="tiny", arg_kw={}, wseed=6, prompt=(3, 40, 15), mode="tts",   # prompt longer than the cap
+                           knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1)),
+    "edit_1span": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(8, 60, 16), mode="edit", spans=[(20, 31)],
+                       knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
+    "edit_2span": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(9, 64, 17), mode="edit", spans=[(10, 18), (40, 47)],
+                       knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
+    "edit_3span_edges": dict(preset="tiny", arg_kw={}, wseed=7, prompt=(9, 50, 18), mode="edit",
+                             spans=[(1, 5), (20, 20), (44, 50)],     # 1-frame head piece, empty span, span to the end
+                             # (a span starting at frame 0 makes the reference itself raise IndexError:
+                             #  zero-length piece in build_pattern_sequence, codebooks_patterns.py:174)
+                             knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
+    "edit_oldscheme": dict(preset="tiny", arg_kw=dict(eos=-1, n_special=3, reduced_eog=0), wseed=4,
+                           prompt=(8, 55, 19), mode="edit", spans=[(15, 25)],
+                           knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
+    "edit_reduced_noeos": dict(preset="tiny", arg_kw=dict(eos=-1, n_special=3, reduced_eog=1), wseed=4,
+                               prompt=(8, 55, 19), mode="edit", spans=[(15, 25)],
+                               knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
+    "edit_sampled": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(8, 60, 16), mode="edit", spans=[(20, 31)], tseed=99,
+                         knobs=dict(top_k=30, top_p=0.8, temperature=1.0, stop_repetition=2, kvcache=1)),
+}
+
+
+def run_reference_case(spec):
+    args = synth.make_args(spec["preset"], **spec["arg_kw"])
+    # un-muted terminator for the early-stop / editing cases would end generation at random places;
+    # keep it muted everywhere so lengths are set by the reference's own cap
+    sd = synth.make_state_dict(args, seed=spec["wseed"], perturb=True, mute_eos=True)
+    model = ref_loader.build_reference_model(args, sd)
+    Lx, T, pseed = spec["prompt"]
+    x, x_lens, y = synth.random_prompt(args, Lx, T, seed=pseed)
+    captured = []
+    hooks = [m.register_forward_hook(lambda mod, inp, out: captured.append(out.detach().clone()))
+             for m in model.predict_layer]
+    if "tseed" in spec:
+        torch.manual_seed(spec["tseed"])
+    kn = dict(spec["knobs"])
+    out = {}
+    with torch.no_grad():
+        if spec["mode"] == "tts":
+            res, gen = model.inference_tts(x, x_lens, y, **kn)
+            out["res"], out["gen"] = res.numpy(), gen.numpy()
+        elif spec["mode"] == "tts_batch":
+            res, gen = model.inference_tts_batch(x, x_lens, y, **kn)
+            out["res"], out["gen"] = res.numpy(), gen.numpy()
+        else:
+            mi = torch.tensor([spec["spans"]], dtype=torch.int64)
+            res = model.inference(x, x_lens, y, mi, **kn)
+            out["res"] = res.numpy()
+            out["mask_interval"] = mi.numpy()
+    for h in hooks:
+        h.remove()
+    K = args.n_codebooks
+    steps = len(captured) // K
+    lg = torch.stack([torch.stack([captured[s * K + k] for k in range(K)], dim=0) for s in range(steps)], dim=0)
+    lg = lg.reshape(steps, K, -1, lg.shape[-1])          # [steps,K,B,V]
+    out["logits_full"] = lg[:FULL_STEPS, :, 0].numpy().astype(np.float32)
+    out["logits_sub"] = lg[:, :, 0, ::STRIDE].numpy().astype(np.float32)
+    out["n_steps"] = np.int64(steps)
+    out["x"], out["y"] = x.numpy(), y.numpy()
+    return out
+
+
+def gen_pattern():
+    _, cp = ref_loader.import_reference()
+    rs = np.random.RandomState(0)
+    out = {}
+    for K in (4, 3, 8):
+        prov = cp.DelayedPatternProvider(n_q=K)
+        for T in (0, 1, 2, 3, 4, 5, 6, 7, 33, 150):
+            if T == 0:
+                continue        # the reference's Pattern cannot be built for T=0 with K>1 edge; covered by closed form only
+            z = rs.randint(0, 2048, size=(2, K, T)).astype(np.int64)
+            pat = prov.get_pattern(T)
+            vals, idx, mask = pat.build_pattern_sequence(torch.from_numpy(z), 2048, keep_only_valid_steps=False)
+            out[f"z_K{K}_T{T}"] = z
+            out[f"shift_K{K}_T{T}"] = vals.numpy()
+            rv, _, _ = pat.revert_pattern_sequence(vals, 2048, keep_only_valid_steps=False)
+            out[f"revert_K{K}_T{T}"] = rv.numpy()
+            # revert of a truncated sequence (S < T+K), as inference_tts cuts it (voicecraft.py:967)
+            cut = vals[:, :, : T + 1]
+            rv2, _, _ = pat.revert_pattern_sequence(cut.contiguous(), 2048, keep_only_valid_steps=False)
+            out[f"revertcut_K{K}_T{T}"] = rv2.numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "pattern.npz"), **out)
+    print("pattern.npz:", len(out), "arrays")
+
+
+def gen_sampler():
+    vc, _ = ref_loader.import_reference()
+    out = {}
+    rs = np.random.RandomState(7)
+    lg = torch.from_numpy(rs.standard_normal(size=(6, 257)).astype(np.float32) * 3)
+    lg[0, 5] = lg[0, 9]                                       # a tie
+    out["logits"] = lg.numpy().copy()
+    for name, (k, p) in {"k5": (5, 1.0), "k40": (40, 1.0), "p08": (0, 0.8), "k20p06": (20, 0.6), "none": (-100, 1.0)}.items():
+        out[f"filt_{name}"] = vc.top_k_top_p_filtering(lg.clone(), top_k=k, top_p=p).numpy()
+    out["kat_topk"] = vc.top_k_top_p_filtering(torch.tensor([[1., 3., 3., 2., 0.]]), top_k=2).numpy()
+    out["kat_topp"] = vc.top_k_top_p_filtering(torch.log(torch.tensor([[.5, .3, .15, .05]])), top_p=0.8).numpy()
+    torch.manual_seed(5)
+    out["draws_seed5"] = torch.stack([vc.topk_sampling(lg.clone(), top_k=10, top_p=0.9, temperature=0.7) for _ in range(8)]).numpy()
+    np.savez_compressed(os.path.join(GOLDEN, "sampler.npz"), **out)
+    print("sampler.npz:", len(out), "arrays")
+
+
+def main():
+    os.makedirs(GOLDEN, exist_ok=True)
+    torch.set_num_threads(8)
+    gen_pattern()
+    gen_sampler()
+    for name, spec in MODEL_CASES.items():
+        out = run_reference_case(spec)
+        np.savez_compressed(os.path.join(GOLDEN, f"model_{name}.npz"), **out)
+        print(f"model_{name}.npz: steps={int(out['n_steps'])} res={out['res'].shape}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,254 @@
+// vc_common.h — internal types shared by the HIP translation units of libvcengine.so.
+// gfx950 only (wave64, MFMA 16x16x32 bf16 / 16x16x4 f32).  Not part of the public ABI.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vc_engine.h"
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+
+#define VC_ROWS 16          // rows (token positions) one forward pass carries = MFMA N dimension
+#define VC_MAX_NSPLIT 16    // split-S factor cap of the decode attention
+#define VC_MAX_KSPLIT 8     // cross-block split-K cap of the rows-GEMM
+#define VC_MAX_SEG 32       // prompt segments (2*spans+1 pieces + placeholders)
+#define VC_VPL 34           // logits per lane in the sampler: V <= 64*34
+
+// ---------------------------------------------------------------- element types
+struct bf16_t { uint16_t u; };
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even (torch .to(bfloat16))
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename WT> struct WTr;
+template <> struct WTr<float> {      // exact mode: v_mfma_f32_16x16x4_f32, 4 per 16-byte fragment
+  static constexpr int EPL = 4;      // elements per lane per fragment
+  static constexpr int KW = 16;      // K elements per fragment tile
+  __device__ static __forceinline__ float ld(const float* p) { return *p; }
+  __device__ static __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct WTr<bf16_t> {     // bf16 mode: v_mfma_f32_16x16x32_bf16, 8 per 16-byte fragment
+  static constexpr int EPL = 8;
+  static constexpr int KW = 32;
+  __device__ static __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->u); }
+  __device__ static __forceinline__ void st(bf16_t* p, float v) { p->u = f32_to_bf16(v); }
+};
+
+// D[n][m] += sum_k W[n][k] * X[m][k] for one 16-byte fragment pair.
+// A operand (weights): lane l holds W[16*nt + (l&15)][KW*kt + EPL*(l>>4) + j]
+// B operand (rows)   : lane l holds X[m = l&15   ][KW*kt + EPL*(l>>4) + j]
+// D                  : lane l holds D[n = 4*(l>>4) + r][m = l&15], r = 0..3
+__device__ __forceinline__ f32x4 mfma_frag(const uint4& w, const uint4& x, f32x4 acc, bf16_t*) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w),
+                                                 __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma_frag(const uint4& w, const uint4& x, f32x4 acc, float*) {
+  // four K=4 steps; step j pairs element j of both fragments (a permutation of k shared by
+  // both operands, so the dot product is unchanged).
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.x), __uint_as_float(x.x), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.y), __uint_as_float(x.y), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.z), __uint_as_float(x.z), acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(w.w), __uint_as_float(x.w), acc, 0, 0, 0);
+  return acc;
+}
+
+// ---------------------------------------------------------------- wave helpers (wave64)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// ---------------------------------------------------------------- per-sequence decode state (device)
+// Mirrors the Python locals of the reference's generation loop (models/voicecraft.py:994-1013,
+// :1037-1067): codebook_eog -> n_eog (always a prefix), cur_num_gen, prev_token,
+// consec_silence_count, y_input.shape[1] -> y_len, num_gen -> span_steps.
+struct SeqState {
+  int Lx;            // phoneme count (x_lens[0])
+  int y_len;         // audio positions embedded so far
+  int cur_num_gen;   // steps taken in the current span
+  int n_eog;         // codebooks already terminated in the current span
+  int prev_token;    // -1 = None
+  int consec_silence;
+  int span;          // index of the span being generated
+  int n_spans;       // spans to generate (1 for TTS)
+  int done;          // 1 once every span is finished (or the sample was dropped)
+  int total_steps;   // rows written to the gen buffer
+  int cap_len;       // y_len > cap_len forces termination (voicecraft.py:1042, :751)
+  int min_gen;       // cur_num_gen <= min_gen suppresses the terminator on cb0 (TTS, :1024); -1 = off
+  int term_token;    // eog_inference (TTS) or eog (editing)
+  int kill_token;    // token whose logit is forced to -10000 on every codebook (:1091-1093, :816-818); -1 = none
+  int group;         // best-of-N group id, -1 = independent
+  int kept;          // 1 if this sample is the group's kept one (or independent)
+  int span_steps[VC_MAX_SPANS];
+  int mask_value[VC_MAX_SPANS];   // mask_embedding row inserted before span i (i >= 1)
+};
+
+// ---------------------------------------------------------------- kernel argument blocks
+enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2 };
+enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4 };
+
+struct GemmArgs {
+  // weights, packed [group][n_tile][k_tile][lane] x 16 bytes
+  const uint4* Wp;
+  const float* bias;        // [group][N] (may be null)
+  int N, K;                 // logical out / in features per group
+  int n_tiles, KT;          // ceil(N/16), K / KW
+  int nchunk;               // k-chunks per block; a chunk = 4 waves * KTW tiles
+  int r_lds;                // rows of X staged in LDS
+  long w_group_stride;      // in uint4 units
+  int bias_group_stride;
+  // rows
+  const int* row_seq;
+  const int* row_pos;
+  const int* n_rows_ptr;
+  int n_rows;
+  const int* n_active;      // early exit when *n_active == 0 (null = never)
+  // prologue LN:   hn = h_in[src] + prev_bias + sum_s parts[s][r]; X = LN(hn) ; h_out[r] = hn
+  const float* h_in;
+  float* h_out;
+  const float* parts;       // [n_parts][VC_ROWS][d]
+  int n_parts;
+  const float* prev_bias;
+  const float* ln_w;
+  const float* ln_b;
+  const int* gather_rows;   // optional indirection on h_in/parts rows (logit rows for the heads)
+  int d;                    // row width of h / parts
+  // prologue PLAIN: X = x_in[r][grp*x_group_stride + k]
+  const void* x_in;
+  int x_ld;
+  int x_group_stride;
+  // prologue ATT: X = combine of attention split partials
+  const float* att_o;       // [VC_ROWS][H][nsplit][hd]
+  const float* att_ml;      // [VC_ROWS][H][nsplit][2]
+  int nsplit, H, hd;
+  // epilogues
+  void* out;                // RELU/GELU: WT [r][out_ld]; LOGITS: float [r][group][N]
+  int out_ld;
+  int out_group_stride;
+  float* q_out;             // QKV: [r][d]
+  void* kcache;             // QKV: WT [seq][H][S_max][hd]
+  void* vcache;
+  long cache_seq_stride;    // H*S_max*hd
+  int S_max;
+  float* part_out;          // PART: [ksplit][VC_ROWS][N]
+};
+
+struct AttnArgs {
+  const float* q;           // [VC_ROWS][d]
+  const void* kcache;
+  const void* vcache;
+  long cache_seq_stride;
+  int S_max, H, hd, d, nsplit;
+  float scale;
+  const int* row_seq;
+  const int* row_pos;
+  const int* n_rows_ptr;
+  int n_rows;
+  const int* n_active;
+  float* att_o;
+  float* att_ml;
+};
+
+struct Segment {            // one run of columns of the rearranged audio sequence
+  int col0, ncols;          // first column and number of columns it contributes
+  int src0, src_len;        // source frames y[src0 .. src0+src_len)
+  int term;                 // token appended after the source frames (eos/eog) or -1
+  int mask_value;           // >= 0: this is a one-column mask placeholder using mask_embedding[mask_value]
+};
+
+struct PromptArgs {
+  const int64_t* x;         // [Lx]
+  const int64_t* y;         // [T][K]
+  int Lx, T, K, d, V;
+  int n_seg, n_cols;        // audio columns in the prefill
+  Segment seg[VC_MAX_SEG];
+  int empty_token;
+  const float* text_emb;    // [text_rows][d]
+  const float* audio_emb;   // [K][V][d]
+  const float* mask_emb;    // [max_n_spans][d]
+  const float* pe;          // [max_positions][d]
+  float alpha_text, alpha_audio;
+  int seq;                  // sequence slot
+  int row0;                 // first row in emb/row tables this prompt occupies
+  float* emb;               // [rows][d]
+  int* row_seq;
+  int* row_pos;
+  int* err;                 // set to 1 when an out-of-range token id is met
+  int text_rows;
+  int* logit_row;           // optional: *logit_row = logit_row_val (row of the last prefill group
+  int logit_row_val;        //           whose hidden state feeds the heads)
+};
+
+struct SampleArgs {
+  const float* logits;      // [B][K][V]
+  int B, K, V, d;
+  int top_k;
+  float top_p, temperature;
+  int stop_repetition, n_silence;
+  int silence[VC_MAX_SILENCE];
+  uint64_t seed;
+  int empty_token;
+  SeqState* st;
+  int* n_active;
+  int* samp;                // scratch [B][K]
+  int* cond;                // scratch [B]
+  int* amax;                // scratch [B]
+  int* gen;                 // [B][max_steps][K]
+  int max_steps;
+  const int64_t* forced;    // [n_forced][K] or null
+  int n_forced;
+  float* logits_out;        // [logit_steps][K][V] or null (sequence 0 only)
+  int logit_steps;
+  // next-step rows
+  int rps;                  // rows per sequence slot (1, or 3 for editing)
+  float* dec_h;             // [B*rps][d]
+  int* row_seq;
+  int* row_pos;
+  int* logit_row;           // [B]
+  const float* audio_emb;
+  const float* mask_emb;
+  const float* pe;
+  float alpha_audio;
+  int max_positions;
+};
+
+struct AssembleArgs {       // writes res [K][res_cap] from y and the generated spans
+  const int64_t* y;         // [T][K]
+  const int* gen;           // [max_steps][K] of the kept sequence
+  int K, T, res_cap, n_piece;
+  // piece i: kind 0 = copy y[src0..src0+len), kind 1 = un-shift gen rows [g0, g0+len+K)
+  int kind[2 * VC_MAX_SPANS + 1];
+  int src0[2 * VC_MAX_SPANS + 1];
+  int len[2 * VC_MAX_SPANS + 1];
+  int dst0[2 * VC_MAX_SPANS + 1];
+  int64_t* res;
+};
+
+// ---------------------------------------------------------------- launchers (defined in the .hip files)
+hipError_t vc_launch_pack(const float* src, void* dst, int N, int K, int dtype, hipStream_t s);
+hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
+                          hipStream_t s);
+size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
+hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);
+hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s);
+hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s);
+hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s);
+hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStream_t s);
+hipError_t vc_launch_copy_kv(void* cache, long seq_stride, int H, int S_max, int hd, int len,
+                             int src_seq, int dst_seq0, int n_dst, int dtype, hipStream_t s);

@@ -1,0 +1,999 @@
+// vc_engine.hip — host side of libvcengine.so: the C ABI of include/vc_engine.h, HBM arena
+// management, weight packing, prefill scheduling, the decode loop (eager or hipGraph replay) and
+// output assembly.  No torch types anywhere; the caller hands raw device pointers and a stream.
+//
+// Control flow restated from VoiceCraft.inference_tts / inference_tts_batch / inference
+// (models/voicecraft.py:908-1153, :1156-1439, :561-906); see DESIGN.md §2 for the mapping.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "vc_common.h"
+
+namespace {
+
+std::string g_create_err;
+
+struct RawTensor {
+  std::vector<int64_t> shape;
+  float* dev = nullptr;   // fp32 staging copy in HBM
+  long numel = 0;
+};
+
+struct Layer {
+  uint4 *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;
+  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
+  void *kc = nullptr, *vc = nullptr;   // KV cache of this layer: WT [max_seqs][H][S_max][hd]
+};
+
+struct Plan { int n_tiles, KT, ksplit, nchunk; };
+
+}  // namespace
+
+struct vc_engine {
+  vc_model_cfg cfg{};
+  int device = 0;
+  int dtype = -1;
+  bool finalized = false;
+  std::string err;
+  std::map<std::string, RawTensor> raw;
+  std::vector<void*> allocs;
+
+  int d = 0, H = 0, hd = 0, L = 0, K = 0, V = 0, P = 0, S_max = 0, B_max = 0;
+  int esz = 2;
+
+  std::vector<Layer> layers;
+  float *lnf_w = nullptr, *lnf_b = nullptr;
+  uint4 *Wh1 = nullptr, *Wh2 = nullptr;
+  float *bh1 = nullptr, *bh2 = nullptr;
+  long wh2_group_stride = 0;
+  float *text_emb = nullptr, *audio_emb = nullptr, *mask_emb = nullptr, *pe = nullptr;
+  float alpha_text = 1.f, alpha_audio = 1.f;
+  Plan p_qkv{}, p_o{}, p_f1{}, p_f2{}, p_h1{}, p_h2{};
+
+  // activations / scratch
+  float *emb = nullptr;                 // prefill rows [S_max][d]
+  int *pre_row_seq = nullptr, *pre_row_pos = nullptr;
+  float *hA = nullptr, *hB = nullptr, *q = nullptr, *parts = nullptr, *att_o = nullptr, *att_ml = nullptr;
+  void *act = nullptr, *hh = nullptr;
+  float *logits = nullptr;              // [B_max][K][V]
+  float *dec_h = nullptr;               // [VC_ROWS][d]
+  int *dec_row_seq = nullptr, *dec_row_pos = nullptr, *logit_row = nullptr;
+  SeqState *st = nullptr;
+  int *n_active = nullptr, *samp = nullptr, *cond = nullptr, *amax = nullptr, *gen = nullptr, *err_flag = nullptr;
+  int gen_cap = 0;
+  // pinned host staging
+  SeqState *h_st = nullptr;
+  int *h_flag = nullptr;
+
+  hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
+  hipEvent_t ev[3]{};
+  float ms[3]{0, 0, 0};
+  double bytes_total = 0;               // HBM bytes owned by the engine
+};
+
+namespace {
+
+int fail(vc_engine* e, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (e) e->err = buf; else g_create_err = buf;
+  return code;
+}
+
+#define HIPCHK(e, call)                                                                  \
+  do {                                                                                   \
+    hipError_t _err = (call);                                                            \
+    if (_err != hipSuccess)                                                              \
+      return fail(e, VC_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), \
+                  __FILE__, __LINE__);                                                   \
+  } while (0)
+
+template <typename T>
+int dalloc(vc_engine* e, T** p, size_t n) {
+  void* v = nullptr;
+  hipError_t err = hipMalloc(&v, std::max<size_t>(n * sizeof(T), 16));
+  if (err != hipSuccess) return fail(e, VC_EHIP, "hipMalloc(%zu bytes) failed: %s", n * sizeof(T), hipGetErrorString(err));
+  e->allocs.push_back(v);
+  e->bytes_total += (double)(n * sizeof(T));
+  *p = reinterpret_cast<T*>(v);
+  return VC_OK;
+}
+
+Plan make_plan(int N, int Kdim, int dtype, bool allow_split, const char* env_override) {
+  Plan p;
+  const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16;
+  p.n_tiles = (N + 15) / 16;
+  p.KT = Kdim / KW;
+  p.ksplit = 1;
+  if (allow_split) {
+    // grow the grid towards ~2 blocks per CU while every wave still streams >= 8 KiB per chunk
+    while (p.n_tiles * p.ksplit < 512 && p.ksplit < VC_MAX_KSPLIT && (p.KT / (p.ksplit * 2)) >= 32 &&
+           (p.KT % (p.ksplit * 2 * 8)) == 0)
+      p.ksplit *= 2;
+    if (env_override) {
+      const char* v = getenv(env_override);
+      if (v) {
+        const int ks = atoi(v);
+        if (ks >= 1 && ks <= VC_MAX_KSPLIT && p.KT % (ks * 8) == 0) p.ksplit = ks;
+      }
+    }
+  }
+  const int per = p.KT / p.ksplit;
+  int ktw = 16;
+  while (ktw > 2 && per % (4 * ktw) != 0) ktw >>= 1;
+  p.nchunk = per / (4 * ktw);
+  return p;
+}
+
+const RawTensor* find_raw(vc_engine* e, const std::string& key) {
+  auto it = e->raw.find(key);
+  return it == e->raw.end() ? nullptr : &it->second;
+}
+
+int need(vc_engine* e, const std::string& key, std::initializer_list<int64_t> shape, const RawTensor** out) {
+  const RawTensor* t = find_raw(e, key);
+  if (!t) return fail(e, VC_EMISSING, "weight '%s' was never loaded", key.c_str());
+  std::vector<int64_t> want(shape);
+  if (t->shape != want) {
+    std::string got, exp;
+    for (auto v : t->shape) got += std::to_string(v) + ",";
+    for (auto v : want) exp += std::to_string(v) + ",";
+    return fail(e, VC_EINVAL, "weight '%s' has shape [%s] but the config implies [%s]", key.c_str(), got.c_str(), exp.c_str());
+  }
+  *out = t;
+  return VC_OK;
+}
+
+int pack_matrix(vc_engine* e, const std::string& key, int N, int Kdim, uint4** out) {
+  const RawTensor* t;
+  int rc = need(e, key, {N, Kdim}, &t);
+  if (rc) return rc;
+  const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
+  const long units = (long)((N + 15) / 16) * (Kdim / KW) * 64;
+  rc = dalloc(e, out, (size_t)units);
+  if (rc) return rc;
+  HIPCHK(e, vc_launch_pack(t->dev, *out, N, Kdim, e->dtype, 0));
+  return VC_OK;
+}
+
+int keep_vec(vc_engine* e, const std::string& key, int n, float** out) {
+  const RawTensor* t;
+  int rc = need(e, key, {n}, &t);
+  if (rc) return rc;
+  rc = dalloc(e, out, (size_t)n);
+  if (rc) return rc;
+  HIPCHK(e, hipMemcpy(*out, t->dev, (size_t)n * 4, hipMemcpyDeviceToDevice));
+  return VC_OK;
+}
+
+// ---------------------------------------------------------------- one forward pass over <= 16 rows
+struct RowSrc {
+  const float* h_in;
+  const int* row_seq;
+  const int* row_pos;
+  const int* n_rows_ptr;
+  int n_rows;       // rows carried (upper bound when n_rows_ptr is set)
+  int nsplit;
+  const int* n_active;
+};
+
+GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdim) {
+  GemmArgs g;
+  memset(&g, 0, sizeof g);
+  g.N = N; g.K = Kdim; g.n_tiles = p.n_tiles; g.KT = p.KT; g.nchunk = p.nchunk;
+  g.r_lds = rs.n_rows;
+  g.row_seq = rs.row_seq; g.row_pos = rs.row_pos; g.n_rows_ptr = rs.n_rows_ptr; g.n_rows = rs.n_rows;
+  g.n_active = rs.n_active;
+  g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
+  g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+  return g;
+}
+
+int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
+  const int d = e->d;
+  for (int l = 0; l < e->L; ++l) {
+    Layer& ly = e->layers[l];
+    {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache
+      GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
+      g.Wp = ly.Wqkv; g.bias = ly.bqkv;
+      g.h_in = (l == 0) ? rs.h_in : e->hB;
+      g.h_out = e->hA;
+      g.parts = (l == 0) ? nullptr : e->parts;
+      g.n_parts = (l == 0) ? 0 : e->p_f2.ksplit;
+      g.prev_bias = (l == 0) ? nullptr : e->layers[l - 1].b2;
+      g.ln_w = ly.ln1w; g.ln_b = ly.ln1b;
+      g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
+    }
+    {
+      AttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc;
+      a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit;
+      a.scale = 1.0f / sqrtf((float)e->hd);
+      a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows_ptr = rs.n_rows_ptr; a.n_rows = rs.n_rows;
+      a.n_active = rs.n_active;
+      a.att_o = e->att_o; a.att_ml = e->att_ml;
+      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
+    }
+    {  // out-projection of the merged attention output -> split-K partial slabs
+      GemmArgs g = base_args(e, rs, e->p_o, d, d);
+      g.Wp = ly.Wo;
+      g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
+      g.part_out = e->parts;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+    }
+    {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)
+      GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
+      g.Wp = ly.W1; g.bias = ly.b1;
+      g.h_in = e->hA; g.h_out = e->hB;
+      g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo;
+      g.ln_w = ly.ln2w; g.ln_b = ly.ln2b;
+      g.out = e->act; g.out_ld = 4 * d;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
+    }
+    {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
+      GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
+      g.Wp = ly.W2;
+      g.x_in = e->act; g.x_ld = 4 * d;
+      g.part_out = e->parts;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
+    }
+  }
+  return VC_OK;
+}
+
+// final LayerNorm + the K prediction heads (voicecraft.py:181-185, :1084-1086) for n rows;
+// row r reads hidden row gather[r] and writes logits row (out_row0 + r).
+int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s) {
+  RowSrc rs{};
+  rs.n_rows = n; rs.n_active = n_active;
+  {
+    GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
+    g.Wp = e->Wh1; g.bias = e->bh1;
+    g.h_in = e->hB; g.h_out = nullptr;
+    g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2;
+    g.ln_w = e->lnf_w; g.ln_b = e->lnf_b; g.gather_rows = gather;
+    g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, s));
+  }
+  {
+    GemmArgs g = base_args(e, rs, e->p_h2, e->V, e->P);
+    g.Wp = e->Wh2; g.bias = e->bh2;
+    g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
+    g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
+    g.out = e->logits + (size_t)out_row0 * e->K * e->V;
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
+  }
+  return VC_OK;
+}
+
+int attn_nsplit(vc_engine* e, int rows) {
+  int ns = 512 / std::max(1, rows * e->H);
+  return std::max(1, std::min(ns, VC_MAX_NSPLIT));
+}
+
+// Prefill of one sequence slot: prompt rows -> emb, then 16-row passes; heads on the last row.
+int prefill_seq(vc_engine* e, PromptArgs& pa, int slot, hipStream_t s) {
+  const int rows = pa.Lx + pa.n_cols;
+  pa.seq = slot; pa.row0 = 0;
+  pa.emb = e->emb; pa.row_seq = e->pre_row_seq; pa.row_pos = e->pre_row_pos; pa.err = e->err_flag;
+  pa.logit_row = e->logit_row + slot;
+  pa.logit_row_val = (rows - 1) % VC_ROWS;
+  HIPCHK(e, vc_launch_prompt(pa, s));
+  for (int r0 = 0; r0 < rows; r0 += VC_ROWS) {
+    RowSrc rs{};
+    rs.h_in = e->emb + (size_t)r0 * e->d;
+    rs.row_seq = e->pre_row_seq + r0; rs.row_pos = e->pre_row_pos + r0;
+    rs.n_rows = std::min(VC_ROWS, rows - r0);
+    rs.nsplit = attn_nsplit(e, rs.n_rows);
+    int rc = forward_rows(e, rs, s);
+    if (rc) return rc;
+  }
+  return run_heads(e, e->logit_row + slot, 1, slot, nullptr, s);
+}
+
+void fill_prompt_common(vc_engine* e, PromptArgs& pa, const int64_t* x, int Lx, const int64_t* y, int T) {
+  memset(&pa, 0, sizeof pa);
+  pa.x = x; pa.y = y; pa.Lx = Lx; pa.T = T; pa.K = e->K; pa.d = e->d; pa.V = e->V;
+  pa.empty_token = e->cfg.empty_token;
+  pa.text_emb = e->text_emb; pa.audio_emb = e->audio_emb; pa.mask_emb = e->mask_emb; pa.pe = e->pe;
+  pa.alpha_text = e->alpha_text; pa.alpha_audio = e->alpha_audio;
+  pa.text_rows = e->cfg.text_rows;
+}
+
+SampleArgs make_sample_args(vc_engine* e, const vc_sample_cfg* sc, int B, int rps) {
+  SampleArgs a;
+  memset(&a, 0, sizeof a);
+  a.logits = e->logits; a.B = B; a.K = e->K; a.V = e->V; a.d = e->d;
+  a.top_k = sc->top_k; a.top_p = sc->top_p; a.temperature = sc->temperature;
+  a.stop_repetition = sc->stop_repetition;
+  a.n_silence = std::max(0, std::min(sc->n_silence, VC_MAX_SILENCE));
+  for (int i = 0; i < a.n_silence; ++i) a.silence[i] = sc->silence_tokens[i];
+  a.seed = sc->seed; a.empty_token = e->cfg.empty_token;
+  a.st = e->st; a.n_active = e->n_active; a.samp = e->samp; a.cond = e->cond; a.amax = e->amax;
+  a.gen = e->gen; a.max_steps = e->gen_cap;
+  a.rps = rps; a.dec_h = e->dec_h; a.row_seq = e->dec_row_seq; a.row_pos = e->dec_row_pos;
+  a.logit_row = e->logit_row;
+  a.audio_emb = e->audio_emb; a.mask_emb = e->mask_emb; a.pe = e->pe; a.alpha_audio = e->alpha_audio;
+  a.max_positions = e->S_max;
+  return a;
+}
+
+int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, hipStream_t s) {
+  RowSrc rs{};
+  rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
+  rs.n_rows = B * rps; rs.nsplit = attn_nsplit(e, B * rps); rs.n_active = e->n_active;
+  int rc = forward_rows(e, rs, s);
+  if (rc) return rc;
+  rc = run_heads(e, e->logit_row, B, 0, e->n_active, s);
+  if (rc) return rc;
+  HIPCHK(e, vc_launch_sample(sa, grouped, s));
+  return VC_OK;
+}
+
+// The decode loop: every step is the same launch sequence (all step-dependent values live in
+// HBM), so it is captured once per call and replayed; the host only polls the active counter.
+int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, const vc_sample_cfg* sc,
+                int max_steps, int* steps_run, hipStream_t s) {
+  const int poll = sc->poll_every > 0 ? sc->poll_every : 16;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  if (sc->use_graph) {
+    HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    int rc = decode_step(e, sa, B, rps, grouped, s);
+    hipError_t ce = hipStreamEndCapture(s, &graph);
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    HIPCHK(e, ce);
+    HIPCHK(e, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+  }
+  int done_steps = 0, rc = VC_OK;
+  while (done_steps < max_steps) {
+    const int n = std::min(poll, max_steps - done_steps);
+    for (int i = 0; i < n && rc == VC_OK; ++i) {
+      if (exec) {
+        hipError_t le = hipGraphLaunch(exec, s);
+        if (le != hipSuccess) rc = fail(e, VC_EHIP, "hipGraphLaunch failed: %s", hipGetErrorString(le));
+      } else {
+        rc = decode_step(e, sa, B, rps, grouped, s);
+      }
+    }
+    if (rc) break;
+    done_steps += n;
+    hipError_t me = hipMemcpyAsync(e->h_flag, e->n_active, sizeof(int), hipMemcpyDeviceToHost, s);
+    if (me == hipSuccess) me = hipStreamSynchronize(s);
+    if (me != hipSuccess) { rc = fail(e, VC_EHIP, "poll failed: %s", hipGetErrorString(me)); break; }
+    if (*e->h_flag <= 0) break;
+  }
+  if (exec) hipGraphExecDestroy(exec);
+  if (graph) hipGraphDestroy(graph);
+  if (steps_run) *steps_run = done_steps;
+  return rc;
+}
+
+SeqState init_state(vc_engine* e, int Lx, int n_cols, bool tts, int n_spans) {
+  SeqState st;
+  memset(&st, 0, sizeof st);
+  st.Lx = Lx; st.y_len = n_cols; st.prev_token = -1; st.n_spans = n_spans; st.kept = 1; st.group = -1;
+  const vc_model_cfg& c = e->cfg;
+  if (tts) {
+    st.cap_len = Lx * (c.encodec_sr / 5);                 // voicecraft.py:1042
+    st.min_gen = c.encodec_sr / 5;                        // :1024
+    st.term_token = c.eos > 0 ? c.eos : c.eog;            // :938
+    st.kill_token = c.eos > 0 ? c.eog : -1;               // :1091-1093
+  } else {
+    st.cap_len = Lx * 10;                                 // :751
+    st.min_gen = -1;
+    st.term_token = c.eog;
+    st.kill_token = c.eos > 0 ? c.eos : -1;               // :816-818
+  }
+  return st;
+}
+
+int check_ready(vc_engine* e) {
+  if (!e) return VC_EINVAL;
+  if (!e->finalized) return fail(e, VC_ESTATE, "weights are not finalized (call vc_finalize_weights)");
+  hipError_t err = hipSetDevice(e->device);
+  if (err != hipSuccess) return fail(e, VC_EHIP, "hipSetDevice: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
+int check_err_flag(vc_engine* e, hipStream_t s) {
+  HIPCHK(e, hipMemcpyAsync(e->h_flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  if (*e->h_flag) {
+    hipMemsetAsync(e->err_flag, 0, sizeof(int), s);
+    return fail(e, VC_EINVAL, "token id out of range in x or y (text rows %d, audio vocab %d)", e->cfg.text_rows, e->V);
+  }
+  return VC_OK;
+}
+
+}  // namespace
+
+// =====================================================================================  C ABI
+extern "C" const char* vc_version(void) { return "vcengine 0.1 (gfx950)"; }
+
+extern "C" const char* vc_last_error(const vc_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
+
+extern "C" int vc_create(const vc_model_cfg* c, int hip_device, vc_engine** out) {
+  if (!c || !out) return fail(nullptr, VC_EINVAL, "null argument");
+  *out = nullptr;
+  if (c->d_model <= 0 || c->d_model % 256 || c->d_model > 2048)
+    return fail(nullptr, VC_EINVAL, "d_model %d must be a multiple of 256 and <= 2048", c->d_model);
+  if (c->nhead <= 0 || c->d_model % c->nhead) return fail(nullptr, VC_EINVAL, "nhead %d does not divide d_model", c->nhead);
+  const int hd = c->d_model / c->nhead;
+  if (hd % 32 || hd > 128) return fail(nullptr, VC_EINVAL, "head_dim %d must be 32, 64, 96 or 128", hd);
+  if ((hd & (hd - 1)) != 0) return fail(nullptr, VC_EINVAL, "head_dim %d must be a power of two", hd);
+  if (c->n_codebooks < 1 || c->n_codebooks > VC_MAX_CODEBOOKS) return fail(nullptr, VC_EINVAL, "n_codebooks %d unsupported", c->n_codebooks);
+  const int V = c->audio_vocab_size + c->n_special;
+  if (V > 64 * VC_VPL) return fail(nullptr, VC_EINVAL, "audio vocabulary %d too large (max %d)", V, 64 * VC_VPL);
+  if (c->head_hidden % 256) return fail(nullptr, VC_EINVAL, "head_hidden %d must be a multiple of 256", c->head_hidden);
+  if (c->empty_token != c->audio_vocab_size || c->eog != c->audio_vocab_size + 1 ||
+      c->audio_pad_token != c->audio_vocab_size + 2)   // voicecraft.py:132-134
+    return fail(nullptr, VC_EINVAL, "special tokens must be empty=V, eog=V+1, pad=V+2");
+  if (c->eos >= V || c->eog >= V) return fail(nullptr, VC_EINVAL, "eos/eog outside the vocabulary");
+  if (c->max_seqs < 1 || c->max_seqs > VC_ROWS) return fail(nullptr, VC_EINVAL, "max_seqs must be in [1,%d]", VC_ROWS);
+  if (c->max_positions < 32) return fail(nullptr, VC_EINVAL, "max_positions too small");
+  if (c->max_n_spans < 1 || c->max_n_spans > VC_MAX_SPANS) return fail(nullptr, VC_EINVAL, "max_n_spans unsupported");
+  hipError_t err = hipSetDevice(hip_device);
+  if (err != hipSuccess) return fail(nullptr, VC_EHIP, "hipSetDevice(%d): %s", hip_device, hipGetErrorString(err));
+  vc_engine* e = new vc_engine();
+  e->cfg = *c; e->device = hip_device;
+  e->d = c->d_model; e->H = c->nhead; e->hd = hd; e->L = c->num_layers; e->K = c->n_codebooks;
+  e->V = V; e->P = c->head_hidden; e->S_max = c->max_positions; e->B_max = c->max_seqs;
+  *out = e;
+  return VC_OK;
+}
+
+extern "C" void vc_destroy(vc_engine* e) {
+  if (!e) return;
+  hipSetDevice(e->device);
+  hipDeviceSynchronize();
+  for (auto& kv : e->raw) if (kv.second.dev) hipFree(kv.second.dev);
+  for (void* p : e->allocs) hipFree(p);
+  if (e->h_st) hipHostFree(e->h_st);
+  if (e->h_flag) hipHostFree(e->h_flag);
+  for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
+  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  delete e;
+}
+
+extern "C" int vc_load_tensor(vc_engine* e, const char* key, const void* data, int on_device, int dtype,
+                              const int64_t* shape, int ndim) {
+  if (!e || !key || !data || ndim < 0 || ndim > 4) return fail(e, VC_EINVAL, "bad argument to vc_load_tensor");
+  if (e->finalized) return fail(e, VC_ESTATE, "weights already finalized");
+  if (dtype != VC_DTYPE_F32) return VC_OK;   // eog / eos buffers (int64) carry no information we need
+  HIPCHK(e, hipSetDevice(e->device));
+  RawTensor t;
+  t.numel = 1;
+  for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.numel *= shape[i]; }
+  if (t.numel <= 0) return fail(e, VC_EINVAL, "empty tensor '%s'", key);
+  auto it = e->raw.find(key);
+  if (it != e->raw.end()) { hipFree(it->second.dev); e->raw.erase(it); }
+  HIPCHK(e, hipMalloc((void**)&t.dev, (size_t)t.numel * 4));
+  HIPCHK(e, hipMemcpy(t.dev, data, (size_t)t.numel * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  e->raw[key] = t;
+  return VC_OK;
+}
+
+extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
+  if (!e) return VC_EINVAL;
+  if (e->finalized) return fail(e, VC_ESTATE, "already finalized");
+  if (compute_dtype != VC_DTYPE_BF16 && compute_dtype != VC_DTYPE_F32) return fail(e, VC_EINVAL, "compute dtype must be bf16 or f32");
+  HIPCHK(e, hipSetDevice(e->device));
+  e->dtype = compute_dtype;
+  e->esz = compute_dtype == VC_DTYPE_BF16 ? 2 : 4;
+  const int d = e->d, L = e->L, K = e->K, V = e->V, P = e->P;
+  int rc;
+  const RawTensor* t;
+  // ---- embeddings (kept fp32: a handful of row gathers per step)
+  if ((rc = need(e, "text_embedding.word_embeddings.weight", {e->cfg.text_rows, d}, &t))) return rc;
+  if ((rc = dalloc(e, &e->text_emb, (size_t)t->numel))) return rc;
+  HIPCHK(e, hipMemcpy(e->text_emb, t->dev, (size_t)t->numel * 4, hipMemcpyDeviceToDevice));
+  if ((rc = dalloc(e, &e->audio_emb, (size_t)K * V * d))) return rc;
+  for (int k = 0; k < K; ++k) {
+    if ((rc = need(e, "audio_embedding." + std::to_string(k) + ".word_embeddings.weight", {V, d}, &t))) return rc;
+    HIPCHK(e, hipMemcpy(e->audio_emb + (size_t)k * V * d, t->dev, (size_t)V * d * 4, hipMemcpyDeviceToDevice));
+  }
+  if ((rc = need(e, "mask_embedding", {e->cfg.max_n_spans, d}, &t))) return rc;
+  if ((rc = dalloc(e, &e->mask_emb, (size_t)t->numel))) return rc;
+  HIPCHK(e, hipMemcpy(e->mask_emb, t->dev, (size_t)t->numel * 4, hipMemcpyDeviceToDevice));
+  if ((rc = need(e, "text_positional_embedding.alpha", {1}, &t))) return rc;
+  HIPCHK(e, hipMemcpy(&e->alpha_text, t->dev, 4, hipMemcpyDeviceToHost));
+  if ((rc = need(e, "audio_positional_embedding.alpha", {1}, &t))) return rc;
+  HIPCHK(e, hipMemcpy(&e->alpha_audio, t->dev, 4, hipMemcpyDeviceToHost));
+  // ---- sinusoidal table (embedding.py:69-92).  "pe" may be supplied by the loader (torch's own
+  // sin/cos); otherwise it is computed here in fp32 with the same formula.
+  if ((rc = dalloc(e, &e->pe, (size_t)e->S_max * d))) return rc;
+  if (const RawTensor* pt = find_raw(e, "pe")) {
+    if (pt->shape.size() != 2 || pt->shape[0] < e->S_max || pt->shape[1] != d)
+      return fail(e, VC_EINVAL, "'pe' must be [>=%d][%d]", e->S_max, d);
+    HIPCHK(e, hipMemcpy(e->pe, pt->dev, (size_t)e->S_max * d * 4, hipMemcpyDeviceToDevice));
+  } else {
+    std::vector<float> pe((size_t)e->S_max * d);
+    for (int i = 0; i < d; i += 2) {
+      const float div = expf((float)i * -(logf(10000.0f) / (float)d));
+      for (int p = 0; p < e->S_max; ++p) {
+        const float a = (float)p * div;
+        pe[(size_t)p * d + i] = sinf(a);
+        pe[(size_t)p * d + i + 1] = cosf(a);
+      }
+    }
+    HIPCHK(e, hipMemcpy(e->pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
+  }
+  // ---- decoder layers
+  e->layers.resize(L);
+  for (int l = 0; l < L; ++l) {
+    const std::string pre = "decoder.layers." + std::to_string(l) + ".";
+    Layer& ly = e->layers[l];
+    if ((rc = pack_matrix(e, pre + "self_attn.in_proj_weight", 3 * d, d, &ly.Wqkv))) return rc;
+    if ((rc = keep_vec(e, pre + "self_attn.in_proj_bias", 3 * d, &ly.bqkv))) return rc;
+    if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo))) return rc;
+    if ((rc = keep_vec(e, pre + "self_attn.out_proj.bias", d, &ly.bo))) return rc;
+    if ((rc = pack_matrix(e, pre + "linear1.weight", 4 * d, d, &ly.W1))) return rc;
+    if ((rc = keep_vec(e, pre + "linear1.bias", 4 * d, &ly.b1))) return rc;
+    if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W2))) return rc;
+    if ((rc = keep_vec(e, pre + "linear2.bias", d, &ly.b2))) return rc;
+    if ((rc = keep_vec(e, pre + "norm1.weight", d, &ly.ln1w))) return rc;
+    if ((rc = keep_vec(e, pre + "norm1.bias", d, &ly.ln1b))) return rc;
+    if ((rc = keep_vec(e, pre + "norm2.weight", d, &ly.ln2w))) return rc;
+    if ((rc = keep_vec(e, pre + "norm2.bias", d, &ly.ln2b))) return rc;
+    const size_t cache_bytes = (size_t)e->B_max * e->H * e->S_max * e->hd * e->esz;
+    char* kc; char* vc;
+    if ((rc = dalloc(e, &kc, cache_bytes))) return rc;
+    if ((rc = dalloc(e, &vc, cache_bytes))) return rc;
+    ly.kc = kc; ly.vc = vc;
+    // free the staging copies of this layer right away (3.3 GB for the 830M shape otherwise)
+    for (const char* k2 : {"self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"}) {
+      auto it = e->raw.find(pre + k2);
+      if (it != e->raw.end()) { hipDeviceSynchronize(); hipFree(it->second.dev); e->raw.erase(it); }
+    }
+  }
+  if ((rc = keep_vec(e, "decoder.norm.weight", d, &e->lnf_w))) return rc;
+  if ((rc = keep_vec(e, "decoder.norm.bias", d, &e->lnf_b))) return rc;
+  // ---- heads: first linears concatenated to one [K*P][d] matrix, second ones one group each
+  {
+    float* cat;
+    HIPCHK(e, hipMalloc((void**)&cat, (size_t)K * P * d * 4));
+    if ((rc = dalloc(e, &e->bh1, (size_t)K * P))) { hipFree(cat); return rc; }
+    for (int k = 0; k < K; ++k) {
+      const std::string pre = "predict_layer." + std::to_string(k) + ".";
+      if ((rc = need(e, pre + "0.weight", {P, d}, &t))) { hipFree(cat); return rc; }
+      hipMemcpy(cat + (size_t)k * P * d, t->dev, (size_t)P * d * 4, hipMemcpyDeviceToDevice);
+      if ((rc = need(e, pre + "0.bias", {P}, &t))) { hipFree(cat); return rc; }
+      hipMemcpy(e->bh1 + (size_t)k * P, t->dev, (size_t)P * 4, hipMemcpyDeviceToDevice);
+    }
+    const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
+    const long units = (long)(K * P / 16) * (d / KW) * 64;
+    if ((rc = dalloc(e, &e->Wh1, (size_t)units))) { hipFree(cat); return rc; }
+    hipError_t pe_ = vc_launch_pack(cat, e->Wh1, K * P, d, e->dtype, 0);
+    hipDeviceSynchronize();
+    hipFree(cat);
+    HIPCHK(e, pe_);
+    const long gunits = (long)((V + 15) / 16) * (P / KW) * 64;
+    e->wh2_group_stride = gunits;
+    if ((rc = dalloc(e, &e->Wh2, (size_t)gunits * K))) return rc;
+    if ((rc = dalloc(e, &e->bh2, (size_t)K * V))) return rc;
+    for (int k = 0; k < K; ++k) {
+      const std::string pre = "predict_layer." + std::to_string(k) + ".";
+      if ((rc = need(e, pre + "2.weight", {V, P}, &t))) return rc;
+      HIPCHK(e, vc_launch_pack(t->dev, e->Wh2 + (size_t)k * gunits, V, P, e->dtype, 0));
+      if ((rc = need(e, pre + "2.bias", {V}, &t))) return rc;
+      HIPCHK(e, hipMemcpy(e->bh2 + (size_t)k * V, t->dev, (size_t)V * 4, hipMemcpyDeviceToDevice));
+    }
+  }
+  HIPCHK(e, hipDeviceSynchronize());
+  for (auto& kv : e->raw) if (kv.second.dev) hipFree(kv.second.dev);
+  e->raw.clear();
+  // ---- launch plans
+  e->p_qkv = make_plan(3 * d, d, e->dtype, false, nullptr);
+  e->p_o = make_plan(d, d, e->dtype, true, "VC_KSPLIT_O");
+  e->p_f1 = make_plan(4 * d, d, e->dtype, false, nullptr);
+  e->p_f2 = make_plan(d, 4 * d, e->dtype, true, "VC_KSPLIT_F");
+  e->p_h1 = make_plan(K * P, d, e->dtype, false, nullptr);
+  e->p_h2 = make_plan(V, P, e->dtype, false, nullptr);
+  // ---- scratch arenas
+  if ((rc = dalloc(e, &e->emb, (size_t)e->S_max * d))) return rc;
+  if ((rc = dalloc(e, &e->pre_row_seq, (size_t)e->S_max + VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->pre_row_pos, (size_t)e->S_max + VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->hA, (size_t)VC_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->hB, (size_t)VC_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->q, (size_t)VC_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->parts, (size_t)VC_MAX_KSPLIT * VC_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->att_o, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * e->hd))) return rc;
+  if ((rc = dalloc(e, &e->att_ml, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * 2))) return rc;
+  char* tmp;
+  if ((rc = dalloc(e, &tmp, (size_t)VC_ROWS * 4 * d * e->esz))) return rc;
+  e->act = tmp;
+  if ((rc = dalloc(e, &tmp, (size_t)VC_ROWS * K * P * e->esz))) return rc;
+  e->hh = tmp;
+  if ((rc = dalloc(e, &e->logits, (size_t)VC_ROWS * K * V))) return rc;
+  if ((rc = dalloc(e, &e->dec_h, (size_t)VC_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->dec_row_seq, (size_t)VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->dec_row_pos, (size_t)VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->logit_row, (size_t)VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->st, (size_t)VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
+  if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
+  if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * VC_MAX_CODEBOOKS))) return rc;
+  if ((rc = dalloc(e, &e->cond, (size_t)VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->amax, (size_t)VC_ROWS))) return rc;
+  e->gen_cap = e->S_max;
+  if ((rc = dalloc(e, &e->gen, (size_t)e->B_max * e->gen_cap * K))) return rc;
+  HIPCHK(e, hipMemset(e->err_flag, 0, 16));
+  HIPCHK(e, hipMemset(e->n_active, 0, 16));
+  HIPCHK(e, hipHostMalloc((void**)&e->h_st, sizeof(SeqState) * VC_ROWS));
+  HIPCHK(e, hipHostMalloc((void**)&e->h_flag, 64));
+  for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
+  // a blocking stream: implicitly ordered after work the caller queued on the null stream
+  HIPCHK(e, hipStreamCreate(&e->own_stream));
+  HIPCHK(e, hipDeviceSynchronize());
+  e->finalized = true;
+  return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------- TTS
+namespace {
+
+struct TtsJob { const int64_t* x; int Lx; const int64_t* y; int T; };
+
+// Shared by vc_tts (one prompt, n_samples >= 1) and vc_tts_multi (B prompts).
+int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const vc_sample_cfg* sc,
+            const int64_t* forced, int n_forced, float* logits_out, int logit_steps, int* steps_out,
+            hipStream_t s) {
+  const int K = e->K;
+  const bool grouped = n_samples > 1;
+  const int B = grouped ? n_samples : (int)jobs.size();
+  if (B > e->B_max) return fail(e, VC_ECAP, "%d sequences requested but max_seqs is %d", B, e->B_max);
+  int max_steps = 0;
+  for (int b = 0; b < (int)jobs.size(); ++b) {
+    const TtsJob& j = jobs[b];
+    if (j.Lx < 1 || j.T < 0) return fail(e, VC_EINVAL, "empty text or negative prompt length");
+    const int n_cols = j.T + 1;                           // T+K columns minus the K-1 dropped ones (:967)
+    const int cap_len = j.Lx * (e->cfg.encodec_sr / 5);
+    const int steps = std::max(0, cap_len - n_cols + 1) + K;
+    if (j.Lx + n_cols + steps + 1 > e->S_max)
+      return fail(e, VC_ECAP, "sequence %d needs %d positions but max_positions is %d", b, j.Lx + n_cols + steps + 1, e->S_max);
+    max_steps = std::max(max_steps, steps);
+  }
+  if (max_steps > e->gen_cap) return fail(e, VC_ECAP, "generation buffer too small");
+  HIPCHK(e, hipEventRecord(e->ev[0], s));
+  // ---- prompt + prefill per job; best-of-N prefills once and replicates the cache
+  for (int b = 0; b < (int)jobs.size(); ++b) {
+    const TtsJob& j = jobs[b];
+    PromptArgs pa;
+    fill_prompt_common(e, pa, j.x, j.Lx, j.y, j.T);
+    pa.n_seg = 1; pa.n_cols = j.T + 1;
+    pa.seg[0] = Segment{0, j.T + 1, 0, j.T, -1, -1};
+    int rc = prefill_seq(e, pa, b, s);
+    if (rc) return rc;
+    SeqState st = init_state(e, j.Lx, j.T + 1, true, 1);
+    e->h_st[b] = st;
+  }
+  if (grouped) {
+    const TtsJob& j = jobs[0];
+    for (int l = 0; l < e->L; ++l) {
+      const long stride = (long)e->H * e->S_max * e->hd;
+      HIPCHK(e, vc_launch_copy_kv(e->layers[l].kc, stride, e->H, e->S_max, e->hd, j.Lx + j.T + 1, 0, 1, B - 1, e->dtype, s));
+      HIPCHK(e, vc_launch_copy_kv(e->layers[l].vc, stride, e->H, e->S_max, e->hd, j.Lx + j.T + 1, 0, 1, B - 1, e->dtype, s));
+    }
+    for (int b = 1; b < B; ++b) {   // every sample starts from the same first-step logits
+      HIPCHK(e, hipMemcpyAsync(e->logits + (size_t)b * K * e->V, e->logits, (size_t)K * e->V * 4, hipMemcpyDeviceToDevice, s));
+      e->h_st[b] = e->h_st[0];
+    }
+    for (int b = 0; b < B; ++b) e->h_st[b].group = 0;
+  }
+  HIPCHK(e, hipMemcpyAsync(e->st, e->h_st, sizeof(SeqState) * B, hipMemcpyHostToDevice, s));
+  e->h_flag[1] = B;
+  HIPCHK(e, hipMemcpyAsync(e->n_active, e->h_flag + 1, sizeof(int), hipMemcpyHostToDevice, s));
+  int rc = check_err_flag(e, s);   // also orders the pinned-buffer reuse
+  if (rc) return rc;
+  // ---- first sample comes from the prefill logits, then the decode loop
+  SampleArgs sa = make_sample_args(e, sc, B, 1);
+  sa.forced = forced; sa.n_forced = forced ? n_forced : 0;
+  sa.logits_out = logits_out; sa.logit_steps = logits_out ? logit_steps : 0;
+  HIPCHK(e, vc_launch_sample(sa, grouped, s));
+  HIPCHK(e, hipEventRecord(e->ev[1], s));
+  int steps_run = 0;
+  rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s);
+  if (rc) return rc;
+  HIPCHK(e, hipEventRecord(e->ev[2], s));
+  HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
+  HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
+  e->ms[2] = e->ms[0] + e->ms[1];
+  if (steps_out) *steps_out = steps_run;
+  return VC_OK;
+}
+
+int assemble_tts(vc_engine* e, const TtsJob& j, int slot, int64_t* res, int res_cap, int* gen_len, hipStream_t s) {
+  const SeqState& st = e->h_st[slot];
+  if (!st.done || st.span < 1) return fail(e, VC_ECAP, "generation did not terminate within the step budget");
+  const int N = st.span_steps[0];
+  const int Tg = N - e->K;                                  // voicecraft.py:1137
+  if (Tg < 0) return fail(e, VC_ESTATE, "internal: span of %d steps", N);
+  if (j.T + Tg > res_cap) return fail(e, VC_ECAP, "res capacity %d < %d", res_cap, j.T + Tg);
+  AssembleArgs a;
+  memset(&a, 0, sizeof a);
+  a.y = j.y; a.gen = e->gen + (size_t)slot * e->gen_cap * e->K; a.K = e->K; a.T = j.T; a.res_cap = res_cap; a.res = res;
+  a.n_piece = 0;
+  if (j.T > 0) { a.kind[a.n_piece] = 0; a.src0[a.n_piece] = 0; a.len[a.n_piece] = j.T; a.dst0[a.n_piece] = 0; a.n_piece++; }
+  if (Tg > 0) { a.kind[a.n_piece] = 1; a.src0[a.n_piece] = 0; a.len[a.n_piece] = Tg; a.dst0[a.n_piece] = j.T; a.n_piece++; }
+  HIPCHK(e, vc_launch_assemble(a, s));
+  *gen_len = Tg;
+  return VC_OK;
+}
+
+}  // namespace
+
+extern "C" int vc_tts(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, int T,
+                      const vc_sample_cfg* sc, int n_samples, const int64_t* forced_dev, int n_forced,
+                      int64_t* res_dev, int res_cap, int* gen_len, float* logits_dev, int logit_steps,
+                      int* n_steps, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (!x_dev || (!y_dev && T > 0) || !sc || !res_dev || !gen_len || n_samples < 1)
+    return fail(e, VC_EINVAL, "null/invalid argument to vc_tts");
+  hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+  std::vector<TtsJob> jobs{TtsJob{x_dev, Lx, y_dev, T}};
+  rc = tts_run(e, jobs, n_samples, sc, forced_dev, n_forced, logits_dev, logit_steps, n_steps, s);
+  if (rc) return rc;
+  int slot = 0;
+  if (n_samples > 1) {
+    slot = -1;
+    for (int b = 0; b < n_samples; ++b) if (e->h_st[b].kept && e->h_st[b].done && e->h_st[b].span >= 1) slot = b;
+    if (slot < 0) return fail(e, VC_ECAP, "no sample terminated within the step budget");
+  }
+  rc = assemble_tts(e, jobs[0], slot, res_dev, res_cap, gen_len, s);
+  if (rc) return rc;
+  HIPCHK(e, hipStreamSynchronize(s));
+  return VC_OK;
+}
+
+extern "C" int vc_tts_multi(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_off,
+                            const int64_t* y_dev, const int32_t* y_off, const vc_sample_cfg* sc,
+                            int64_t* res_dev, int res_cap, int* gen_len, int* n_steps, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (B < 1 || !x_dev || !x_off || !y_dev || !y_off || !sc || !res_dev || !gen_len)
+    return fail(e, VC_EINVAL, "null/invalid argument to vc_tts_multi");
+  hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+  std::vector<TtsJob> jobs;
+  for (int b = 0; b < B; ++b)
+    jobs.push_back(TtsJob{x_dev + x_off[b], x_off[b + 1] - x_off[b], y_dev + (size_t)y_off[b] * e->K, y_off[b + 1] - y_off[b]});
+  rc = tts_run(e, jobs, 1, sc, nullptr, 0, nullptr, 0, n_steps, s);
+  if (rc) return rc;
+  for (int b = 0; b < B; ++b) {
+    rc = assemble_tts(e, jobs[b], b, res_dev + (size_t)b * e->K * res_cap, res_cap, &gen_len[b], s);
+    if (rc) return rc;
+  }
+  HIPCHK(e, hipStreamSynchronize(s));
+  return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------- editing
+extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, int T,
+                       const int32_t* mask_intervals, int M, const int32_t* mask_values,
+                       const vc_sample_cfg* sc, const int64_t* forced_dev, int n_forced,
+                       int64_t* res_dev, int res_cap, int* res_len, float* logits_dev, int logit_steps,
+                       int* n_steps, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (!x_dev || !y_dev || !mask_intervals || !mask_values || !sc || !res_dev || !res_len)
+    return fail(e, VC_EINVAL, "null argument to vc_edit");
+  if (M < 1 || M > e->cfg.max_n_spans || 2 * M + 1 > VC_MAX_SPANS * 2 + 1)
+    return fail(e, VC_EINVAL, "number of spans %d outside [1,%d]", M, e->cfg.max_n_spans);
+  if (Lx < 1 || T < 1) return fail(e, VC_EINVAL, "empty text or audio");
+  hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+  const int K = e->K;
+  const vc_model_cfg& c = e->cfg;
+  if (c.eos > 0 && !c.reduced_eog) return fail(e, VC_EINVAL, "eos > 0 requires reduced_eog (voicecraft.py:244)");
+  // non-mask intervals (voicecraft.py:620-628)
+  std::vector<int> ns(M + 1), ne(M + 1);
+  for (int i = 0; i <= M; ++i) {
+    ns[i] = (i == 0) ? 0 : mask_intervals[2 * (i - 1) + 1];
+    ne[i] = (i == M) ? T : mask_intervals[2 * i];
+    if (ns[i] < 0 || ne[i] > T || ne[i] < ns[i]) return fail(e, VC_EINVAL, "mask intervals must be ordered, disjoint and inside [0,%d]", T);
+  }
+  for (int i = 0; i < M; ++i)
+    if (mask_intervals[2 * i + 1] < mask_intervals[2 * i]) return fail(e, VC_EINVAL, "mask interval %d is reversed", i);
+  for (int i = 0; i < 2 * M; ++i)
+    if (mask_values[i] < 0 || mask_values[i] >= c.max_n_spans) return fail(e, VC_EINVAL, "mask value out of range");
+  // segments of the prefill: every non-mask piece (delay-shifted, K extra columns), a mask
+  // placeholder after each of them, and the first all-empty column of the first masked piece
+  // (rearrange :239-252, shift :254-262, insert_mask :264-288, the cut at :672-679)
+  PromptArgs pa;
+  fill_prompt_common(e, pa, x_dev, Lx, y_dev, T);
+  int col = 0, nseg = 0;
+  for (int i = 0; i <= M; ++i) {
+    int term = -1;
+    if (c.eos > 0) term = (i == M) ? c.eos : -1;
+    else if (c.reduced_eog) term = (i == M) ? c.eog : -1;
+    else term = c.eog;
+    const int n = (ne[i] - ns[i]) + (term >= 0 ? 1 : 0);
+    pa.seg[nseg++] = Segment{col, n + K, ns[i], ne[i] - ns[i], term, -1};
+    col += n + K;
+    pa.seg[nseg++] = Segment{col, 1, 0, 0, -1, mask_values[i]};
+    col += 1;
+  }
+  pa.seg[nseg++] = Segment{col, 1, 0, 0, -1, -1};   // s = 0 of the first masked piece: all `empty`
+  col += 1;
+  pa.n_seg = nseg; pa.n_cols = col;
+  const int cap_len = Lx * 10;
+  const int max_steps = std::max(0, cap_len - col + 1) + M * (K + 4) + 8;
+  if (Lx + col + max_steps + 3 * M + 1 > e->S_max)
+    return fail(e, VC_ECAP, "editing needs %d positions but max_positions is %d", Lx + col + max_steps + 3 * M + 1, e->S_max);
+  if (max_steps > e->gen_cap) return fail(e, VC_ECAP, "generation buffer too small");
+  HIPCHK(e, hipEventRecord(e->ev[0], s));
+  rc = prefill_seq(e, pa, 0, s);
+  if (rc) return rc;
+  SeqState st = init_state(e, Lx, col, false, M);
+  for (int i = 1; i < M; ++i) st.mask_value[i] = mask_values[M + i];   // more_mask_value (:676)
+  e->h_st[0] = st;
+  HIPCHK(e, hipMemcpyAsync(e->st, e->h_st, sizeof(SeqState), hipMemcpyHostToDevice, s));
+  e->h_flag[1] = 1;
+  HIPCHK(e, hipMemcpyAsync(e->n_active, e->h_flag + 1, sizeof(int), hipMemcpyHostToDevice, s));
+  rc = check_err_flag(e, s);
+  if (rc) return rc;
+  const int rps = (M > 1) ? 3 : 1;
+  SampleArgs sa = make_sample_args(e, sc, 1, rps);
+  sa.forced = forced_dev; sa.n_forced = forced_dev ? n_forced : 0;
+  sa.logits_out = logits_dev; sa.logit_steps = logits_dev ? logit_steps : 0;
+  HIPCHK(e, vc_launch_sample(sa, false, s));
+  HIPCHK(e, hipEventRecord(e->ev[1], s));
+  int steps_run = 0;
+  rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, &steps_run, s);
+  if (rc) return rc;
+  HIPCHK(e, hipEventRecord(e->ev[2], s));
+  HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
+  HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
+  e->ms[2] = e->ms[0] + e->ms[1];
+  if (n_steps) *n_steps = steps_run;
+  const SeqState& fs = e->h_st[0];
+  if (!fs.done || fs.span < M) return fail(e, VC_ECAP, "editing did not terminate within the step budget");
+  // res = nonmask_0, gen_0, nonmask_1, gen_1, ..., nonmask_M (voicecraft.py:890-898)
+  AssembleArgs a;
+  memset(&a, 0, sizeof a);
+  a.y = y_dev; a.gen = e->gen; a.K = K; a.T = T; a.res_cap = res_cap; a.res = res_dev;
+  int dst = 0, g0 = 0;
+  for (int i = 0; i <= M; ++i) {
+    if (ne[i] > ns[i]) { int p = a.n_piece++; a.kind[p] = 0; a.src0[p] = ns[i]; a.len[p] = ne[i] - ns[i]; a.dst0[p] = dst; dst += ne[i] - ns[i]; }
+    if (i < M) {
+      const int N = fs.span_steps[i], Tg = N - K;
+      if (Tg < 0) return fail(e, VC_ESTATE, "internal: span of %d steps", N);
+      if (Tg > 0) { int p = a.n_piece++; a.kind[p] = 1; a.src0[p] = g0; a.len[p] = Tg; a.dst0[p] = dst; dst += Tg; }
+      g0 += N;
+    }
+  }
+  if (dst > res_cap) return fail(e, VC_ECAP, "res capacity %d < %d", res_cap, dst);
+  HIPCHK(e, vc_launch_assemble(a, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  *res_len = dst;
+  return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------- hooks
+extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int64_t nbytes) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  const void* src = nullptr;
+  int64_t avail = 0;
+  const std::string n = name ? name : "";
+  if (n == "logits") { src = e->logits; avail = (int64_t)VC_ROWS * e->K * e->V * 4; }
+  else if (n == "hA") { src = e->hA; avail = (int64_t)VC_ROWS * e->d * 4; }
+  else if (n == "hB") { src = e->hB; avail = (int64_t)VC_ROWS * e->d * 4; }
+  else if (n == "q") { src = e->q; avail = (int64_t)VC_ROWS * e->d * 4; }
+  else if (n == "parts") { src = e->parts; avail = (int64_t)VC_MAX_KSPLIT * VC_ROWS * e->d * 4; }
+  else if (n == "emb") { src = e->emb; avail = (int64_t)e->S_max * e->d * 4; }
+  else if (n == "dec_h") { src = e->dec_h; avail = (int64_t)VC_ROWS * e->d * 4; }
+  else if (n == "gen") { src = e->gen; avail = (int64_t)e->B_max * e->gen_cap * e->K * 4; }
+  else if (n == "state") { src = e->st; avail = (int64_t)sizeof(SeqState) * VC_ROWS; }
+  else if (n == "kcache0") { src = e->layers[0].kc; avail = (int64_t)e->B_max * e->H * e->S_max * e->hd * e->esz; }
+  else if (n == "vcache0") { src = e->layers[0].vc; avail = (int64_t)e->B_max * e->H * e->S_max * e->hd * e->esz; }
+  else if (n == "pe") { src = e->pe; avail = (int64_t)e->S_max * e->d * 4; }
+  else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
+  if (nbytes > avail) return fail(e, VC_ECAP, "debug buffer '%s' holds %lld bytes", n.c_str(), (long long)avail);
+  HIPCHK(e, hipDeviceSynchronize());
+  HIPCHK(e, hipMemcpy(host_dst, src, (size_t)nbytes, hipMemcpyDeviceToHost));
+  return VC_OK;
+}
+
+extern "C" int vc_last_timing(const vc_engine* e, float ms[3]) {
+  if (!e || !ms) return VC_EINVAL;
+  ms[0] = e->ms[0]; ms[1] = e->ms[1]; ms[2] = e->ms[2];
+  return VC_OK;
+}
+
+// Times one kernel of the decode step in isolation (HIP events on the launch stream).
+//   which = "ffn1" | "ffn2" | "qkv" | "oproj" : the rows-GEMM of layer (i % L), n_rows rows
+//   which = "step" : one whole decode step (forward + heads, sampler excluded) for n_rows sequences
+extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int iters, float* avg_ms,
+                               double* alg_bytes, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (!which || n_rows < 1 || n_rows > VC_ROWS || iters < 1 || !avg_ms) return fail(e, VC_EINVAL, "bad argument to vc_bench_kernel");
+  hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+  const std::string w = which;
+  const int d = e->d;
+  // neutral rows: sequence 0, positions 0..n_rows-1 (position only matters to attention/caches)
+  std::vector<int> seq(VC_ROWS, 0), pos(VC_ROWS, 0);
+  for (int i = 0; i < VC_ROWS; ++i) pos[i] = i;
+  HIPCHK(e, hipMemcpyAsync(e->dec_row_seq, seq.data(), VC_ROWS * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemcpyAsync(e->dec_row_pos, pos.data(), VC_ROWS * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemsetAsync(e->dec_h, 0, (size_t)VC_ROWS * d * 4, s));
+  HIPCHK(e, hipMemsetAsync(e->hA, 0, (size_t)VC_ROWS * d * 4, s));
+  HIPCHK(e, hipMemsetAsync(e->hB, 0, (size_t)VC_ROWS * d * 4, s));
+  HIPCHK(e, hipMemsetAsync(e->parts, 0, (size_t)VC_MAX_KSPLIT * VC_ROWS * d * 4, s));
+  HIPCHK(e, hipMemsetAsync(e->act, 0, (size_t)VC_ROWS * 4 * d * e->esz, s));
+  HIPCHK(e, hipMemsetAsync(e->att_o, 0, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * e->hd * 4, s));
+  HIPCHK(e, hipMemsetAsync(e->att_ml, 0, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * 2 * 4, s));
+  HIPCHK(e, hipMemsetAsync(e->logit_row, 0, VC_ROWS * 4, s));
+  RowSrc rs{};
+  rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
+  rs.n_rows = n_rows; rs.nsplit = attn_nsplit(e, n_rows);
+  auto one = [&](int i) -> int {
+    Layer& ly = e->layers[i % e->L];
+    if (w == "ffn1") {
+      GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
+      g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
+      g.prev_bias = ly.bo; g.ln_w = ly.ln2w; g.ln_b = ly.ln2b; g.out = e->act; g.out_ld = 4 * d;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
+    } else if (w == "ffn2") {
+      GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
+      g.Wp = ly.W2; g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
+    } else if (w == "qkv") {
+      GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
+      g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.h_in = e->hB; g.h_out = e->hA; g.parts = e->parts; g.n_parts = e->p_f2.ksplit;
+      g.prev_bias = ly.b2; g.ln_w = ly.ln1w; g.ln_b = ly.ln1b; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
+    } else if (w == "oproj") {
+      GemmArgs g = base_args(e, rs, e->p_o, d, d);
+      g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+    } else if (w == "step") {
+      int r = forward_rows(e, rs, s);
+      if (r) return r;
+      return run_heads(e, e->logit_row, n_rows, 0, nullptr, s);
+    } else {
+      return fail(e, VC_EINVAL, "unknown kernel '%s'", which);
+    }
+    return VC_OK;
+  };
+  for (int i = 0; i < 3; ++i) { rc = one(i); if (rc) return rc; }
+  HIPCHK(e, hipEventRecord(e->ev[0], s));
+  for (int i = 0; i < iters; ++i) { rc = one(i); if (rc) return rc; }
+  HIPCHK(e, hipEventRecord(e->ev[1], s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  float ms = 0;
+  HIPCHK(e, hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
+  *avg_ms = ms / (float)iters;
+  if (alg_bytes) {
+    const double es = e->esz;
+    double b = 0;
+    if (w == "ffn1") b = 4.0 * d * d * es + n_rows * (d * 4.0 + 4.0 * d * es);
+    else if (w == "ffn2") b = 4.0 * d * d * es + n_rows * (4.0 * d * es + d * 4.0);
+    else if (w == "qkv") b = 3.0 * d * d * es + n_rows * (d * 4.0 + 3.0 * d * es);
+    else if (w == "oproj") b = 1.0 * d * d * es + n_rows * (d * 4.0 * 2);
+    else b = (double)e->L * (12.0 * d * d + 13.0 * d) * es + 2.0 * d * es +
+             (double)e->K * ((double)d * e->P + e->P + (double)e->P * e->V + e->V) * es;
+    *alg_bytes = b;
+  }
+  return VC_OK;
+}

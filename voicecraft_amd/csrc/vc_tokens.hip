@@ -1,0 +1,465 @@
+// vc_tokens.hip — the integer side of the path: delayed-codebook pattern kernels, prompt
+// construction (+ embedding gather), the device-side sampler / end-of-generation state machine
+// and the output assembly.  Everything here that produces token ids is bit-exact by contract.
+#include "vc_common.h"
+
+// =============================================================== delayed pattern (bit-exact)
+// Closed forms of Pattern.build_pattern_sequence / revert_pattern_sequence for the
+// DelayedPatternProvider(delays = 0..K-1) layout (models/codebooks_patterns.py:117-176,:177-245,
+// :336-352): sequence step s holds (t = s-1-q, q).  One thread per output element; a wave covers
+// 64 consecutive steps of one codebook, so both the load and the store are coalesced.
+__global__ void pattern_shift_k(const int64_t* __restrict__ z, int K, int T, int64_t special,
+                                int64_t* __restrict__ out, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int S = T + K;
+  const int s = (int)(idx % S);
+  const long bq = idx / S;               // b*K + q
+  const int q = (int)(bq % K);
+  const int t = s - 1 - q;
+  out[idx] = (t >= 0 && t < T) ? z[bq * T + t] : special;
+}
+__global__ void pattern_revert_k(const int64_t* __restrict__ sq, int K, int S, int T, int64_t special,
+                                 int64_t* __restrict__ out, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int t = (int)(idx % T);
+  const long bq = idx / T;
+  const int q = (int)(bq % K);
+  const int s = t + 1 + q;
+  out[idx] = (s < S) ? sq[bq * S + s] : special;
+}
+// un-shift of a generated span (models/voicecraft.py:1125-1139): span is step-major [N][K];
+// out[j][t] = span[j + t][j] for t in [0, N-K).
+__global__ void pattern_unshift_k(const int64_t* __restrict__ span, int N, int K,
+                                  int64_t* __restrict__ out) {
+  const int W = N - K;
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)K * W) return;
+  const int j = (int)(idx / W), t = (int)(idx % W);
+  out[idx] = span[(long)(j + t) * K + j];
+}
+
+extern "C" int vc_pattern_shift(const int64_t* z_dev, int B, int K, int T, int64_t special,
+                                int64_t* out_dev, void* stream) {
+  if (!z_dev || !out_dev || B <= 0 || K <= 0 || T < 0) return VC_EINVAL;
+  const long total = (long)B * K * (T + K);
+  hipLaunchKernelGGL(pattern_shift_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, z_dev, K, T, special, out_dev, total);
+  return hipGetLastError() == hipSuccess ? VC_OK : VC_EHIP;
+}
+extern "C" int vc_pattern_revert(const int64_t* s_dev, int B, int K, int S, int T, int64_t special,
+                                 int64_t* out_dev, void* stream) {
+  if (!s_dev || !out_dev || B <= 0 || K <= 0 || S < 0 || T < 0 || S > T + K) return VC_EINVAL;
+  const long total = (long)B * K * T;
+  if (total == 0) return VC_OK;
+  hipLaunchKernelGGL(pattern_revert_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, s_dev, K, S, T, special, out_dev, total);
+  return hipGetLastError() == hipSuccess ? VC_OK : VC_EHIP;
+}
+extern "C" int vc_pattern_unshift(const int64_t* span_dev, int N, int K, int64_t* out_dev,
+                                  void* stream) {
+  if (!span_dev || !out_dev || K <= 0 || N < K) return VC_EINVAL;
+  const long total = (long)K * (N - K);
+  if (total == 0) return VC_OK;
+  hipLaunchKernelGGL(pattern_unshift_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, span_dev, N, K, out_dev);
+  return hipGetLastError() == hipSuccess ? VC_OK : VC_EHIP;
+}
+
+// =============================================================== prompt build + embedding
+// One block per prefill row.  Rows [0,Lx) are phonemes: text_embedding + alpha*pe (voicecraft.py:
+// 950-951).  Rows [Lx, Lx+n_cols) are the rearranged, delay-shifted audio sequence of
+// rearrange/shift/insert_mask/cat_y/embed_y (voicecraft.py:239-320; TTS: :957-985): column c falls
+// in exactly one Segment; a shifted piece of content length n (source frames + optional terminator)
+// contributes columns s = 0..ncols with token(q) = content[s-1-q] or `empty`; a mask placeholder
+// column takes mask_embedding[mask_value] instead of the 4-table sum.  Audio positions restart at 0.
+__global__ __launch_bounds__(256) void prompt_k(const PromptArgs a) {
+  const int row = blockIdx.x;
+  const int d = a.d;
+  float* dst = a.emb + (long)(a.row0 + row) * d;
+  if (threadIdx.x == 0) {
+    a.row_seq[a.row0 + row] = a.seq;
+    a.row_pos[a.row0 + row] = row;
+    if (row == 0 && a.logit_row) *a.logit_row = a.logit_row_val;
+  }
+  if (row < a.Lx) {
+    long tok = a.x[row];
+    if (tok < 0 || tok >= a.text_rows) { if (threadIdx.x == 0) *a.err = 1; tok = 0; }
+    const float* e = a.text_emb + tok * d;
+    const float* pe = a.pe + (long)row * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = e[c] + a.alpha_text * pe[c];
+    return;
+  }
+  const int col = row - a.Lx;
+  int si = 0;
+  for (int i = 0; i < a.n_seg; ++i)
+    if (col >= a.seg[i].col0 && col < a.seg[i].col0 + a.seg[i].ncols) si = i;
+  const Segment sg = a.seg[si];
+  const float* pe = a.pe + (long)col * d;
+  if (sg.mask_value >= 0) {
+    const float* e = a.mask_emb + (long)sg.mask_value * d;
+    for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = e[c] + a.alpha_audio * pe[c];
+    return;
+  }
+  const int s = col - sg.col0;
+  const int n = sg.src_len + (sg.term >= 0 ? 1 : 0);
+  const float* e[VC_MAX_CODEBOOKS];
+  for (int q = 0; q < a.K; ++q) {
+    const int i = s - 1 - q;
+    long tok = a.empty_token;
+    if (i >= 0 && i < n) tok = (i < sg.src_len) ? a.y[(long)(sg.src0 + i) * a.K + q] : sg.term;
+    if (tok < 0 || tok >= a.V) { if (threadIdx.x == 0) *a.err = 1; tok = a.empty_token; }
+    e[q] = a.audio_emb + ((long)q * a.V + tok) * d;
+  }
+  for (int c = threadIdx.x; c < d; c += blockDim.x) {
+    float v = e[0][c];
+    for (int q = 1; q < a.K; ++q) v += e[q][c];       // stack(...).sum(dim=0): k = 0..K-1 in order
+    dst[c] = v + a.alpha_audio * pe[c];
+  }
+}
+hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(prompt_k, dim3(a.Lx + a.n_cols), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// =============================================================== sampler + EOG state machine
+// Philox4x32-10 (Salmon et al. 2011), one uniform per (sequence, step, codebook).
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3,
+                                             uint32_t k0, uint32_t k1) {
+  const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+  const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+  const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+__device__ __forceinline__ float philox_uniform(uint64_t seed, uint32_t seq, uint32_t step, uint32_t cb) {
+  uint32_t c0 = step, c1 = seq, c2 = cb, c3 = 0x5643u;
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  return (float)(c0 >> 8) * (1.0f / 16777216.0f);   // [0, 1)
+}
+
+__device__ __forceinline__ uint32_t fkey(float f) {   // order-preserving float -> uint
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ bool is_silence(const SampleArgs& a, int tok) {
+  bool r = false;
+  for (int i = 0; i < a.n_silence; ++i) r |= (a.silence[i] == tok);
+  return r;
+}
+
+// Phase 1 (one block per sequence, one wave per codebook): logit edits, top-k / top-p filter,
+// categorical draw.  Restates sample_helper + topk_sampling + top_k_top_p_filtering
+// (models/voicecraft.py:1018-1067, :71-86, :26-68).  Writes samp[b][k], cond[b], amax[b].
+__device__ void sample_phase(const SampleArgs& a, int b) {
+  const SeqState st = a.st[b];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (st.done) return;
+  const int step = st.total_steps;
+  for (int k = wave; k < a.K; k += 4) {
+    const float* row = a.logits + ((long)b * a.K + k) * a.V;
+    float v[VC_VPL];
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) {
+      const int i = lane + 64 * j;
+      v[j] = (i < a.V) ? row[i] : -INFINITY;
+    }
+    if (a.logits_out && b == 0 && step < a.logit_steps) {
+      float* lo = a.logits_out + ((long)step * a.K + k) * a.V;
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) {
+        const int i = lane + 64 * j;
+        if (i < a.V) lo[i] = v[j];
+      }
+    }
+    // ---- logit edits, in the reference's order
+    const int term = st.term_token;
+    const bool kill_tl = (st.n_eog == 0) ? (k >= 1) : (k > st.n_eog);            // [term],[empty] on later codebooks
+    const bool kill_t0 = (st.n_eog == 0 && k == 0 && st.min_gen >= 0 && st.cur_num_gen <= st.min_gen);
+    const bool pen = (st.n_eog == 0 && k == 0 && a.stop_repetition > 0 && st.prev_token >= 0 &&
+                      is_silence(a, st.prev_token) && st.consec_silence > a.stop_repetition);
+    const float pen_f = (float)(st.consec_silence - (a.stop_repetition - 1));
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) {
+      const int i = lane + 64 * j;
+      if (i >= a.V) continue;
+      if (i == st.kill_token) v[j] = -10000.f;
+      if (kill_tl && (i == term || i == a.empty_token)) v[j] = -10000.f;
+      if (kill_t0 && i == term) v[j] = -10000.f;
+      if (pen && i == st.prev_token) v[j] = (v[j] < 0.f) ? v[j] * pen_f : v[j] / pen_f;
+    }
+    // ---- argmax of the edited logits (first index on ties, as torch.argmax)
+    float bv = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) {
+      const int i = lane + 64 * j;
+      if (i < a.V && (v[j] > bv || (v[j] == bv && i < bi))) { bv = v[j]; bi = i; }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      const float ov = __shfl_xor(bv, off, 64);
+      const int oi = __shfl_xor(bi, off, 64);
+      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    // ---- temperature
+    if (a.temperature != 1.0f) {
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) v[j] = v[j] / a.temperature;
+    }
+    // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive)
+    if (a.top_k > 0) {
+      const int kk = min(max(a.top_k, 1), a.V);
+      uint32_t t = 0;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = t | (1u << bit);
+        int c = 0;
+#pragma unroll
+        for (int j = 0; j < VC_VPL; ++j) c += (lane + 64 * j < a.V && fkey(v[j]) >= cand) ? 1 : 0;
+        c = wave_sum_i(c);
+        if (c >= kk) t = cand;
+      }
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j)
+        if (fkey(v[j]) < t) v[j] = -INFINITY;
+    }
+    // ---- softmax numerators
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) mx = fmaxf(mx, v[j]);
+    mx = wave_max(mx);
+    float p[VC_VPL];
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) { p[j] = (v[j] == -INFINITY) ? 0.f : expf(v[j] - mx); ps += p[j]; }
+    float tot = wave_sum(ps);
+    // ---- top-p: drop a token when the mass of the strictly larger ones already exceeds top_p
+    if (a.top_p < 1.0f) {
+      const float lim = a.top_p * tot;
+      // find the largest key t with mass(key > t) > lim; keep keys >= t+1 (all keys if none fails)
+      float m0 = 0.f;
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) m0 += (fkey(v[j]) > 0u) ? p[j] : 0.f;
+      m0 = wave_sum(m0);
+      if (m0 > lim) {
+        uint32_t t = 0;
+        for (int bit = 31; bit >= 0; --bit) {
+          const uint32_t cand = t | (1u << bit);
+          float mm = 0.f;
+#pragma unroll
+          for (int j = 0; j < VC_VPL; ++j) mm += (fkey(v[j]) > cand) ? p[j] : 0.f;
+          mm = wave_sum(mm);
+          if (mm > lim) t = cand;
+        }
+        ps = 0.f;
+#pragma unroll
+        for (int j = 0; j < VC_VPL; ++j) {
+          if (fkey(v[j]) <= t) p[j] = 0.f;
+          ps += p[j];
+        }
+        tot = wave_sum(ps);
+      }
+    }
+    // ---- categorical draw by inverse CDF, order = (lane, j)
+    const float u = philox_uniform(a.seed, (uint32_t)b, (uint32_t)step, (uint32_t)k);
+    const float target = u * tot;
+    float incl = ps;
+    for (int off = 1; off < 64; off <<= 1) {
+      const float o = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += o;
+    }
+    const float excl = incl - ps;
+    const bool mine = (ps > 0.f) && (target >= excl) && (target < incl);
+    uint64_t ball = __ballot(mine);
+    int src_lane;
+    if (ball) src_lane = __ffsll((long long)ball) - 1;
+    else {     // rounding put target at/after the end: take the last lane with mass
+      const uint64_t nz = __ballot(ps > 0.f);
+      src_lane = nz ? 63 - __clzll((long long)nz) : 0;
+    }
+    int tok = 0;
+    if (lane == src_lane) {
+      float acc = excl;
+      int pick = -1, last = -1;
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) {
+        if (p[j] > 0.f) {
+          last = lane + 64 * j;
+          acc += p[j];
+          if (pick < 0 && target < acc) pick = lane + 64 * j;
+        }
+      }
+      tok = (pick >= 0) ? pick : last;
+    }
+    tok = __shfl(tok, src_lane, 64);
+    if (lane == 0) {
+      a.samp[b * a.K + k] = tok;
+      if (k == 0) a.amax[b] = bi;
+    }
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int c = 0;
+    if (st.n_eog == 0) {
+      const int t0 = a.samp[b * a.K];
+      c = (t0 == st.term_token) || (a.amax[b] == st.term_token) || (st.y_len > st.cap_len);
+    }
+    a.cond[b] = c;
+  }
+}
+
+// Phase 2 (one block per sequence): advance the state machine, log the step's tokens and build
+// the next decode rows (embedding sum + position, voicecraft.py:1102-1116; span switch :838-858).
+__device__ void advance_phase(const SampleArgs& a, int b, bool grouped) {
+  __shared__ int s_tok[VC_MAX_CODEBOOKS];
+  __shared__ int s_mode;     // 0: row inactive, 1: one new row, 3: span switch (three rows)
+  __shared__ int s_ylen, s_mask, s_Lx;
+  const int tid = threadIdx.x;
+  const int K = a.K;
+  if (tid == 0) {
+    SeqState st = a.st[b];
+    s_mode = 0;
+    if (!st.done) {
+      int tok[VC_MAX_CODEBOOKS];
+      for (int k = 0; k < K; ++k) tok[k] = a.samp[b * K + k];
+      int cond = a.cond[b];
+      bool drop = false;
+      if (grouped && st.n_eog == 0) {
+        // best-of-N (voicecraft.py:1296-1302): the LAST sample whose first codebook terminates is kept
+        int keep = -1;
+        for (int bb = 0; bb < a.B; ++bb)
+          if (a.st[bb].group == st.group && a.cond[bb]) keep = bb;   // group is immutable; every member is
+                                                                      // still alive while n_eog == 0
+        if (keep >= 0 && keep != b) drop = true;
+      }
+      const int step = st.total_steps;
+      const bool forced = a.forced && step < a.n_forced;
+      if (st.n_eog == 0) {
+        if (st.cur_num_gen < K - 1)
+          for (int jj = 1; jj < K - st.cur_num_gen; ++jj) tok[K - jj] = a.empty_token;
+        if (forced) {
+          for (int k = 0; k < K; ++k) tok[k] = (int)a.forced[(long)step * K + k];
+          cond = (tok[0] == st.term_token);
+        }
+        if (cond) { tok[0] = st.term_token; st.n_eog = 1; }
+        if (is_silence(a, tok[0]) && tok[0] == st.prev_token) st.consec_silence += 1;
+        else st.consec_silence = 0;
+        st.prev_token = tok[0];
+      } else {
+        for (int k = 0; k < st.n_eog; ++k) tok[k] = a.empty_token;
+        tok[st.n_eog] = st.term_token;
+        if (forced)
+          for (int k = 0; k < K; ++k) tok[k] = (int)a.forced[(long)step * K + k];
+        st.n_eog += 1;
+      }
+      st.cur_num_gen += 1;
+      if (step < a.max_steps)
+        for (int k = 0; k < K; ++k) a.gen[((long)b * a.max_steps + step) * K + k] = tok[k];
+      st.total_steps = step + 1;
+      for (int k = 0; k < K; ++k) s_tok[k] = tok[k];
+      s_ylen = st.y_len;
+      s_Lx = st.Lx;
+      if (drop) {
+        st.done = 1; st.kept = 0;
+        atomicSub(a.n_active, 1);
+      } else if (st.n_eog == K) {            // span finished
+        st.span_steps[st.span] = st.cur_num_gen;
+        st.cur_num_gen = 0;
+        st.n_eog = 0;
+        st.span += 1;
+        if (st.span >= st.n_spans || st.total_steps >= a.max_steps ||
+            st.Lx + st.y_len + 3 > a.max_positions) {
+          st.done = 1;
+          atomicSub(a.n_active, 1);
+        } else {
+          s_mode = 3;
+          s_mask = st.mask_value[st.span];
+          st.y_len += 3;
+          st.prev_token = -1;
+          st.consec_silence = 0;
+        }
+      } else if (st.total_steps >= a.max_steps ||
+                 st.Lx + st.y_len + 1 > a.max_positions) {   // capacity guard (never hit when sized right)
+        st.done = 1;
+        atomicSub(a.n_active, 1);
+      } else {
+        s_mode = 1;
+        st.y_len += 1;
+      }
+      a.st[b] = st;
+    }
+    const int r0 = b * a.rps;
+    for (int i = 0; i < a.rps; ++i) {
+      a.row_seq[r0 + i] = b;
+      a.row_pos[r0 + i] = (i < s_mode) ? (s_Lx + s_ylen + i) : -1;
+    }
+    a.logit_row[b] = r0 + (s_mode == 3 ? 2 : 0);
+  }
+  __syncthreads();
+  const int mode = s_mode;
+  if (mode == 0) return;
+  const int d = a.d;
+  const int ylen = s_ylen;
+  float* h0 = a.dec_h + (long)(b * a.rps) * d;
+  const float* pe0 = a.pe + (long)ylen * d;
+  for (int c = tid; c < d; c += blockDim.x) {
+    float v = a.audio_emb[((long)0 * a.V + s_tok[0]) * d + c];
+    for (int k = 1; k < K; ++k) v += a.audio_emb[((long)k * a.V + s_tok[k]) * d + c];
+    h0[c] = v + a.alpha_audio * pe0[c];
+    if (mode == 3) {
+      h0[d + c] = a.mask_emb[(long)s_mask * d + c] + a.alpha_audio * pe0[d + c];
+      float e = a.audio_emb[((long)0 * a.V + a.empty_token) * d + c];
+      for (int k = 1; k < K; ++k) e += a.audio_emb[((long)k * a.V + a.empty_token) * d + c];
+      h0[2 * d + c] = e + a.alpha_audio * pe0[2 * d + c];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
+  if (*a.n_active == 0) return;
+  sample_phase(a, blockIdx.x);
+  __syncthreads();
+  advance_phase(a, blockIdx.x, false);
+}
+__global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
+  if (*a.n_active == 0) return;
+  sample_phase(a, blockIdx.x);
+}
+__global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
+  if (*a.n_active == 0) return;
+  advance_phase(a, blockIdx.x, true);
+}
+hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
+  if (!grouped) {
+    hipLaunchKernelGGL(sample_fused_k, dim3(a.B), dim3(256), 0, s, a);
+  } else {
+    // the keep decision reads every sample's cond flag, so it needs the kernel boundary
+    hipLaunchKernelGGL(sample_only_k, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(advance_only_k, dim3(a.B), dim3(256), 0, s, a);
+  }
+  return hipGetLastError();
+}
+
+// =============================================================== output assembly
+// res = cat(non-mask pieces of y, un-shifted generated spans) (voicecraft.py:1141-1153, :890-898).
+__global__ void assemble_k(const AssembleArgs a) {
+  const int p = blockIdx.y;
+  const int len = a.len[p];
+  const long total = (long)a.K * len;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(idx / len), t = (int)(idx % len);
+    int64_t v;
+    if (a.kind[p] == 0) v = a.y[(long)(a.src0[p] + t) * a.K + j];
+    else v = (int64_t)a.gen[(long)(a.src0[p] + j + t) * a.K + j];
+    a.res[(long)j * a.res_cap + a.dst0[p] + t] = v;
+  }
+}
+hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s) {
+  if (a.n_piece <= 0) return hipSuccess;
+  hipLaunchKernelGGL(assemble_k, dim3(8, a.n_piece), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
