@@ -156,7 +156,7 @@ class VoiceCraftOracle:
 
     # ---- the shared generation loop
     def _run(self, x, cols0, mask_cols, *, mode, more_mask, n_spans, B, top_k, top_p, temperature,
-             stop_repetition, kvcache, silence_tokens, trace, forced=None):
+             stop_repetition, kvcache, silence_tokens, trace, forced=None, max_steps=None):
         """x [1,Lx]; cols0 [K,S0] prompt columns; mask_cols {col: mask_embedding row}.
         Returns (spans: list of [N,K] int arrays per finished span, kept sample index)."""
         K, V = self.K, self.V
@@ -244,6 +244,8 @@ class VoiceCraftOracle:
                 cb_eog[n_eog] = True
             cur_num_gen += 1
             step += 1
+            if max_steps is not None and step >= max_steps:      # bounded sample for CPU timing only
+                return None, step
             if sum(cb_eog) == 0:
                 for b in range(B):
                     cur[b].append(samples[b].clone())
@@ -276,7 +278,8 @@ class VoiceCraftOracle:
     # ---- public mirrors of the reference API
     @torch.no_grad()
     def inference_tts(self, x, x_lens, y, top_k=-100, top_p=1.0, temperature=1.0, stop_repetition=3,
-                      kvcache=1, silence_tokens=(1388, 1898, 131), batch_size=1, trace=None, forced=None):
+                      kvcache=1, silence_tokens=(1388, 1898, 131), batch_size=1, trace=None, forced=None,
+                      max_steps=None):
         assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3
         if self.special_first:
             y = y + self.n_special
@@ -288,7 +291,10 @@ class VoiceCraftOracle:
         assert not (cols == self.pad).any()
         spans, _ = self._run(x, cols, {}, mode="tts", more_mask=[], n_spans=1, B=batch_size, top_k=top_k,
                              top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
-                             kvcache=kvcache, silence_tokens=list(silence_tokens), trace=trace, forced=forced)
+                             kvcache=kvcache, silence_tokens=list(silence_tokens), trace=trace, forced=forced,
+                             max_steps=max_steps)
+        if spans is None:
+            return None, None
         gen = torch.from_numpy(unshift_span(spans[0]))                       # [K,Tg]
         res = torch.cat([yk[0], gen], dim=1).unsqueeze(0)
         if self.special_first:

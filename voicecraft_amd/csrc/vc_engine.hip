@@ -825,6 +825,8 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
     else if (c.reduced_eog) term = (i == M) ? c.eog : -1;
     else term = c.eog;
     const int n = (ne[i] - ns[i]) + (term >= 0 ? 1 : 0);
+    if (n <= 0)   // the reference raises IndexError here (codebooks_patterns.py:174 on a zero-length piece)
+      return fail(e, VC_EINVAL, "non-masked piece %d is empty (a span may not start at frame 0)", i);
     pa.seg[nseg++] = Segment{col, n + K, ns[i], ne[i] - ns[i], term, -1};
     col += n + K;
     pa.seg[nseg++] = Segment{col, 1, 0, 0, -1, mask_values[i]};

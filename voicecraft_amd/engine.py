@@ -1,0 +1,353 @@
+"""Python mirror of the reference's model interface for the decode path.
+
+`VoiceCraftEngine` exposes `inference_tts`, `inference_tts_batch` and `inference` with the
+signatures, argument meaning, return shapes and AssertionErrors of `models.voicecraft.VoiceCraft`
+(models/voicecraft.py:908, :1156, :561), so `inference_tts_scale.inference_one_sample`
+(inference_tts_scale.py:42-105) and its editing twin run unchanged on it.  All compute happens in
+libvcengine.so (HIP, gfx950) behind the C ABI of include/vc_engine.h; torch is used only to hold
+device memory for inputs/outputs, to read the state_dict and to name the current stream.
+There is no CPU or eager fallback: without the library every constructor raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+import math
+import random
+from argparse import Namespace
+from typing import Iterable
+
+import torch
+
+from . import _lib
+from ._lib import ModelCfg, SampleCfg, check
+
+_DTYPES = {"bf16": _lib.VC_DTYPE_BF16, "bfloat16": _lib.VC_DTYPE_BF16, torch.bfloat16: _lib.VC_DTYPE_BF16,
+           "fp32": _lib.VC_DTYPE_F32, "float32": _lib.VC_DTYPE_F32, torch.float32: _lib.VC_DTYPE_F32}
+
+
+def _sine_table(n: int, d: int) -> torch.Tensor:
+    # same torch ops as SinePositionalEmbedding.extend_pe (models/modules/embedding.py:77-90)
+    pos = torch.arange(0, n, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe = torch.zeros(n, d)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.contiguous()
+
+
+class VoiceCraftEngine:
+    """Drop-in for `VoiceCraft(args)` + `load_state_dict` + `.to(device).eval()` on the inference path."""
+
+    def __init__(self, args: Namespace | dict, state_dict: dict[str, torch.Tensor], device="cuda:0",
+                 dtype="bf16", max_seqs: int = 8, max_positions: int = 2048, use_graph: bool = True):
+        self.lib = _lib.load()
+        a = Namespace(**args) if isinstance(args, dict) else Namespace(**vars(args))
+        # the same normalisation VoiceCraft.__init__ applies (models/voicecraft.py:117-127)
+        if not getattr(a, "special_first", False):
+            a.special_first = 0
+        if not getattr(a, "n_special", False):
+            a.n_special = 3
+        a.eos = getattr(a, "eos", -1)
+        if isinstance(a.audio_vocab_size, str):
+            a.audio_vocab_size = eval(a.audio_vocab_size)
+        assert a.text_pad_token == a.text_vocab_size, (a.text_vocab_size, a.text_pad_token)
+        assert a.audio_vocab_size == a.empty_token, a.empty_token
+        assert a.eog == a.audio_vocab_size + 1, a.eog
+        assert a.audio_pad_token == a.audio_vocab_size + 2, a.audio_pad_token
+        if a.eos > 0:
+            assert a.eos != a.audio_pad_token and a.eos != a.empty_token, a.eos
+        self.args = a
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("VoiceCraftEngine runs on an MI355X only (device must be cuda:N); there is no CPU path")
+        self.compute_dtype = _DTYPES[dtype]
+        self.use_graph = bool(use_graph)
+        self.max_seqs, self.max_positions = int(max_seqs), int(max_positions)
+        cfg = ModelCfg(
+            d_model=a.d_model, nhead=a.nhead, num_layers=a.num_decoder_layers, n_codebooks=a.n_codebooks,
+            audio_vocab_size=a.audio_vocab_size, n_special=int(a.n_special), text_rows=a.text_vocab_size + 1,
+            head_hidden=a.audio_vocab_size // 2, empty_token=a.empty_token, eog=a.eog,
+            audio_pad_token=a.audio_pad_token, eos=a.eos if a.eos > 0 else -1,
+            reduced_eog=int(getattr(a, "reduced_eog", 0) or 0), encodec_sr=int(a.encodec_sr),
+            max_n_spans=int(a.max_n_spans), max_seqs=self.max_seqs, max_positions=self.max_positions)
+        self._h = C.c_void_p()
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device("cuda", index)
+        check(self.lib.vc_create(C.byref(cfg), index, C.byref(self._h)), None, "vc_create")
+        self._load(state_dict)
+        self.last_steps = 0
+
+    # ------------------------------------------------------------------ nn.Module look-alikes
+    def eval(self):
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self.lib.vc_destroy(h)
+            except Exception:  # pragma: no cover
+                pass
+
+    # ------------------------------------------------------------------ weights
+    def _load(self, state_dict) -> None:
+        keep = []
+        for key, t in state_dict.items():
+            if not torch.is_tensor(t) or not t.is_floating_point():
+                continue                      # eog / eos buffers, torchmetrics state
+            if key.startswith("accuracy_metrics"):
+                continue
+            t = t.detach().to(torch.float32).contiguous()
+            keep.append(t)
+            shape = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            check(self.lib.vc_load_tensor(self._h, key.encode(), C.c_void_p(t.data_ptr()), int(t.is_cuda),
+                                          _lib.VC_DTYPE_F32, shape, t.dim()), self._h, f"vc_load_tensor({key})")
+        pe = _sine_table(self.max_positions, self.args.d_model)
+        shape = (C.c_int64 * 2)(*pe.shape)
+        check(self.lib.vc_load_tensor(self._h, b"pe", C.c_void_p(pe.data_ptr()), 0, _lib.VC_DTYPE_F32, shape, 2),
+              self._h, "vc_load_tensor(pe)")
+        check(self.lib.vc_finalize_weights(self._h, self.compute_dtype), self._h, "vc_finalize_weights")
+
+    # ------------------------------------------------------------------ helpers
+    def _stream(self) -> C.c_void_p:
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _sample_cfg(self, top_k, top_p, temperature, stop_repetition, silence_tokens, seed=None) -> SampleCfg:
+        sc = SampleCfg()
+        sc.top_k = int(top_k)
+        sc.top_p = float(top_p)
+        sc.temperature = float(temperature)
+        sc.stop_repetition = int(stop_repetition)
+        sil = list(silence_tokens)[: _lib.VC_MAX_SILENCE]
+        sc.n_silence = len(sil)
+        for i, v in enumerate(sil):
+            sc.silence_tokens[i] = int(v)
+        # the reference draws from torch's global generator (seed_everything, inference_tts_scale.py:128-135);
+        # one draw from it keys the device Philox stream, so torch.manual_seed still makes runs repeatable
+        sc.seed = int(torch.randint(0, 2 ** 62, (1,)).item()) if seed is None else int(seed)
+        sc.use_graph = int(self.use_graph)
+        sc.poll_every = 0
+        return sc
+
+    def _prep(self, x, x_lens, y):
+        assert x.ndim == 2, x.shape
+        assert x_lens.ndim == 1, x_lens.shape
+        assert y.ndim == 3, y.shape
+        if self.args.special_first:
+            y = y + int(self.args.n_special)
+        assert y.shape[0] == 1 and y.shape[2] == self.args.n_codebooks, y.shape
+        assert x.shape[0] == 1, x.shape
+        Lx = int(x_lens[0])
+        xd = x[0, :Lx].to(self.device, torch.int64).contiguous()
+        yd = y[0].to(self.device, torch.int64).contiguous()          # [T,K], time-major as given
+        return xd, Lx, yd, int(yd.shape[0])
+
+    def _gen_budget(self, Lx: int, n_cols: int, mult: int, spans: int = 1) -> int:
+        K = self.args.n_codebooks
+        return max(0, Lx * mult - n_cols + 1) + spans * (K + 4) + 8
+
+    # ------------------------------------------------------------------ TTS
+    @torch.no_grad()
+    def inference_tts(self, x, x_lens, y, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
+                      stop_repetition: int = 3, kvcache: int = 1, silence_tokens: Iterable[int] = (1388, 1898, 131),
+                      *kargs, _n_samples: int = 1, _forced=None, _logit_steps: int = 0, _seed=None):
+        """models/voicecraft.py:908.  `kvcache` is accepted and ignored: the cache is always on
+        (kvcache=0 and kvcache=1 give identical tokens in the reference)."""
+        xd, Lx, yd, T = self._prep(x, x_lens, y)
+        logging.info(f"silence tokens: {list(silence_tokens)}, note that if you are not using the pretrained encodec 6f79c6a8, make sure you specified it yourself, rather than using the default")
+        K = self.args.n_codebooks
+        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed)
+        cap = T + self._gen_budget(Lx, T + 1, self.args.encodec_sr // 5)
+        res = torch.empty((K, cap), dtype=torch.int64, device=self.device)
+        forced_ptr, n_forced = None, 0
+        if _forced is not None:
+            fd = torch.as_tensor(_forced, dtype=torch.int64).to(self.device).contiguous()
+            forced_ptr, n_forced = C.c_void_p(fd.data_ptr()), int(fd.shape[0])
+        logits = None
+        if _logit_steps > 0:
+            V = self.args.audio_vocab_size + int(self.args.n_special)
+            logits = torch.zeros((_logit_steps, K, V), dtype=torch.float32, device=self.device)
+        gen_len, n_steps = C.c_int(0), C.c_int(0)
+        rc = self.lib.vc_tts(self._h, C.c_void_p(xd.data_ptr()), Lx, C.c_void_p(yd.data_ptr()), T, C.byref(sc),
+                             int(_n_samples), forced_ptr, n_forced, C.c_void_p(res.data_ptr()), cap, C.byref(gen_len),
+                             C.c_void_p(logits.data_ptr()) if logits is not None else None, int(_logit_steps),
+                             C.byref(n_steps), self._stream())
+        check(rc, self._h, "vc_tts")
+        self.last_steps = n_steps.value
+        Tg = gen_len.value
+        out = res[:, : T + Tg].unsqueeze(0)
+        gen = res[:, T: T + Tg].unsqueeze(0)
+        expected_y_len = T + Tg
+        assert out.shape == torch.Size((1, K, expected_y_len)), out.shape
+        if self.args.special_first:
+            out, gen = out - int(self.args.n_special), gen - int(self.args.n_special)
+        if logits is not None:
+            return out, gen, logits
+        return out, gen
+
+    @torch.no_grad()
+    def inference_tts_batch(self, x, x_lens, y, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
+                            stop_repetition: int = 3, kvcache: int = 1, batch_size: int = 5,
+                            silence_tokens: Iterable[int] = (1388, 1898, 131), *kargs, _seed=None):
+        """models/voicecraft.py:1156 — best-of-N sampling of ONE utterance; returns the kept sample."""
+        return self.inference_tts(x, x_lens, y, top_k, top_p, temperature, stop_repetition, kvcache,
+                                  silence_tokens, _n_samples=int(batch_size), _seed=_seed)
+
+    @torch.no_grad()
+    def inference_tts_multi(self, xs, ys, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
+                            stop_repetition: int = 3, silence_tokens: Iterable[int] = (1388, 1898, 131), _seed=None):
+        """B different utterances as one batch (not in the reference: SURVEY.md §8f-1).
+        xs: list of int64 [Lx_i]; ys: list of int64 [T_i,K].  Returns list of (res [1,K,T_i+Tg_i], gen)."""
+        B = len(xs)
+        assert B == len(ys) and 1 <= B <= self.max_seqs, (B, self.max_seqs)
+        K = self.args.n_codebooks
+        xcat = torch.cat([torch.as_tensor(v, dtype=torch.int64).reshape(-1) for v in xs]).to(self.device).contiguous()
+        ycat = torch.cat([torch.as_tensor(v, dtype=torch.int64).reshape(-1, K) for v in ys]).to(self.device).contiguous()
+        if self.args.special_first:
+            ycat = ycat + int(self.args.n_special)
+        xo, yo = [0], [0]
+        cap = 0
+        for xv, yv in zip(xs, ys):
+            Lx, T = int(torch.as_tensor(xv).numel()), int(torch.as_tensor(yv).reshape(-1, K).shape[0])
+            xo.append(xo[-1] + Lx)
+            yo.append(yo[-1] + T)
+            cap = max(cap, T + self._gen_budget(Lx, T + 1, self.args.encodec_sr // 5))
+        x_off = (C.c_int32 * (B + 1))(*xo)
+        y_off = (C.c_int32 * (B + 1))(*yo)
+        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed)
+        res = torch.empty((B, K, cap), dtype=torch.int64, device=self.device)
+        gen_len = (C.c_int * B)()
+        n_steps = C.c_int(0)
+        rc = self.lib.vc_tts_multi(self._h, B, C.c_void_p(xcat.data_ptr()), x_off, C.c_void_p(ycat.data_ptr()), y_off,
+                                   C.byref(sc), C.c_void_p(res.data_ptr()), cap, gen_len, C.byref(n_steps), self._stream())
+        check(rc, self._h, "vc_tts_multi")
+        self.last_steps = n_steps.value
+        outs = []
+        for b in range(B):
+            T, Tg = yo[b + 1] - yo[b], gen_len[b]
+            r, g = res[b, :, : T + Tg].unsqueeze(0), res[b, :, T: T + Tg].unsqueeze(0)
+            if self.args.special_first:
+                r, g = r - int(self.args.n_special), g - int(self.args.n_special)
+            outs.append((r, g))
+        return outs
+
+    # ------------------------------------------------------------------ editing
+    @torch.no_grad()
+    def inference(self, x, x_lens, y, mask_interval, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
+                  stop_repetition: int = -1, kvcache: int = 1, silence_tokens: Iterable[int] = (1388, 1898, 131),
+                  _forced=None, _logit_steps: int = 0, _seed=None):
+        """models/voicecraft.py:561."""
+        xd, Lx, yd, T = self._prep(x, x_lens, y)
+        assert mask_interval.shape == torch.Size((1, mask_interval.shape[1], 2)), mask_interval
+        logging.info(f"silence tokens: {list(silence_tokens)}, note that if you are not using the pretrained encodec 6f79c6a8, make sure you specified it yourself, rather than using the default")
+        K = self.args.n_codebooks
+        ivs = [(int(a), int(b)) for a, b in mask_interval[0].tolist()]
+        M = len(ivs)
+        # insert_mask (models/voicecraft.py:264-288): which mask_embedding row each placeholder uses
+        emb_inds = list(range(int(self.args.max_n_spans)))
+        if getattr(self.args, "shuffle_mask_embedding", 0):
+            random.shuffle(emb_inds)
+        use = emb_inds[:M]
+        assert len(use) == M, f"{M} spans but max_n_spans is {self.args.max_n_spans}"
+        mask_value = use + use
+        # a zero-length piece makes the reference raise inside build_pattern_sequence (codebooks_patterns.py:174)
+        starts = [iv[0] for iv in ivs] + [T]
+        ends = [0] + [iv[1] for iv in ivs]
+        eos, reduced = self.args.eos, int(getattr(self.args, "reduced_eog", 0) or 0)
+        for i, (s, e) in enumerate(zip(ends, starts)):
+            has_term = (i == M) if (eos > 0 or reduced) else True
+            if e - s + int(has_term) <= 0:
+                raise IndexError("index is out of bounds for dimension with size 0 (zero-length non-masked piece)")
+        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed)
+        flat = [v for iv in ivs for v in iv]
+        iv_arr = (C.c_int32 * (2 * M))(*flat)
+        mv_arr = (C.c_int32 * (2 * M))(*mask_value)
+        n_cols = T + 2 * (M + 1) + (M + 1) * K + 1
+        cap = T + self._gen_budget(Lx, n_cols, 10, spans=M)
+        res = torch.empty((K, cap), dtype=torch.int64, device=self.device)
+        forced_ptr, n_forced = None, 0
+        if _forced is not None:
+            fd = torch.as_tensor(_forced, dtype=torch.int64).to(self.device).contiguous()
+            forced_ptr, n_forced = C.c_void_p(fd.data_ptr()), int(fd.shape[0])
+        logits = None
+        if _logit_steps > 0:
+            V = self.args.audio_vocab_size + int(self.args.n_special)
+            logits = torch.zeros((_logit_steps, K, V), dtype=torch.float32, device=self.device)
+        res_len, n_steps = C.c_int(0), C.c_int(0)
+        rc = self.lib.vc_edit(self._h, C.c_void_p(xd.data_ptr()), Lx, C.c_void_p(yd.data_ptr()), T, iv_arr, M, mv_arr,
+                              C.byref(sc), forced_ptr, n_forced, C.c_void_p(res.data_ptr()), cap, C.byref(res_len),
+                              C.c_void_p(logits.data_ptr()) if logits is not None else None, int(_logit_steps),
+                              C.byref(n_steps), self._stream())
+        check(rc, self._h, "vc_edit")
+        self.last_steps = n_steps.value
+        out = res[:, : res_len.value].unsqueeze(0)
+        if self.args.special_first:
+            out = out - int(self.args.n_special)
+        if logits is not None:
+            return out, logits
+        return out
+
+    # ------------------------------------------------------------------ measurement hooks
+    def last_timing_ms(self):
+        ms = (C.c_float * 3)()
+        check(self.lib.vc_last_timing(self._h, ms), self._h, "vc_last_timing")
+        return {"prefill_ms": ms[0], "decode_ms": ms[1], "total_ms": ms[2]}
+
+    def bench_kernel(self, which: str, n_rows: int = 1, iters: int = 50):
+        ms, nbytes = C.c_float(0), C.c_double(0)
+        check(self.lib.vc_bench_kernel(self._h, which.encode(), n_rows, iters, C.byref(ms), C.byref(nbytes), self._stream()),
+              self._h, "vc_bench_kernel")
+        return ms.value, nbytes.value
+
+    def debug_read(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
+        out = torch.empty(shape, dtype=dtype)
+        check(self.lib.vc_debug_read(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel() * out.element_size()),
+              self._h, "vc_debug_read")
+        return out
+
+
+# ---------------------------------------------------------------------- pattern ops (no engine needed)
+def _pattern_call(fn, *args):
+    rc = fn(*args)
+    if rc != 0:
+        raise AssertionError(f"pattern kernel rejected its arguments (code {rc})")
+
+
+def pattern_shift(z: torch.Tensor, special: int) -> torch.Tensor:
+    """z int64 [B,K,T] on the GPU -> [B,K,T+K] (Pattern.build_pattern_sequence values, codebooks_patterns.py:151-176)."""
+    lib = _lib.load()
+    assert z.is_cuda and z.dtype == torch.int64 and z.ndim == 3
+    z = z.contiguous()
+    B, K, T = z.shape
+    out = torch.empty((B, K, T + K), dtype=torch.int64, device=z.device)
+    _pattern_call(lib.vc_pattern_shift, C.c_void_p(z.data_ptr()), B, K, T, int(special), C.c_void_p(out.data_ptr()),
+                  C.c_void_p(torch.cuda.current_stream(z.device).cuda_stream))
+    return out
+
+
+def pattern_revert(s: torch.Tensor, T: int, special: int) -> torch.Tensor:
+    """s int64 [B,K,S] -> [B,K,T] (Pattern.revert_pattern_sequence values, codebooks_patterns.py:222-245)."""
+    lib = _lib.load()
+    assert s.is_cuda and s.dtype == torch.int64 and s.ndim == 3
+    s = s.contiguous()
+    B, K, S = s.shape
+    out = torch.empty((B, K, T), dtype=torch.int64, device=s.device)
+    _pattern_call(lib.vc_pattern_revert, C.c_void_p(s.data_ptr()), B, K, S, int(T), int(special),
+                  C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(s.device).cuda_stream))
+    return out
+
+
+def pattern_unshift(span: torch.Tensor) -> torch.Tensor:
+    """span int64 [N,K] (one row per decode step) -> [K,N-K] (models/voicecraft.py:1125-1139)."""
+    lib = _lib.load()
+    assert span.is_cuda and span.dtype == torch.int64 and span.ndim == 2
+    span = span.contiguous()
+    N, K = span.shape
+    out = torch.empty((K, N - K), dtype=torch.int64, device=span.device)
+    _pattern_call(lib.vc_pattern_unshift, C.c_void_p(span.data_ptr()), N, K, C.c_void_p(out.data_ptr()),
+                  C.c_void_p(torch.cuda.current_stream(span.device).cuda_stream))
+    return out
