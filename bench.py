@@ -44,6 +44,7 @@ def parse():
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=48, help="decode steps of the bounded CPU sample")
+    p.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads for the CPU baseline (capped at the core count)")
     return p.parse_args()
 
 
@@ -53,6 +54,7 @@ def cpu_baseline(args, sd, a, x, x_lens, y):
     from oracle.voicecraft_oracle import VoiceCraftOracle
     orc = VoiceCraftOracle(a, sd)
     torch.manual_seed(0)
+    torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     n = args.cpu_steps
     t0 = time.perf_counter()
     orc.inference_tts(x, x_lens, y, top_k=args.top_k, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1,
@@ -154,6 +156,10 @@ def main():
         # dominant kernel: the FFN up-projection rows-GEMM (LayerNorm prologue, ReLU epilogue)
         k_ms, k_bytes = eng.bench_kernel("ffn1", n_rows=B, iters=64)
         step_ms, _ = eng.bench_kernel("step", n_rows=B, iters=8)
+        kernels = {}
+        for kn in ("qkv", "oproj", "ffn1", "ffn2"):
+            ms_, by_ = eng.bench_kernel(kn, n_rows=B, iters=64)
+            kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
         roof = {"bound": "hbm", "kernel": "rows_gemm_k<LN,ReLU> (FFN up-projection)",
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
@@ -170,7 +176,7 @@ def main():
             "decode_ms_per_token_step": round(dec_step_ms, 4), "prefill_ms": round(pre_ms / args.steps, 2),
             "decode_step": {"alg_bytes": int(step_bytes), "isolated_step_ms": round(step_ms, 4),
                             "hbm_frac_in_loop": round(step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_step_ms > 0 else None},
-            "roofline": roof,
+            "roofline": roof, "kernels": kernels,
         }
         if n_gpus == 1 and not args.no_cpu_baseline:
             try:

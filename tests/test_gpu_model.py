@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 GREEDY = [n for n, s in MODEL_CASES.items() if s["knobs"]["top_k"] == 1 and s["knobs"]["kvcache"] == 1]
 
 
+def rel_l2(got, want):
+    """Per-step relative L2 error of the head logits.  The synthetic checkpoints mute the terminator
+    with a -1e4 bias; those columns would swamp the norm, so they are left out."""
+    live = np.abs(want) < 1e3
+    num = np.sqrt((((got - want) * live) ** 2).reshape(len(want), -1).sum(1))
+    den = np.sqrt(((want * live) ** 2).reshape(len(want), -1).sum(1))
+    return num / den
+
+
 def make_engine(name, dtype, **kw):
     from voicecraft_amd.engine import VoiceCraftEngine
     spec, args, sd, x, x_lens, y = build_case(name)
@@ -72,7 +81,7 @@ def test_bf16_teacher_forced_logits(name):
     # teacher forcing replays the reference trajectory, so the assembled output must be identical
     assert np.array_equal(res.cpu().numpy(), res_o.numpy())
     got = lg.cpu().numpy()
-    rel = np.linalg.norm((got - want).reshape(len(trace), -1), axis=1) / np.linalg.norm(want.reshape(len(trace), -1), axis=1)
+    rel = rel_l2(got, want)
     assert rel.max() <= 2e-2, f"bf16 relative L2 error per step: max {rel.max():.4f}"
     max_err = np.abs(got - want).max()
     srt = np.sort(want, axis=-1)

@@ -42,7 +42,7 @@ __global__ void pattern_unshift_k(const int64_t* __restrict__ span, int N, int K
 
 extern "C" int vc_pattern_shift(const int64_t* z_dev, int B, int K, int T, int64_t special,
                                 int64_t* out_dev, void* stream) {
-  if (!z_dev || !out_dev || B <= 0 || K <= 0 || T < 0) return VC_EINVAL;
+  if ((!z_dev && T > 0) || !out_dev || B <= 0 || K <= 0 || T < 0) return VC_EINVAL;
   const long total = (long)B * K * (T + K);
   hipLaunchKernelGGL(pattern_shift_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, z_dev, K, T, special, out_dev, total);
