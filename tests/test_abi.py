@@ -80,4 +80,5 @@ def test_bad_config_is_rejected(lib):
 
 def test_pattern_entry_points_validate_arguments(lib):
     assert lib.vc_pattern_shift(None, 1, 4, 3, 0, None, None) == -1
-    assert lib.vc_pattern_unshift(None, 2, 4, None, None) == -1
+    assert lib.vc_pattern_unshift(None, 2, 4, None, None) == -1      # N < K
+    assert lib.vc_pattern_unshift(None, 4, 4, None, None) == 0       # N == K: nothing to write

@@ -10,7 +10,7 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 
 #define VC_ROWS 16          // rows (token positions) one forward pass carries = MFMA N dimension
 #define VC_MAX_NSPLIT 16    // split-S factor cap of the decode attention
-#define VC_MAX_KSPLIT 8     // cross-block split-K cap of the rows-GEMM
+#define VC_MAX_KSPLIT 4     // cross-block split-K cap of the rows-GEMM (the LN prologue prefetches this many slabs)
 #define VC_MAX_SEG 32       // prompt segments (2*spans+1 pieces + placeholders)
 #define VC_VPL 34           // logits per lane in the sampler: V <= 64*34
 
@@ -58,20 +58,67 @@ __device__ __forceinline__ f32x4 mfma_frag(const uint4& w, const uint4& x, f32x4
 }
 
 // ---------------------------------------------------------------- wave helpers (wave64)
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the DPP path (no LDS crossbar): four steps reduce each 16-lane row
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror, row_mirror), then the four row
+// results are combined through v_readlane.  ~8 instructions against 6 dependent ds_bpermute.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+#define VC_DPP_QP_1032 0xB1
+#define VC_DPP_QP_2301 0x4E
+#define VC_DPP_ROW_HALF_MIRROR 0x141
+#define VC_DPP_ROW_MIRROR 0x140
+
+__device__ __forceinline__ float row_sum(float v) {        // every lane gets the sum of its 16-lane row
+  v += dpp_f<VC_DPP_QP_1032>(v);
+  v += dpp_f<VC_DPP_QP_2301>(v);
+  v += dpp_f<VC_DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_f<VC_DPP_ROW_MIRROR>(v);
   return v;
+}
+__device__ __forceinline__ float half_row_sum(float v) {   // sum over aligned groups of 8 lanes
+  v += dpp_f<VC_DPP_QP_1032>(v);
+  v += dpp_f<VC_DPP_QP_2301>(v);
+  v += dpp_f<VC_DPP_ROW_HALF_MIRROR>(v);
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  v = row_sum(v);
+  return (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)) +
+          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))) +
+         (__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)) +
+          __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48)));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  v = fmaxf(v, dpp_f<VC_DPP_QP_1032>(v));
+  v = fmaxf(v, dpp_f<VC_DPP_QP_2301>(v));
+  v = fmaxf(v, dpp_f<VC_DPP_ROW_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f<VC_DPP_ROW_MIRROR>(v));
+  return fmaxf(fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 0)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 16))),
+               fmaxf(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 32)),
+                     __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 48))));
 }
 __device__ __forceinline__ int wave_sum_i(int v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_i<VC_DPP_QP_1032>(v);
+  v += dpp_i<VC_DPP_QP_2301>(v);
+  v += dpp_i<VC_DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_i<VC_DPP_ROW_MIRROR>(v);
+  return (__builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16)) +
+         (__builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48));
+}
+__device__ __forceinline__ int wave_min_i(int v) {
+  v = min(v, dpp_i<VC_DPP_QP_1032>(v));
+  v = min(v, dpp_i<VC_DPP_QP_2301>(v));
+  v = min(v, dpp_i<VC_DPP_ROW_HALF_MIRROR>(v));
+  v = min(v, dpp_i<VC_DPP_ROW_MIRROR>(v));
+  return min(min(__builtin_amdgcn_readlane(v, 0), __builtin_amdgcn_readlane(v, 16)),
+             min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
 // ---------------------------------------------------------------- per-sequence decode state (device)
@@ -122,9 +169,10 @@ struct GemmArgs {
   // prologue LN:   hn = h_in[src] + prev_bias + sum_s parts[s][r]; X = LN(hn) ; h_out[r] = hn
   const float* h_in;
   float* h_out;
-  const float* parts;       // [n_parts][VC_ROWS][d]
+  const float* parts;       // [VC_MAX_KSPLIT][VC_ROWS][d], always readable; the first n_parts slabs are summed
   int n_parts;
-  const float* prev_bias;
+  const float* prev_bias;   // always a readable [d] vector; added only when has_prev_bias
+  int has_prev_bias;
   const float* ln_w;
   const float* ln_b;
   const int* gather_rows;   // optional indirection on h_in/parts rows (logit rows for the heads)

@@ -210,9 +210,10 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wqkv; g.bias = ly.bqkv;
       g.h_in = (l == 0) ? rs.h_in : e->hB;
       g.h_out = e->hA;
-      g.parts = (l == 0) ? nullptr : e->parts;
+      g.parts = e->parts;
       g.n_parts = (l == 0) ? 0 : e->p_f2.ksplit;
-      g.prev_bias = (l == 0) ? nullptr : e->layers[l - 1].b2;
+      g.prev_bias = (l == 0) ? ly.ln1b : e->layers[l - 1].b2;
+      g.has_prev_bias = (l == 0) ? 0 : 1;
       g.ln_w = ly.ln1w; g.ln_b = ly.ln1b;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
@@ -240,7 +241,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1;
       g.h_in = e->hA; g.h_out = e->hB;
-      g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo;
+      g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.ln_w = ly.ln2w; g.ln_b = ly.ln2b;
       g.out = e->act; g.out_ld = 4 * d;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
@@ -265,7 +266,7 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
     GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
     g.Wp = e->Wh1; g.bias = e->bh1;
     g.h_in = e->hB; g.h_out = nullptr;
-    g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2;
+    g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     g.ln_w = e->lnf_w; g.ln_b = e->lnf_b; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
     HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, s));
@@ -954,7 +955,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
-      g.prev_bias = ly.bo; g.ln_w = ly.ln2w; g.ln_b = ly.ln2b; g.out = e->act; g.out_ld = 4 * d;
+      g.prev_bias = ly.bo; g.has_prev_bias = 1; g.ln_w = ly.ln2w; g.ln_b = ly.ln2b; g.out = e->act; g.out_ld = 4 * d;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
     } else if (w == "ffn2") {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
@@ -963,7 +964,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     } else if (w == "qkv") {
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.h_in = e->hB; g.h_out = e->hA; g.parts = e->parts; g.n_parts = e->p_f2.ksplit;
-      g.prev_bias = ly.b2; g.ln_w = ly.ln1w; g.ln_b = ly.ln1b; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      g.prev_bias = ly.b2; g.has_prev_bias = 1; g.ln_w = ly.ln1w; g.ln_b = ly.ln1b; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
     } else if (w == "oproj") {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);

@@ -98,70 +98,102 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   char* xl = smem;
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
 
-  // (1) put this wave's first weight burst in flight before anything else: it does not depend on X.
   const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * 64 + lane;
   uint4 wf[KTW];
-  {
-    const int kt = kt0 + wave * KTW;
-#pragma unroll
-    for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt + i) * 64];
+  // Issue order matters: a wave's loads return in order, so anything the prologue needs is
+  // requested BEFORE the weight burst and consumed behind a counted vmcnt while the weights
+  // (which do not depend on X) are still streaming.
+#define VC_ISSUE_WEIGHTS()                                              \
+  {                                                                     \
+    const int kt_ = kt0 + wave * KTW;                                   \
+    _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt_ + i) * 64]; \
   }
 
-  // (2) prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.
+  // (2) prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.  n_rows >= 1 (host contract).
+  // Every prologue load is unconditional and branch-free (out-of-range lanes re-read column 0,
+  // unused split slabs are read and discarded by a select): a load inside a branch makes the
+  // compiler drain the whole queue (vmcnt(0)) and the weight burst with it.
   if constexpr (PRO == PRO_LN) {
-    // one wave per row: two-pass LayerNorm in registers (eps 1e-5, transformer.py:30)
+    // LayerNorm of hn = h + prev_bias + sum(parts) (eps 1e-5, transformer.py:30), two-pass, the
+    // whole block on one row at a time: thread t owns float4 columns t and t+256.
+    float* s_sum = reinterpret_cast<float*>(red);        // [4] wave partials (the reduce area is free until step 4)
+    float* s_sq = s_sum + 4;
     const int d = a.d;
-    const int nv4 = d >> 8;                       // float4 per lane
-    for (int r = wave; r < n_rows; r += 4) {
-      const int sr = a.gather_rows ? a.gather_rows[r] : r;
-      const float* hp = a.h_in + (long)sr * d;
-      float4 v[VC_LN_MAXV4];
-      float sum = 0.f;
-#pragma unroll
-      for (int i = 0; i < VC_LN_MAXV4; ++i) {
-        if (i < nv4) {
-          const int c = (i * 64 + lane) * 4;
-          float4 x = *reinterpret_cast<const float4*>(hp + c);
-          if (a.prev_bias) {
-            const float4 b = *reinterpret_cast<const float4*>(a.prev_bias + c);
-            x.x += b.x; x.y += b.y; x.z += b.z; x.w += b.w;
-          }
-          for (int s = 0; s < a.n_parts; ++s) {
-            const float4 p = *reinterpret_cast<const float4*>(a.parts + ((long)(s * VC_ROWS + sr)) * d + c);
-            x.x += p.x; x.y += p.y; x.z += p.z; x.w += p.w;
-          }
-          v[i] = x;
-          sum += (x.x + x.y) + (x.z + x.w);
-        }
-      }
-      const float mean = wave_sum(sum) / (float)d;
-      float sq = 0.f;
-#pragma unroll
-      for (int i = 0; i < VC_LN_MAXV4; ++i) {
-        if (i < nv4) {
-          const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
-          sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
-        }
-      }
-      const float rstd = 1.0f / sqrtf(wave_sum(sq) / (float)d + 1e-5f);
-      const bool writer = a.h_out && grp == 0 && ((r % (int)gridDim.x) == (int)blockIdx.x);
-#pragma unroll
-      for (int i = 0; i < VC_LN_MAXV4; ++i) {
-        if (i < nv4) {
-          const int c = (i * 64 + lane) * 4;
-          if (writer) *reinterpret_cast<float4*>(a.h_out + (long)r * d + c) = v[i];
-          const float4 g = *reinterpret_cast<const float4*>(a.ln_w + c);
-          const float4 b = *reinterpret_cast<const float4*>(a.ln_b + c);
-          f32x4 y;
-          y[0] = (v[i].x - mean) * rstd * g.x + b.x;
-          y[1] = (v[i].y - mean) * rstd * g.y + b.y;
-          y[2] = (v[i].z - mean) * rstd * g.z + b.z;
-          y[3] = (v[i].w - mean) * rstd * g.w + b.w;
-          store4(reinterpret_cast<WT*>(xl + (size_t)r * xs) + c, y);
-        }
-      }
+    const int nq = d >> 2;                               // float4 per row (<= 512)
+    const bool on0 = tid < nq, on1 = tid + 256 < nq;
+    const int c0 = on0 ? tid * 4 : 0, c1 = on1 ? (tid + 256) * 4 : 0;
+    const float4 g0 = *reinterpret_cast<const float4*>(a.ln_w + c0), g1 = *reinterpret_cast<const float4*>(a.ln_w + c1);
+    const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + c0), b1 = *reinterpret_cast<const float4*>(a.ln_b + c1);
+    const float4 pb0 = *reinterpret_cast<const float4*>(a.prev_bias + c0), pb1 = *reinterpret_cast<const float4*>(a.prev_bias + c1);
+    const bool use_pb = a.has_prev_bias != 0;
+    float4 x0, x1, p0[VC_MAX_KSPLIT], p1[VC_MAX_KSPLIT];
+    int sr;
+#define VC_LOAD_ROW(r)                                                                          \
+    {                                                                                            \
+      sr = (r);                                                                                  \
+      if (a.gather_rows) sr = a.gather_rows[(r)];                                                \
+      const float* hp_ = a.h_in + (long)sr * d;                                                  \
+      x0 = *reinterpret_cast<const float4*>(hp_ + c0);                                           \
+      x1 = *reinterpret_cast<const float4*>(hp_ + c1);                                           \
+      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_KSPLIT; ++s_) {                             \
+        const float* pp_ = a.parts + ((long)(s_ * VC_ROWS + sr)) * d;                            \
+        p0[s_] = *reinterpret_cast<const float4*>(pp_ + c0);                                     \
+        p1[s_] = *reinterpret_cast<const float4*>(pp_ + c1);                                     \
+      }                                                                                          \
     }
+#define VC_FINISH_ROW(r)                                                                         \
+    {                                                                                            \
+      if (use_pb) {                                                                              \
+        x0.x += pb0.x; x0.y += pb0.y; x0.z += pb0.z; x0.w += pb0.w;                              \
+        x1.x += pb1.x; x1.y += pb1.y; x1.z += pb1.z; x1.w += pb1.w;                              \
+      }                                                                                          \
+      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_KSPLIT; ++s_) {                             \
+        const bool u_ = s_ < a.n_parts;                                                          \
+        x0.x += u_ ? p0[s_].x : 0.f; x0.y += u_ ? p0[s_].y : 0.f; x0.z += u_ ? p0[s_].z : 0.f; x0.w += u_ ? p0[s_].w : 0.f; \
+        x1.x += u_ ? p1[s_].x : 0.f; x1.y += u_ ? p1[s_].y : 0.f; x1.z += u_ ? p1[s_].z : 0.f; x1.w += u_ ? p1[s_].w : 0.f; \
+      }                                                                                          \
+      const float t0_ = on0 ? ((x0.x + x0.y) + (x0.z + x0.w)) : 0.f;                             \
+      const float t1_ = on1 ? ((x1.x + x1.y) + (x1.z + x1.w)) : 0.f;                             \
+      const float ws_ = wave_sum(t0_ + t1_);                                                     \
+      if (lane == 0) s_sum[wave] = ws_;                                                          \
+      __syncthreads();                                                                           \
+      const float mean_ = ((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) / (float)d;            \
+      const float dx_ = x0.x - mean_, dy_ = x0.y - mean_, dz_ = x0.z - mean_, dw_ = x0.w - mean_; \
+      const float ex_ = x1.x - mean_, ey_ = x1.y - mean_, ez_ = x1.z - mean_, ew_ = x1.w - mean_; \
+      const float q0_ = on0 ? ((dx_ * dx_ + dy_ * dy_) + (dz_ * dz_ + dw_ * dw_)) : 0.f;         \
+      const float q1_ = on1 ? ((ex_ * ex_ + ey_ * ey_) + (ez_ * ez_ + ew_ * ew_)) : 0.f;         \
+      const float wq_ = wave_sum(q0_ + q1_);                                                     \
+      if (lane == 0) s_sq[wave] = wq_;                                                           \
+      __syncthreads();                                                                           \
+      const float rstd_ = 1.0f / sqrtf(((s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3])) / (float)d + 1e-5f); \
+      const bool writer_ = a.h_out && grp == 0 && (((r) % (int)gridDim.x) == (int)blockIdx.x);   \
+      WT* xr_ = reinterpret_cast<WT*>(xl + (size_t)(r) * xs);                                    \
+      if (on0) {                                                                                 \
+        if (writer_) *reinterpret_cast<float4*>(a.h_out + (long)(r) * d + c0) = x0;              \
+        f32x4 y_;                                                                                \
+        y_[0] = dx_ * rstd_ * g0.x + b0.x; y_[1] = dy_ * rstd_ * g0.y + b0.y;                    \
+        y_[2] = dz_ * rstd_ * g0.z + b0.z; y_[3] = dw_ * rstd_ * g0.w + b0.w;                    \
+        store4(xr_ + c0, y_);                                                                    \
+      }                                                                                          \
+      if (on1) {                                                                                 \
+        if (writer_) *reinterpret_cast<float4*>(a.h_out + (long)(r) * d + c1) = x1;              \
+        f32x4 y_;                                                                                \
+        y_[0] = ex_ * rstd_ * g1.x + b1.x; y_[1] = ey_ * rstd_ * g1.y + b1.y;                    \
+        y_[2] = ez_ * rstd_ * g1.z + b1.z; y_[3] = ew_ * rstd_ * g1.w + b1.w;                    \
+        store4(xr_ + c1, y_);                                                                    \
+      }                                                                                          \
+    }
+    VC_LOAD_ROW(0);
+    VC_ISSUE_WEIGHTS();
+    VC_FINISH_ROW(0);
+    for (int r = 1; r < n_rows; ++r) {
+      VC_LOAD_ROW(r);
+      VC_FINISH_ROW(r);
+    }
+#undef VC_LOAD_ROW
+#undef VC_FINISH_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
+    VC_ISSUE_WEIGHTS();
     const int upr = kblk * (int)sizeof(WT) / 16;  // 16-byte units per row
     const char* src = reinterpret_cast<const char*>(a.x_in);
     for (int idx = tid; idx < n_rows * upr; idx += 256) {
@@ -170,29 +202,58 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + off);
     }
   } else {  // PRO_ATT: merge the split-S partials of the decode attention (softmax denominators)
+    // item = (row, 4 columns of one head); its 2*VC_MAX_NSPLIT loads are requested before the
+    // weight burst, the exp/scale arithmetic runs behind it.
     const int q4 = kblk >> 2;
-    for (int idx = tid; idx < n_rows * q4; idx += 256) {
-      const int r = idx / q4, c = k0 + (idx - r * q4) * 4;
-      const int h = c / a.hd, e = c - h * a.hd;
-      const float* ml = a.att_ml + ((long)(r * a.H + h) * a.nsplit) * 2;
-      const float* op = a.att_o + ((long)(r * a.H + h) * a.nsplit) * a.hd + e;
-      float M = -INFINITY;
-      for (int s = 0; s < a.nsplit; ++s) M = fmaxf(M, ml[2 * s]);
-      float L = 0.f;
-      f32x4 o = {0.f, 0.f, 0.f, 0.f};
-      for (int s = 0; s < a.nsplit; ++s) {
-        const float ms = ml[2 * s];
-        if (ms == -INFINITY) continue;
-        const float w = expf(ms - M);
-        L += w * ml[2 * s + 1];
-        const float4 os = *reinterpret_cast<const float4*>(op + (long)s * a.hd);
-        o[0] += w * os.x; o[1] += w * os.y; o[2] += w * os.z; o[3] += w * os.w;
-      }
-      const float inv = (L > 0.f) ? 1.0f / L : 0.f;
-      o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
-      store4(reinterpret_cast<WT*>(xl + (size_t)r * xs) + (c - k0), o);
+    const int n_items = n_rows * q4;
+    float2 mls[VC_MAX_NSPLIT];
+    float4 os[VC_MAX_NSPLIT];
+    int r_, c_;
+    bool on_;
+#define VC_LOAD_ITEMS(base)                                                                      \
+    {                                                                                            \
+      const int idx_ = (base) + tid;                                                             \
+      on_ = idx_ < n_items;                                                                      \
+      r_ = on_ ? idx_ / q4 : 0;                                                                  \
+      c_ = k0 + (on_ ? (idx_ - r_ * q4) : 0) * 4;                                                \
+      const int h_ = c_ / a.hd, e_ = c_ - h_ * a.hd;                                             \
+      const float2* ml_ = reinterpret_cast<const float2*>(a.att_ml) + (long)(r_ * a.H + h_) * a.nsplit; \
+      const float* op_ = a.att_o + ((long)(r_ * a.H + h_) * a.nsplit) * a.hd + e_;               \
+      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
+        const int se_ = (s_ < a.nsplit) ? s_ : 0;                                                \
+        mls[s_] = ml_[se_];                                                                      \
+        os[s_] = *reinterpret_cast<const float4*>(op_ + (long)se_ * a.hd);                       \
+      }                                                                                          \
     }
+#define VC_FINISH_ITEMS()                                                                        \
+    {                                                                                            \
+      float M_ = -INFINITY;                                                                      \
+      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
+        mls[s_].x = (s_ < a.nsplit) ? mls[s_].x : -INFINITY;                                     \
+        M_ = fmaxf(M_, mls[s_].x);                                                               \
+      }                                                                                          \
+      float L_ = 0.f;                                                                            \
+      f32x4 o_ = {0.f, 0.f, 0.f, 0.f};                                                           \
+      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
+        const float w_ = (mls[s_].x == -INFINITY) ? 0.f : expf(mls[s_].x - M_);                  \
+        L_ += w_ * mls[s_].y;                                                                    \
+        o_[0] += w_ * os[s_].x; o_[1] += w_ * os[s_].y; o_[2] += w_ * os[s_].z; o_[3] += w_ * os[s_].w; \
+      }                                                                                          \
+      const float inv_ = (L_ > 0.f) ? 1.0f / L_ : 0.f;                                           \
+      o_[0] *= inv_; o_[1] *= inv_; o_[2] *= inv_; o_[3] *= inv_;                                \
+      if (on_) store4(reinterpret_cast<WT*>(xl + (size_t)r_ * xs) + (c_ - k0), o_);              \
+    }
+    VC_LOAD_ITEMS(0);
+    VC_ISSUE_WEIGHTS();
+    VC_FINISH_ITEMS();
+    for (int base = 256; base < n_items; base += 256) {
+      VC_LOAD_ITEMS(base);
+      VC_FINISH_ITEMS();
+    }
+#undef VC_LOAD_ITEMS
+#undef VC_FINISH_ITEMS
   }
+#undef VC_ISSUE_WEIGHTS
   __syncthreads();
 
   // (3) main loop: one ds_read_b128 + one MFMA per 1 KiB weight burst

@@ -50,18 +50,20 @@ extern "C" int vc_pattern_shift(const int64_t* z_dev, int B, int K, int T, int64
 }
 extern "C" int vc_pattern_revert(const int64_t* s_dev, int B, int K, int S, int T, int64_t special,
                                  int64_t* out_dev, void* stream) {
-  if (!s_dev || !out_dev || B <= 0 || K <= 0 || S < 0 || T < 0 || S > T + K) return VC_EINVAL;
+  if (B <= 0 || K <= 0 || S < 0 || T < 0 || S > T + K) return VC_EINVAL;
   const long total = (long)B * K * T;
   if (total == 0) return VC_OK;
+  if (!s_dev || !out_dev) return VC_EINVAL;
   hipLaunchKernelGGL(pattern_revert_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, s_dev, K, S, T, special, out_dev, total);
   return hipGetLastError() == hipSuccess ? VC_OK : VC_EHIP;
 }
 extern "C" int vc_pattern_unshift(const int64_t* span_dev, int N, int K, int64_t* out_dev,
                                   void* stream) {
-  if (!span_dev || !out_dev || K <= 0 || N < K) return VC_EINVAL;
+  if (K <= 0 || N < K) return VC_EINVAL;
   const long total = (long)K * (N - K);
-  if (total == 0) return VC_OK;
+  if (total == 0) return VC_OK;                      // N == K: a span of only terminator steps holds no frame
+  if (!span_dev || !out_dev) return VC_EINVAL;
   hipLaunchKernelGGL(pattern_unshift_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, span_dev, N, K, out_dev);
   return hipGetLastError() == hipSuccess ? VC_OK : VC_EHIP;
@@ -149,7 +151,8 @@ __device__ __forceinline__ uint32_t fkey(float f) {   // order-preserving float 
 }
 __device__ __forceinline__ bool is_silence(const SampleArgs& a, int tok) {
   bool r = false;
-  for (int i = 0; i < a.n_silence; ++i) r |= (a.silence[i] == tok);
+#pragma unroll
+  for (int i = 0; i < VC_MAX_SILENCE; ++i) r |= (i < a.n_silence && a.silence[i] == tok);   // static indices: no scratch copy
   return r;
 }
 
@@ -165,9 +168,10 @@ __device__ void sample_phase(const SampleArgs& a, int b) {
     const float* row = a.logits + ((long)b * a.K + k) * a.V;
     float v[VC_VPL];
 #pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) {
+    for (int j = 0; j < VC_VPL; ++j) {               // unconditional (clamped) loads: all 34 in flight at once
       const int i = lane + 64 * j;
-      v[j] = (i < a.V) ? row[i] : -INFINITY;
+      const float t = row[min(i, a.V - 1)];
+      v[j] = (i < a.V) ? t : -INFINITY;
     }
     if (a.logits_out && b == 0 && step < a.logit_steps) {
       float* lo = a.logits_out + ((long)step * a.K + k) * a.V;
@@ -194,43 +198,42 @@ __device__ void sample_phase(const SampleArgs& a, int b) {
       if (pen && i == st.prev_token) v[j] = (v[j] < 0.f) ? v[j] * pen_f : v[j] / pen_f;
     }
     // ---- argmax of the edited logits (first index on ties, as torch.argmax)
-    float bv = -INFINITY; int bi = 0x7fffffff;
+    float bv = -INFINITY;
 #pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) {
-      const int i = lane + 64 * j;
-      if (i < a.V && (v[j] > bv || (v[j] == bv && i < bi))) { bv = v[j]; bi = i; }
-    }
-    for (int off = 32; off > 0; off >>= 1) {
-      const float ov = __shfl_xor(bv, off, 64);
-      const int oi = __shfl_xor(bi, off, 64);
-      if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
-    }
+    for (int j = 0; j < VC_VPL; ++j) bv = fmaxf(bv, v[j]);     // padding lanes hold -inf
+    bv = wave_max(bv);
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int j = VC_VPL - 1; j >= 0; --j)
+      if (v[j] == bv && lane + 64 * j < a.V) bi = lane + 64 * j;
+    bi = wave_min_i(bi);
     // ---- temperature
     if (a.temperature != 1.0f) {
 #pragma unroll
       for (int j = 0; j < VC_VPL; ++j) v[j] = v[j] / a.temperature;
     }
-    // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive)
+    // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive).
+    // Bitwise binary search for the k-th largest order-preserving key; per-lane counts are
+    // combined on the DPP path.
     if (a.top_k > 0) {
       const int kk = min(max(a.top_k, 1), a.V);
+      uint32_t key[VC_VPL];
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) key[j] = (lane + 64 * j < a.V) ? fkey(v[j]) : 0u;
       uint32_t t = 0;
       for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = t | (1u << bit);
         int c = 0;
 #pragma unroll
-        for (int j = 0; j < VC_VPL; ++j) c += (lane + 64 * j < a.V && fkey(v[j]) >= cand) ? 1 : 0;
-        c = wave_sum_i(c);
-        if (c >= kk) t = cand;
+        for (int j = 0; j < VC_VPL; ++j) c += (key[j] >= cand) ? 1 : 0;
+        if (wave_sum_i(c) >= kk) t = cand;
       }
 #pragma unroll
       for (int j = 0; j < VC_VPL; ++j)
-        if (fkey(v[j]) < t) v[j] = -INFINITY;
+        if (key[j] < t) v[j] = -INFINITY;
     }
     // ---- softmax numerators
-    float mx = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) mx = fmaxf(mx, v[j]);
-    mx = wave_max(mx);
+    const float mx = (a.temperature != 1.0f) ? bv / a.temperature : bv;   // filters never remove the maximum
     float p[VC_VPL];
     float ps = 0.f;
 #pragma unroll
