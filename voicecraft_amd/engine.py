@@ -347,6 +347,7 @@ def pattern_unshift(span: torch.Tensor) -> torch.Tensor:
     assert span.is_cuda and span.dtype == torch.int64 and span.ndim == 2
     span = span.contiguous()
     N, K = span.shape
+    assert N >= K, f"a span has at least K={K} steps, got {N}"      # voicecraft.py:1137
     out = torch.empty((K, N - K), dtype=torch.int64, device=span.device)
     _pattern_call(lib.vc_pattern_unshift, C.c_void_p(span.data_ptr()), N, K, C.c_void_p(out.data_ptr()),
                   C.c_void_p(torch.cuda.current_stream(span.device).cuda_stream))
