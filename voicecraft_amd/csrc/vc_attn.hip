@@ -62,24 +62,38 @@ __global__ __launch_bounds__(256) void rows_attn_k(const AttnArgs a) {
     const long base = (long)a.row_seq[r] * a.cache_seq_stride + (long)h * a.S_max * hd + li * EPL;
     const WT* kb = reinterpret_cast<const WT*>(a.kcache) + base;
     const WT* vb = reinterpret_cast<const WT*>(a.vcache) + base;
-    const int step = 4 * PPW;
-    for (int p = p0 + wave * PPW + sub; p < p1; p += step) {
-      const uint4 ku = *reinterpret_cast<const uint4*>(kb + (long)p * hd);
-      const uint4 vu = *reinterpret_cast<const uint4*>(vb + (long)p * hd);
-      float kf[EPL], vf[EPL];
-      unpack16<WT>(ku, kf);
-      unpack16<WT>(vu, vf);
-      float s = 0.f;
+    // 4 visits per wave are requested at once (clamped, unconditional) so that K and V of up to
+    // 16*PPW positions are in flight together; the online-softmax update then runs on registers.
+    for (int pb = p0; pb < p1; pb += 16 * PPW) {
+      uint4 ku[4], vu[4];
+      int pp[4];
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) s += q[j] * kf[j];
-      for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
-      const float mn = fmaxf(m, s);
-      const float corr = expf(m - mn);     // m = -inf on the first visit -> 0
-      const float pe = expf(s - mn);
-      l = l * corr + pe;
+      for (int it = 0; it < 4; ++it) {
+        pp[it] = pb + (it * 4 + wave) * PPW + sub;
+        const long pc = min(pp[it], p1 - 1);
+        ku[it] = *reinterpret_cast<const uint4*>(kb + pc * hd);
+        vu[it] = *reinterpret_cast<const uint4*>(vb + pc * hd);
+      }
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) o[j] = o[j] * corr + pe * vf[j];
-      m = mn;
+      for (int it = 0; it < 4; ++it) {
+        float kf[EPL], vf[EPL];
+        unpack16<WT>(ku[it], kf);
+        unpack16<WT>(vu[it], vf);
+        float sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) sc += q[j] * kf[j];
+        if (LPR == 8) sc = half_row_sum(sc);
+        else { sc = row_sum(sc); if (LPR == 32) sc += __shfl_xor(sc, 16, 64); }
+        if (pp[it] < p1) {
+          const float mn = fmaxf(m, sc);
+          const float corr = expf(m - mn);     // m = -inf on the first visit -> 0
+          const float pe = expf(sc - mn);
+          l = l * corr + pe;
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) o[j] = o[j] * corr + pe * vf[j];
+          m = mn;
+        }
+      }
     }
   }
   // merge the PPW position groups of this wave (same li, different sub)

@@ -298,5 +298,7 @@ hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s);
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s);
 hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s);
 hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStream_t s);
+struct PrefetchArgs { const uint4* p[6]; long n[6]; int n_seg; };   // n in 16-byte units
+hipError_t vc_launch_prefetch(const PrefetchArgs& a, hipStream_t s);
 hipError_t vc_launch_copy_kv(void* cache, long seq_stride, int H, int S_max, int hd, int len,
                              int src_seq, int dst_seq0, int n_dst, int dtype, hipStream_t s);

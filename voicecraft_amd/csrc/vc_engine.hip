@@ -75,6 +75,10 @@ struct vc_engine {
   int *h_flag = nullptr;
 
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
+  hipStream_t pf_stream = nullptr;      // side stream of the Infinity-Cache weight prefetch
+  std::vector<hipEvent_t> pf_ev;        // fork/join events, one pair per stage
+  int prefetch = 0;                     // VC_PREFETCH=1: overlap next-stage weight streaming
+  std::vector<PrefetchArgs> pf_args;    // stage i: layer i (i < L), stage L: the heads
   hipEvent_t ev[3]{};
   float ms[3]{0, 0, 0};
   double bytes_total = 0;               // HBM bytes owned by the engine
@@ -201,10 +205,25 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   return g;
 }
 
-int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
+// Fork: the side stream starts streaming stage (st+1)'s weights once stage st begins.
+int fork_prefetch(vc_engine* e, int st, hipStream_t s) {
+  const int nxt = (st + 1) % (e->L + 1);
+  HIPCHK(e, hipEventRecord(e->pf_ev[2 * st], s));
+  HIPCHK(e, hipStreamWaitEvent(e->pf_stream, e->pf_ev[2 * st], 0));
+  HIPCHK(e, vc_launch_prefetch(e->pf_args[nxt], e->pf_stream));
+  return VC_OK;
+}
+int join_prefetch(vc_engine* e, hipStream_t s) {
+  HIPCHK(e, hipEventRecord(e->pf_ev[1], e->pf_stream));
+  HIPCHK(e, hipStreamWaitEvent(s, e->pf_ev[1], 0));
+  return VC_OK;
+}
+
+int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = false) {
   const int d = e->d;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
+    if (prefetch) { int rc = fork_prefetch(e, l, s); if (rc) return rc; }
     {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; g.bias = ly.bqkv;
@@ -338,11 +357,14 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = B * rps; rs.nsplit = attn_nsplit(e, B * rps); rs.n_active = e->n_active;
-  int rc = forward_rows(e, rs, s);
+  const bool pf = e->prefetch != 0;
+  int rc = forward_rows(e, rs, s, pf);
   if (rc) return rc;
+  if (pf) { rc = fork_prefetch(e, e->L, s); if (rc) return rc; }
   rc = run_heads(e, e->logit_row, B, 0, e->n_active, s);
   if (rc) return rc;
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
+  if (pf) { rc = join_prefetch(e, s); if (rc) return rc; }
   return VC_OK;
 }
 
@@ -469,6 +491,8 @@ extern "C" void vc_destroy(vc_engine* e) {
   if (e->h_flag) hipHostFree(e->h_flag);
   for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
+  if (e->pf_stream) hipStreamDestroy(e->pf_stream);
+  for (auto& ev : e->pf_ev) if (ev) hipEventDestroy(ev);
   delete e;
 }
 
@@ -629,7 +653,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->st, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
-  if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * VC_MAX_CODEBOOKS))) return rc;
+  if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->amax, (size_t)VC_ROWS))) return rc;
   e->gen_cap = e->S_max;
@@ -641,6 +665,30 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
   // a blocking stream: implicitly ordered after work the caller queued on the null stream
   HIPCHK(e, hipStreamCreate(&e->own_stream));
+  HIPCHK(e, hipStreamCreateWithFlags(&e->pf_stream, hipStreamNonBlocking));
+  e->pf_ev.resize(2 * (size_t)(L + 1));
+  for (auto& ev : e->pf_ev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  {
+    const char* pv = getenv("VC_PREFETCH");
+    e->prefetch = pv ? atoi(pv) : 0;
+    const long KWb = 1;   // sizes below are in 16-byte units = packed fragments
+    e->pf_args.resize((size_t)L + 1);
+    auto units = [&](int N, int Kd) { const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16; return (long)((N + 15) / 16) * (Kd / KW) * 64 * KWb; };
+    for (int l = 0; l < L; ++l) {
+      PrefetchArgs& pa = e->pf_args[l];
+      memset(&pa, 0, sizeof pa);
+      pa.n_seg = 4;
+      pa.p[0] = e->layers[l].Wqkv; pa.n[0] = units(3 * d, d);
+      pa.p[1] = e->layers[l].Wo; pa.n[1] = units(d, d);
+      pa.p[2] = e->layers[l].W1; pa.n[2] = units(4 * d, d);
+      pa.p[3] = e->layers[l].W2; pa.n[3] = units(d, 4 * d);
+    }
+    PrefetchArgs& ph = e->pf_args[L];
+    memset(&ph, 0, sizeof ph);
+    ph.n_seg = 2;
+    ph.p[0] = e->Wh1; ph.n[0] = units(K * P, d);
+    ph.p[1] = e->Wh2; ph.n[1] = e->wh2_group_stride * K;
+  }
   HIPCHK(e, hipDeviceSynchronize());
   e->finalized = true;
   return VC_OK;
@@ -950,8 +998,12 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = n_rows; rs.nsplit = attn_nsplit(e, n_rows);
+  bool hot = false;
+  std::string w2 = w;
+  if (w.size() > 4 && w.substr(w.size() - 4) == "_hot") { hot = true; w2 = w.substr(0, w.size() - 4); }
   auto one = [&](int i) -> int {
-    Layer& ly = e->layers[i % e->L];
+    Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
+    const std::string& w = w2;
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
@@ -970,6 +1022,13 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+    } else if (w == "attn") {
+      AttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
+      a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
+      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);
       if (r) return r;
@@ -989,6 +1048,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   *avg_ms = ms / (float)iters;
   if (alg_bytes) {
     const double es = e->esz;
+    const std::string& w = w2;
     double b = 0;
     if (w == "ffn1") b = 4.0 * d * d * es + n_rows * (d * 4.0 + 4.0 * d * es);
     else if (w == "ffn2") b = 4.0 * d * d * es + n_rows * (4.0 * d * es + d * 4.0);

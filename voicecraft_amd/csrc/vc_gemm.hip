@@ -68,8 +68,32 @@ hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStr
   return hipGetLastError();
 }
 
+// ------------------------------------------------------------------ Infinity-Cache prefetch
+// A dependency-free streaming read of the NEXT stage's weights, launched on a side stream while the
+// current stage's (dependent, latency-bound) kernels run: it pulls the bytes through HBM into the
+// 256 MiB memory-side cache, so the consumer's weight burst is served from there.  It never waits on
+// anything, so it cannot deadlock; one 256-thread block per CU leaves the consumers their slots.
+__global__ __launch_bounds__(256) void prefetch_k(const PrefetchArgs a) {
+  uint32_t acc = 0;
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (int sg = 0; sg < a.n_seg; ++sg) {
+    const uint4* p = a.p[sg];
+    const long n = a.n[sg];
+    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+      const uint4 v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
+      acc ^= v0.x ^ v1.x ^ v2.x ^ v3.x;
+    }
+    for (; i < n; i += stride) acc ^= p[i].x;
+  }
+  asm volatile("" ::"v"(acc));   // keep the loads alive without storing anything
+}
+hipError_t vc_launch_prefetch(const PrefetchArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL(prefetch_k, dim3(256), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 // ------------------------------------------------------------------ rows GEMM
-#define VC_LN_MAXV4 8      // d <= 64 lanes * 4 floats * 8 = 2048 (checked in vc_create)
 
 __device__ __forceinline__ void store4(float* p, const f32x4& v) {
   *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);

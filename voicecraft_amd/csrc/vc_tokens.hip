@@ -159,8 +159,10 @@ __device__ __forceinline__ bool is_silence(const SampleArgs& a, int tok) {
 // Phase 1 (one block per sequence, one wave per codebook): logit edits, top-k / top-p filter,
 // categorical draw.  Restates sample_helper + topk_sampling + top_k_top_p_filtering
 // (models/voicecraft.py:1018-1067, :71-86, :26-68).  Writes samp[b][k], cond[b], amax[b].
-__device__ void sample_phase(const SampleArgs& a, int b) {
-  const SeqState st = a.st[b];
+// `sp` is the sequence state (in LDS); results go to xs (LDS in the fused kernel, HBM scratch when the
+// keep decision needs the kernel boundary): xs[0..K) tokens, xs[K] arg-max of codebook 0, xs[K+1] cond.
+__device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int* xs) {
+  const SeqState st = *sp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (st.done) return;
   const int step = st.total_steps;
@@ -299,43 +301,41 @@ __device__ void sample_phase(const SampleArgs& a, int b) {
     }
     tok = __shfl(tok, src_lane, 64);
     if (lane == 0) {
-      a.samp[b * a.K + k] = tok;
-      if (k == 0) a.amax[b] = bi;
+      xs[k] = tok;
+      if (k == 0) xs[a.K] = bi;
     }
   }
   __syncthreads();
   if (tid == 0) {
     int c = 0;
-    if (st.n_eog == 0) {
-      const int t0 = a.samp[b * a.K];
-      c = (t0 == st.term_token) || (a.amax[b] == st.term_token) || (st.y_len > st.cap_len);
-    }
-    a.cond[b] = c;
+    if (st.n_eog == 0) c = (xs[0] == st.term_token) || (xs[a.K] == st.term_token) || (st.y_len > st.cap_len);
+    xs[a.K + 1] = c;
   }
 }
 
 // Phase 2 (one block per sequence): advance the state machine, log the step's tokens and build
 // the next decode rows (embedding sum + position, voicecraft.py:1102-1116; span switch :838-858).
-__device__ void advance_phase(const SampleArgs& a, int b, bool grouped) {
+__device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState* sp, const int* xs) {
   __shared__ int s_tok[VC_MAX_CODEBOOKS];
   __shared__ int s_mode;     // 0: row inactive, 1: one new row, 3: span switch (three rows)
   __shared__ int s_ylen, s_mask, s_Lx;
   const int tid = threadIdx.x;
   const int K = a.K;
   if (tid == 0) {
-    SeqState st = a.st[b];
+    SeqState& st = *sp;                 // lives in LDS: the span arrays are indexed dynamically
     s_mode = 0;
     if (!st.done) {
       int tok[VC_MAX_CODEBOOKS];
-      for (int k = 0; k < K; ++k) tok[k] = a.samp[b * K + k];
-      int cond = a.cond[b];
+#pragma unroll
+      for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) tok[k] = (k < K) ? xs[k] : 0;
+      int cond = xs[K + 1];
       bool drop = false;
       if (grouped && st.n_eog == 0) {
         // best-of-N (voicecraft.py:1296-1302): the LAST sample whose first codebook terminates is kept
         int keep = -1;
         for (int bb = 0; bb < a.B; ++bb)
-          if (a.st[bb].group == st.group && a.cond[bb]) keep = bb;   // group is immutable; every member is
-                                                                      // still alive while n_eog == 0
+          if (a.st[bb].group == st.group && a.samp[bb * (VC_MAX_CODEBOOKS + 2) + K + 1]) keep = bb;
+        // (group ids are immutable and every member is still alive while n_eog == 0)
         if (keep >= 0 && keep != b) drop = true;
       }
       const int step = st.total_steps;
@@ -392,7 +392,6 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped) {
         s_mode = 1;
         st.y_len += 1;
       }
-      a.st[b] = st;
     }
     const int r0 = b * a.rps;
     for (int i = 0; i < a.rps; ++i) {
@@ -421,19 +420,38 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped) {
   }
 }
 
-__global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
-  if (*a.n_active == 0) return;
-  sample_phase(a, blockIdx.x);
+__device__ __forceinline__ void load_state(const SampleArgs& a, int b, SeqState* sp) {
+  constexpr int W = sizeof(SeqState) / 4;
+  if (threadIdx.x < W) reinterpret_cast<int*>(sp)[threadIdx.x] = reinterpret_cast<const int*>(a.st + b)[threadIdx.x];
   __syncthreads();
-  advance_phase(a, blockIdx.x, false);
+}
+__device__ __forceinline__ void store_state(const SampleArgs& a, int b, const SeqState* sp) {
+  constexpr int W = sizeof(SeqState) / 4;
+  __syncthreads();
+  if (threadIdx.x < W) reinterpret_cast<int*>(a.st + b)[threadIdx.x] = reinterpret_cast<const int*>(sp)[threadIdx.x];
+}
+__global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
+  __shared__ SeqState s_st;
+  __shared__ int s_xs[VC_MAX_CODEBOOKS + 2];
+  if (*a.n_active == 0) return;
+  load_state(a, blockIdx.x, &s_st);
+  sample_phase(a, blockIdx.x, &s_st, s_xs);
+  __syncthreads();
+  advance_phase(a, blockIdx.x, false, &s_st, s_xs);
+  store_state(a, blockIdx.x, &s_st);
 }
 __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
+  __shared__ SeqState s_st;
   if (*a.n_active == 0) return;
-  sample_phase(a, blockIdx.x);
+  load_state(a, blockIdx.x, &s_st);
+  sample_phase(a, blockIdx.x, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2));
 }
 __global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
+  __shared__ SeqState s_st;
   if (*a.n_active == 0) return;
-  advance_phase(a, blockIdx.x, true);
+  load_state(a, blockIdx.x, &s_st);
+  advance_phase(a, blockIdx.x, true, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2));
+  store_state(a, blockIdx.x, &s_st);
 }
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
   if (!grouped) {
