@@ -86,6 +86,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 
+    from voicecraft_amd import dist as vdist
     from voicecraft_amd import synth
     from voicecraft_amd.engine import VoiceCraftEngine
     a = synth.make_args(args.preset)
@@ -111,11 +112,7 @@ def main():
             gens = [o[1] for o in outs]
         n_tok = sum(int(g.shape[2]) * K for g in gens)
         if dist is not None:   # the single collective of the job: gather every rank's token block
-            blk = torch.full((B, K, Tg + 8), -1, dtype=torch.int32, device=dev)
-            for b, g in enumerate(gens):
-                blk[b, :, : g.shape[2]] = g[0].to(torch.int32)
-            out = [torch.empty_like(blk) for _ in range(world)]
-            dist.all_gather(out, blk)
+            vdist.gather_token_blocks([g[0] for g in gens], Tg + 8, n_slots=B, K=K, device=dev)
         return n_tok
 
     for w in range(args.warmup):
@@ -157,7 +154,8 @@ def main():
         k_ms, k_bytes = eng.bench_kernel("ffn1", n_rows=B, iters=64)
         step_ms, _ = eng.bench_kernel("step", n_rows=B, iters=8)
         kernels = {}
-        for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
+        for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot",
+                   "ffn1_pf", "pf_ffn1", "ffn2_pf", "pf_ffn2"):
             ms_, by_ = eng.bench_kernel(kn, n_rows=B, iters=64)
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
         roof = {"bound": "hbm", "kernel": "rows_gemm_k<LN,ReLU> (FFN up-projection)",

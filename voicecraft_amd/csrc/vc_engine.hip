@@ -998,12 +998,26 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = n_rows; rs.nsplit = attn_nsplit(e, n_rows);
-  bool hot = false;
+  bool hot = false, pre = false;
   std::string w2 = w;
   if (w.size() > 4 && w.substr(w.size() - 4) == "_hot") { hot = true; w2 = w.substr(0, w.size() - 4); }
+  // "<k>_pf": a dependency-free streaming read of the same weights runs right before the kernel
+  // (same stream); "pf_<k>": that read alone.  t(<k>_pf) - t(pf_<k>) = the kernel on cache-warm weights.
+  if (w.size() > 3 && w.substr(w.size() - 3) == "_pf") { pre = true; w2 = w.substr(0, w.size() - 3); }
+  bool only_pf = false;
+  if (w.size() > 3 && w.substr(0, 3) == "pf_") { only_pf = true; pre = true; w2 = w.substr(3); }
   auto one = [&](int i) -> int {
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
+    if (pre) {
+      PrefetchArgs pa;
+      memset(&pa, 0, sizeof pa);
+      const PrefetchArgs& full = e->pf_args[i % e->L];
+      const int sg = w == "qkv" ? 0 : w == "oproj" ? 1 : w == "ffn1" ? 2 : 3;
+      pa.n_seg = 1; pa.p[0] = full.p[sg]; pa.n[0] = full.n[sg];
+      HIPCHK(e, vc_launch_prefetch(pa, s));
+      if (only_pf) return VC_OK;
+    }
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;

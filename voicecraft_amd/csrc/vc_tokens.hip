@@ -403,19 +403,48 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState
   __syncthreads();
   const int mode = s_mode;
   if (mode == 0) return;
+  // next-step input row(s): sum of the K codebook embeddings of the emitted tokens + alpha*pe
+  // (voicecraft.py:1102-1116).  All K gathers of a thread are requested together (float4 columns).
   const int d = a.d;
   const int ylen = s_ylen;
   float* h0 = a.dec_h + (long)(b * a.rps) * d;
   const float* pe0 = a.pe + (long)ylen * d;
-  for (int c = tid; c < d; c += blockDim.x) {
-    float v = a.audio_emb[((long)0 * a.V + s_tok[0]) * d + c];
-    for (int k = 1; k < K; ++k) v += a.audio_emb[((long)k * a.V + s_tok[k]) * d + c];
-    h0[c] = v + a.alpha_audio * pe0[c];
-    if (mode == 3) {
-      h0[d + c] = a.mask_emb[(long)s_mask * d + c] + a.alpha_audio * pe0[d + c];
-      float e = a.audio_emb[((long)0 * a.V + a.empty_token) * d + c];
-      for (int k = 1; k < K; ++k) e += a.audio_emb[((long)k * a.V + a.empty_token) * d + c];
-      h0[2 * d + c] = e + a.alpha_audio * pe0[2 * d + c];
+  const int nq = d >> 2;
+  for (int i = tid; i < nq; i += blockDim.x) {
+    float4 e[VC_MAX_CODEBOOKS];
+#pragma unroll
+    for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) {
+      const int kk = (k < K) ? k : 0;
+      e[k] = *reinterpret_cast<const float4*>(a.audio_emb + ((long)kk * a.V + s_tok[kk]) * d + i * 4);
+    }
+    const float4 p = *reinterpret_cast<const float4*>(pe0 + i * 4);
+    float4 v = e[0];
+#pragma unroll
+    for (int k = 1; k < VC_MAX_CODEBOOKS; ++k)
+      if (k < K) { v.x += e[k].x; v.y += e[k].y; v.z += e[k].z; v.w += e[k].w; }
+    v.x += a.alpha_audio * p.x; v.y += a.alpha_audio * p.y; v.z += a.alpha_audio * p.z; v.w += a.alpha_audio * p.w;
+    *reinterpret_cast<float4*>(h0 + i * 4) = v;
+  }
+  if (mode == 3) {   // span switch: [last token, mask_embedding[next span], all-empty column] (voicecraft.py:838-858)
+    for (int i = tid; i < nq; i += blockDim.x) {
+      const float4 mk = *reinterpret_cast<const float4*>(a.mask_emb + (long)s_mask * d + i * 4);
+      const float4 p1 = *reinterpret_cast<const float4*>(pe0 + d + i * 4);
+      const float4 p2 = *reinterpret_cast<const float4*>(pe0 + 2 * d + i * 4);
+      float4 e[VC_MAX_CODEBOOKS];
+#pragma unroll
+      for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) {
+        const int kk = (k < K) ? k : 0;
+        e[k] = *reinterpret_cast<const float4*>(a.audio_emb + ((long)kk * a.V + a.empty_token) * d + i * 4);
+      }
+      float4 v = e[0];
+#pragma unroll
+      for (int k = 1; k < VC_MAX_CODEBOOKS; ++k)
+        if (k < K) { v.x += e[k].x; v.y += e[k].y; v.z += e[k].z; v.w += e[k].w; }
+      float4 o1, o2;
+      o1.x = mk.x + a.alpha_audio * p1.x; o1.y = mk.y + a.alpha_audio * p1.y; o1.z = mk.z + a.alpha_audio * p1.z; o1.w = mk.w + a.alpha_audio * p1.w;
+      o2.x = v.x + a.alpha_audio * p2.x; o2.y = v.y + a.alpha_audio * p2.y; o2.z = v.z + a.alpha_audio * p2.z; o2.w = v.w + a.alpha_audio * p2.w;
+      *reinterpret_cast<float4*>(h0 + d + i * 4) = o1;
+      *reinterpret_cast<float4*>(h0 + 2 * d + i * 4) = o2;
     }
   }
 }
