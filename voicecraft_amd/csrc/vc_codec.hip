@@ -1,0 +1,772 @@
+// vc_codec.hip — EnCodec (SEANet encoder/decoder + LSTM + residual VQ) on gfx950.
+//
+// Replaces AudioTokenizer.encode/.decode (data/tokenizer.py:127-133 -> audiocraft EncodecModel,
+// not vendored; architecture restated from transformers.EncodecModel at the VoiceCraft codec shape,
+// SURVEY.md §8c).  Everything is fp32: RVQ codes come out of an arg-min, so the convolutions are
+// kept at full precision and run on the fp32 MFMA (v_mfma_f32_16x16x4_f32, an exact fma chain).
+//
+// Layout: activations are CHANNELS-LAST [time][channel].  A 1-D convolution is then an implicit
+// GEMM  out[t][co] = sum_{k,ci} W[co][ci][k] * x[t*s + k*d - pad][ci]  whose K index is ordered
+// (tap k, channel ci): one 16-wide K tile is 16 consecutive channels of ONE input position, so
+// both MFMA operands are plain 16-byte loads — weights from a pre-packed fragment image, inputs
+// straight from the activation row (no im2col, no LDS staging).  A transposed convolution with
+// kernel = 2*stride is `stride` such GEMMs (one per output phase r) with two taps each:
+//   out[t*s + r - pl][co] = sum_ci W[ci][co][r]*x[t][ci] + W[ci][co][r+s]*x[t-1][ci].
+// ELU always precedes a convolution in SEANet, so every epilogue can write the raw tensor (for
+// the residual skip) and/or its ELU (for the next convolution) — each element is activated once.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/vc_codec.h"
+#include "vc_common.h"
+
+// ============================================================================ kernels
+struct ConvArgs {
+  const float* x;        // [L_in][Ci]
+  const float4* Wp;      // [phase][co_tile][k_tile][lane]
+  const float* bias;     // [Co]
+  const float* res;      // optional residual [L_dst][Co]
+  float* out_raw;        // optional [L_dst][Co]
+  float* out_elu;        // optional [L_dst][Co]
+  int L_in, T, Ci, Co, Kw;
+  int s_in, dil, pad, reflect;
+  int s_out, o_off, L_dst;
+  long w_phase_stride;   // float4 units
+};
+
+__device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
+
+// block = 4 waves along t; a wave owns 32 output channels x 32 positions (2x2 MFMA tiles).
+__global__ __launch_bounds__(256) void conv_gemm_k(const ConvArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int g = lane >> 4, m = lane & 15;
+  const int phase = blockIdx.z;
+  const int t0 = (blockIdx.x * 4 + wave) * 32;
+  const int cot0 = blockIdx.y * 2;                       // first 16-channel tile
+  if (t0 >= a.T) return;
+  const int ktpk = a.Ci >> 4;                            // k-tiles per tap
+  const int KT = a.Kw * ktpk;
+  const float4* wp0 = a.Wp + (long)phase * a.w_phase_stride + ((long)cot0 * KT) * 64 + lane;
+  const float4* wp1 = wp0 + (long)KT * 64;
+  const bool two = (cot0 + 1) * 16 < a.Co;               // Co may be a single 16-tile multiple of 32? (always 32-multiples here)
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < a.Kw; ++k) {
+    const float* xp[2];
+    bool ok[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int t = min(t0 + ni * 16 + m, a.T - 1);
+      int p = t * a.s_in + k * a.dil - a.pad;
+      bool v = true;
+      if (a.reflect) {
+        if (p < 0) p = -p;
+        if (p >= a.L_in) p = 2 * (a.L_in - 1) - p;
+        p = max(0, min(p, a.L_in - 1));                  // only reached for inputs shorter than the padding
+      } else {
+        v = (p >= 0 && p < a.L_in);
+        p = max(0, min(p, a.L_in - 1));
+      }
+      ok[ni] = v;
+      xp[ni] = a.x + (long)p * a.Ci + 4 * g;
+    }
+    const float4* w0 = wp0 + (long)k * ktpk * 64;
+    const float4* w1 = wp1 + (long)k * ktpk * 64;
+#pragma unroll 2
+    for (int c = 0; c < ktpk; ++c) {
+      const float4 wa = w0[(long)c * 64];
+      const float4 wb = two ? w1[(long)c * 64] : z4;
+      float4 xa = *reinterpret_cast<const float4*>(xp[0] + c * 16);
+      float4 xb = *reinterpret_cast<const float4*>(xp[1] + c * 16);
+      if (!ok[0]) xa = z4;
+      if (!ok[1]) xb = z4;
+      const uint4 uwa = __builtin_bit_cast(uint4, wa), uwb = __builtin_bit_cast(uint4, wb);
+      const uint4 uxa = __builtin_bit_cast(uint4, xa), uxb = __builtin_bit_cast(uint4, xb);
+      acc[0][0] = mfma_frag(uwa, uxa, acc[0][0], (float*)nullptr);
+      acc[0][1] = mfma_frag(uwa, uxb, acc[0][1], (float*)nullptr);
+      acc[1][0] = mfma_frag(uwb, uxa, acc[1][0], (float*)nullptr);
+      acc[1][1] = mfma_frag(uwb, uxb, acc[1][1], (float*)nullptr);
+    }
+  }
+  // epilogue: lane holds channels co..co+3 of position t
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int co = (cot0 + mi) * 16 + 4 * g;
+    if (co >= a.Co) continue;
+    const float4 b = *reinterpret_cast<const float4*>(a.bias + co);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      const int t = t0 + ni * 16 + m;
+      const int o = t * a.s_out + a.o_off + phase;
+      if (t >= a.T || o < 0 || o >= a.L_dst) continue;
+      float4 v = make_float4(acc[mi][ni][0] + b.x, acc[mi][ni][1] + b.y, acc[mi][ni][2] + b.z, acc[mi][ni][3] + b.w);
+      const long off = (long)o * a.Co + co;
+      if (a.res) {
+        const float4 r = *reinterpret_cast<const float4*>(a.res + off);
+        v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+      }
+      if (a.out_raw) *reinterpret_cast<float4*>(a.out_raw + off) = v;
+      if (a.out_elu) *reinterpret_cast<float4*>(a.out_elu + off) = make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));
+    }
+  }
+}
+
+// weights -> fragment image.  conv: W[Co][Ci][Kw]; transposed (phase r, taps r and r+s): W[Ci][Co][2s]
+__global__ void conv_pack_k(const float* __restrict__ W, float4* __restrict__ Wp, int Co, int Ci, int Kw,
+                            int transposed, int stride, int phase, long total) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int lane = (int)(idx & 63);
+  const long tile = idx >> 6;
+  const int ktpk = Ci >> 4;
+  const int KT = Kw * ktpk;
+  const int kt = (int)(tile % KT), cot = (int)(tile / KT);
+  const int k = kt / ktpk, cit = kt - k * ktpk;
+  const int co = cot * 16 + (lane & 15);
+  const int ci = cit * 16 + 4 * (lane >> 4);
+  float v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (co >= Co) v[j] = 0.f;
+    else if (!transposed) v[j] = W[((long)co * Ci + ci + j) * Kw + k];
+    else v[j] = W[((long)(ci + j) * Co + co) * (2 * stride) + phase + k * stride];
+  }
+  Wp[idx] = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+// first layer: 1 -> Co channels, reflect padding (Ci = 1 has no 16-wide K tile)
+__global__ void conv_first_k(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                             float* __restrict__ out_raw, float* __restrict__ out_elu, int L, int Co, int Kw, int pad) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int cq = Co >> 2;
+  if (idx >= (long)L * cq) return;
+  const int t = (int)(idx / cq), co = (int)(idx % cq) * 4;
+  float4 v = *reinterpret_cast<const float4*>(bias + co);
+  for (int k = 0; k < Kw; ++k) {
+    int p = t + k - pad;
+    if (p < 0) p = -p;
+    if (p >= L) p = 2 * (L - 1) - p;
+    p = max(0, min(p, L - 1));
+    const float xv = x[p];
+    v.x += W[(co + 0) * Kw + k] * xv; v.y += W[(co + 1) * Kw + k] * xv;
+    v.z += W[(co + 2) * Kw + k] * xv; v.w += W[(co + 3) * Kw + k] * xv;
+  }
+  const long off = (long)t * Co + co;
+  if (out_raw) *reinterpret_cast<float4*>(out_raw + off) = v;
+  if (out_elu) *reinterpret_cast<float4*>(out_elu + off) = make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));
+}
+
+// last layer: Ci -> 1 channel.  W is [1][Ci][Kw]; x is the ELU'd [L][Ci].
+__global__ void conv_last_k(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
+                            float* __restrict__ out, int L, int Ci, int Kw, int pad) {
+  extern __shared__ float s_w[];                         // [Kw][Ci]
+  for (int i = threadIdx.x; i < Kw * Ci; i += blockDim.x) { const int k = i / Ci, ci = i - k * Ci; s_w[i] = W[ci * Kw + k]; }
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= L) return;
+  float acc = bias[0];
+  for (int k = 0; k < Kw; ++k) {
+    int p = t + k - pad;
+    if (p < 0) p = -p;
+    if (p >= L) p = 2 * (L - 1) - p;
+    p = max(0, min(p, L - 1));
+    const float4* xr = reinterpret_cast<const float4*>(x + (long)p * Ci);
+    const float4* wr = reinterpret_cast<const float4*>(s_w + k * Ci);
+    for (int c = 0; c < (Ci >> 2); ++c) {
+      const float4 a = xr[c], w = wr[c];
+      acc += (a.x * w.x + a.y * w.y) + (a.z * w.z + a.w * w.w);
+    }
+  }
+  out[t] = acc;
+}
+
+// ---- LSTM recurrence, one launch per time step (nn.LSTM gate order i,f,g,o; rows re-ordered so the
+// four gates of hidden unit u are rows 4u..4u+3).  gates = G[t] (input projection + both biases,
+// computed for all t by one implicit GEMM) + W_hh h_{t-1}.
+struct LstmArgs {
+  const float* Whh;      // [4H][H], rows permuted (unit-major)
+  const float* G;        // [T][4H] permuted the same way
+  const float* h_prev;   // [H]
+  float* c;              // [H] in/out
+  float* h_out;          // [H]: row t of the layer's output sequence
+  const float* skip;     // optional [H]: x_t, added to h for the block output (EncodecLSTM: lstm(x) + x)
+  float* out_raw;        // optional [H]
+  float* out_elu;        // optional [H]
+  int H;
+};
+__global__ __launch_bounds__(256) void lstm_step_k(const LstmArgs a) {
+  // one wave per hidden unit: its four gate rows (4 x H floats, contiguous after the permutation) are
+  // streamed with 16-byte loads, h_{t-1} comes from LDS, each dot product ends in a DPP wave sum.
+  extern __shared__ float s_h[];                         // h_{t-1}
+  const int H = a.H;
+  for (int i = threadIdx.x; i < H; i += blockDim.x) s_h[i] = a.h_prev[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + wave;                   // hidden unit
+  if (u >= H) return;
+  const int nq = H >> 2;                                 // float4 per row
+  const float4* w = reinterpret_cast<const float4*>(a.Whh + (long)(4 * u) * H);
+  const float4* hv = reinterpret_cast<const float4*>(s_h);
+  float g4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = lane; i < nq; i += 64) {
+    const float4 hh = hv[i];
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) {
+      const float4 ww = w[(long)gate * nq + i];
+      g4[gate] += (ww.x * hh.x + ww.y * hh.y) + (ww.z * hh.z + ww.w * hh.w);
+    }
+  }
+#pragma unroll
+  for (int gate = 0; gate < 4; ++gate) g4[gate] = wave_sum(g4[gate]);
+  if (lane != 0) return;
+  const float4 gi = *reinterpret_cast<const float4*>(a.G + 4 * u);
+  const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
+  const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
+  const float gg = tanhf(g4[2] + gi.z);
+  const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
+  const float c = fg * a.c[u] + ig * gg;
+  const float h = og * tanhf(c);
+  a.c[u] = c;
+  a.h_out[u] = h;
+  if (a.skip) {
+    const float y = h + a.skip[u];
+    if (a.out_raw) a.out_raw[u] = y;
+    if (a.out_elu) a.out_elu[u] = elu1(y);
+  }
+}
+
+// ---- residual VQ (EncodecResidualVectorQuantizer.encode/.decode).  One block per frame.
+// dist = -(|r|^2 - 2 r.e + |e|^2), arg-max with the lowest index on ties (torch.max), residual update.
+__global__ __launch_bounds__(256) void rvq_encode_k(const float* __restrict__ z, const float* __restrict__ Et,
+                                                    const float* __restrict__ E, const float* __restrict__ e2,
+                                                    int64_t* __restrict__ codes, int T, int D, int C, int Q) {
+  extern __shared__ float s_r[];                         // [D] residual, then scratch
+  __shared__ float s_bv[4];
+  __shared__ int s_bi[4];
+  __shared__ int s_best;
+  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < D; i += blockDim.x) s_r[i] = z[(long)t * D + i];
+  __syncthreads();
+  for (int qz = 0; qz < Q; ++qz) {
+    float r2 = 0.f;
+    for (int i = 0; i < D; ++i) r2 += s_r[i] * s_r[i];
+    const float* et = Et + (long)qz * D * C;
+    float bv = -INFINITY; int bi = 0x7fffffff;
+    for (int c = tid; c < C; c += blockDim.x) {
+      float dot = 0.f;
+      for (int i = 0; i < D; ++i) dot += s_r[i] * et[(long)i * C + c];
+      const float dist = -(r2 - 2.f * dot + e2[qz * C + c]);
+      if (dist > bv) { bv = dist; bi = c; }              // c ascending: first maximum wins
+    }
+    const float wm = wave_max(bv);
+    const int wi = wave_min_i(bv == wm ? bi : 0x7fffffff);
+    if (lane == 0) { s_bv[wave] = wm; s_bi[wave] = wi; }
+    __syncthreads();
+    if (tid == 0) {
+      float m = s_bv[0]; int b = s_bi[0];
+      for (int w = 1; w < 4; ++w) if (s_bv[w] > m || (s_bv[w] == m && s_bi[w] < b)) { m = s_bv[w]; b = s_bi[w]; }
+      s_best = b;
+      codes[(long)qz * T + t] = b;
+    }
+    __syncthreads();
+    const float* eb = E + ((long)qz * C + s_best) * D;
+    for (int i = tid; i < D; i += blockDim.x) s_r[i] -= eb[i];
+    __syncthreads();
+  }
+}
+__global__ void rvq_decode_k(const int64_t* __restrict__ codes, const float* __restrict__ E, float* __restrict__ out,
+                             int T, int D, int C, int Q, int* err) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)T * D) return;
+  const int t = (int)(idx / D), i = (int)(idx % D);
+  float v = 0.f;
+  for (int q = 0; q < Q; ++q) {                          // quantized_out = 0 + q0 + q1 + ... in this order
+    long c = codes[(long)q * T + t];
+    if (c < 0 || c >= C) { *err = 1; c = 0; }
+    v = v + E[((long)q * C + c) * D + i];
+  }
+  out[idx] = v;
+}
+__global__ void transpose_k(const float* __restrict__ src, float* __restrict__ dst, int R, int Cc) {   // [R][Cc] -> [Cc][R]
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)R * Cc) return;
+  const int r = (int)(idx / Cc), c = (int)(idx % Cc);
+  dst[(long)c * R + r] = src[idx];
+}
+__global__ void rownorm2_k(const float* __restrict__ E, float* __restrict__ e2, int rows, int D) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float s = 0.f;
+  for (int i = 0; i < D; ++i) s += E[(long)r * D + i] * E[(long)r * D + i];
+  e2[r] = s;
+}
+// unit-major row permutation of LSTM matrices/biases: dst row 4u+g <- src row g*H+u
+__global__ void lstm_perm_k(const float* __restrict__ src, float* __restrict__ dst, int H, int cols) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)4 * H * cols) return;
+  const int row = (int)(idx / cols), col = (int)(idx % cols);
+  const int u = row >> 2, g = row & 3;
+  dst[idx] = src[((long)g * H + u) * cols + col];
+}
+__global__ void add_vec_k(float* __restrict__ a, const float* __restrict__ b, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) a[i] += b[i];
+}
+
+// ============================================================================ host side
+namespace {
+std::string g_codec_create_err;
+
+struct Conv {
+  int Ci = 0, Co = 0, Kw = 0, stride = 1, transposed = 0;
+  float* w_raw = nullptr;   // device fp32, reference layout
+  float* bias = nullptr;
+  float4* Wp = nullptr;     // packed (all phases)
+  long phase_stride = 0;
+};
+struct Lstm {
+  int H = 0, layers = 0;
+  std::vector<float*> Whh;   // permuted [4H][H]
+  std::vector<Conv> Wih;     // as 1x1 "convs" H -> 4H with the summed, permuted bias
+};
+}  // namespace
+
+struct vc_codec {
+  vc_codec_cfg cfg{};
+  int device = 0;
+  bool finalized = false;
+  std::string err;
+  std::map<std::string, std::pair<std::vector<int64_t>, float*>> raw;
+  std::vector<void*> allocs;
+  int hop = 1;
+  // encoder
+  Conv enc_first, enc_last;
+  std::vector<Conv> enc_res3, enc_res1, enc_down;
+  Lstm enc_lstm;
+  // decoder
+  Conv dec_first, dec_last;
+  std::vector<Conv> dec_up, dec_res3, dec_res1;
+  Lstm dec_lstm;
+  // quantizer
+  float *E = nullptr, *Et = nullptr, *e2 = nullptr;
+  // activations
+  float *A_raw = nullptr, *A_elu = nullptr, *B_elu = nullptr, *H_elu = nullptr, *latent = nullptr;
+  float *G = nullptr, *HS0 = nullptr, *HS1 = nullptr, *cstate = nullptr, *hzero = nullptr;
+  int* err_flag = nullptr;
+  int* h_flag = nullptr;
+  int T_max = 0;
+  int last_T = 0;
+  hipEvent_t ev[2]{};
+  float last_ms = 0;
+  hipStream_t own_stream = nullptr;
+};
+
+namespace {
+int cfail(vc_codec* c, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  if (c) c->err = buf; else g_codec_create_err = buf;
+  return code;
+}
+#define CCHK(c, call)                                                                    \
+  do {                                                                                   \
+    hipError_t _e = (call);                                                              \
+    if (_e != hipSuccess) return cfail(c, VC_EHIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_e), __FILE__, __LINE__); \
+  } while (0)
+
+template <typename T>
+int calloc_dev(vc_codec* c, T** p, size_t n) {
+  void* v = nullptr;
+  hipError_t e = hipMalloc(&v, std::max<size_t>(n * sizeof(T), 16));
+  if (e != hipSuccess) return cfail(c, VC_EHIP, "hipMalloc(%zu) failed: %s", n * sizeof(T), hipGetErrorString(e));
+  c->allocs.push_back(v);
+  *p = reinterpret_cast<T*>(v);
+  return VC_OK;
+}
+
+int get_raw(vc_codec* c, const std::string& key, std::vector<int64_t> shape, float** out) {
+  auto it = c->raw.find(key);
+  if (it == c->raw.end()) return cfail(c, VC_EMISSING, "codec weight '%s' was never loaded", key.c_str());
+  if (it->second.first != shape) {
+    std::string got, exp;
+    for (auto v : it->second.first) got += std::to_string(v) + ",";
+    for (auto v : shape) exp += std::to_string(v) + ",";
+    return cfail(c, VC_EINVAL, "codec weight '%s' has shape [%s], expected [%s]", key.c_str(), got.c_str(), exp.c_str());
+  }
+  *out = it->second.second;
+  return VC_OK;
+}
+
+int make_conv(vc_codec* c, const std::string& prefix, int Ci, int Co, int Kw, int stride, int transposed, Conv* cv, bool pack) {
+  cv->Ci = Ci; cv->Co = Co; cv->Kw = Kw; cv->stride = stride; cv->transposed = transposed;
+  int rc;
+  if (transposed) { if ((rc = get_raw(c, prefix + ".weight", {Ci, Co, Kw}, &cv->w_raw))) return rc; }
+  else { if ((rc = get_raw(c, prefix + ".weight", {Co, Ci, Kw}, &cv->w_raw))) return rc; }
+  if ((rc = get_raw(c, prefix + ".bias", {Co}, &cv->bias))) return rc;
+  if (!pack) return VC_OK;
+  if (Ci % 16 || Co % 16) return cfail(c, VC_EINVAL, "%s: channels must be multiples of 16 (%d -> %d)", prefix.c_str(), Ci, Co);
+  const int cot = (Co + 31) / 32 * 2;                    // tiles allocated in pairs (a wave owns two)
+  if (!transposed) {
+    const long KT = (long)Kw * (Ci / 16);
+    const long total = (long)cot * KT * 64;
+    if ((rc = calloc_dev(c, &cv->Wp, (size_t)total))) return rc;
+    cv->phase_stride = total;
+    hipLaunchKernelGGL(conv_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, cv->w_raw, cv->Wp, Co, Ci, Kw, 0, 1, 0, total);
+  } else {
+    if (Kw != 2 * stride) return cfail(c, VC_EINVAL, "%s: transposed conv needs kernel = 2*stride", prefix.c_str());
+    const long KT = 2L * (Ci / 16);
+    const long total = (long)cot * KT * 64;
+    if ((rc = calloc_dev(c, &cv->Wp, (size_t)total * stride))) return rc;
+    cv->phase_stride = total;
+    for (int r = 0; r < stride; ++r)
+      hipLaunchKernelGGL(conv_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, cv->w_raw, cv->Wp + (long)r * total, Co, Ci, 2, 1, stride, r, total);
+  }
+  CCHK(c, hipGetLastError());
+  return VC_OK;
+}
+
+int make_lstm(vc_codec* c, const std::string& prefix, int H, int layers, Lstm* L) {
+  L->H = H; L->layers = layers;
+  int rc;
+  for (int n = 0; n < layers; ++n) {
+    const std::string sfx = "_l" + std::to_string(n);
+    float *wih, *whh, *bih, *bhh;
+    if ((rc = get_raw(c, prefix + ".weight_ih" + sfx, {4 * H, H}, &wih))) return rc;
+    if ((rc = get_raw(c, prefix + ".weight_hh" + sfx, {4 * H, H}, &whh))) return rc;
+    if ((rc = get_raw(c, prefix + ".bias_ih" + sfx, {4 * H}, &bih))) return rc;
+    if ((rc = get_raw(c, prefix + ".bias_hh" + sfx, {4 * H}, &bhh))) return rc;
+    float *pwhh, *pwih, *pb, *pb2;
+    if ((rc = calloc_dev(c, &pwhh, (size_t)4 * H * H))) return rc;
+    if ((rc = calloc_dev(c, &pwih, (size_t)4 * H * H))) return rc;
+    if ((rc = calloc_dev(c, &pb, (size_t)4 * H))) return rc;
+    if ((rc = calloc_dev(c, &pb2, (size_t)4 * H))) return rc;
+    const long tot = (long)4 * H * H;
+    hipLaunchKernelGGL(lstm_perm_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, whh, pwhh, H, H);
+    hipLaunchKernelGGL(lstm_perm_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, 0, wih, pwih, H, H);
+    hipLaunchKernelGGL(lstm_perm_k, dim3((unsigned)((4 * H + 255) / 256)), dim3(256), 0, 0, bih, pb, H, 1);
+    hipLaunchKernelGGL(lstm_perm_k, dim3((unsigned)((4 * H + 255) / 256)), dim3(256), 0, 0, bhh, pb2, H, 1);
+    hipLaunchKernelGGL(add_vec_k, dim3((unsigned)((4 * H + 255) / 256)), dim3(256), 0, 0, pb, pb2, 4 * H);
+    L->Whh.push_back(pwhh);
+    Conv cv;
+    cv.Ci = H; cv.Co = 4 * H; cv.Kw = 1; cv.stride = 1; cv.transposed = 0; cv.w_raw = pwih; cv.bias = pb;
+    const long KT = H / 16;
+    const long total = (long)(4 * H / 16) * KT * 64;
+    if ((rc = calloc_dev(c, &cv.Wp, (size_t)total))) return rc;
+    cv.phase_stride = total;
+    hipLaunchKernelGGL(conv_pack_k, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, 0, pwih, cv.Wp, 4 * H, H, 1, 0, 1, 0, total);
+    L->Wih.push_back(cv);
+  }
+  CCHK(c, hipGetLastError());
+  return VC_OK;
+}
+
+// out positions of a strided / plain convolution, padding split as EncodecConv1d does
+// (non-causal: right = total//2, left = total - right; the "extra" right padding is reflect too)
+int run_conv(vc_codec* c, const Conv& cv, const float* x, int L_in, const float* res, float* out_raw, float* out_elu,
+             int* L_out, hipStream_t s) {
+  const int pt = cv.Kw - cv.stride;
+  const int pr = pt / 2, pl = pt - pr;
+  const int T = (L_in + cv.stride - 1) / cv.stride;
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.Wp = cv.Wp; a.bias = cv.bias; a.res = res; a.out_raw = out_raw; a.out_elu = out_elu;
+  a.L_in = L_in; a.T = T; a.Ci = cv.Ci; a.Co = cv.Co; a.Kw = cv.Kw;
+  a.s_in = cv.stride; a.dil = 1; a.pad = pl; a.reflect = 1;
+  a.s_out = 1; a.o_off = 0; a.L_dst = T; a.w_phase_stride = cv.phase_stride;
+  hipLaunchKernelGGL(conv_gemm_k, dim3((T + 127) / 128, (cv.Co + 31) / 32, 1), dim3(256), 0, s, a);
+  CCHK(c, hipGetLastError());
+  *L_out = T;
+  return VC_OK;
+}
+// EncodecConvTranspose1d: full length (L-1)*s + 2s, trimmed by (left = total - total//2, right = total//2)
+int run_convT(vc_codec* c, const Conv& cv, const float* x, int L_in, float* out_raw, float* out_elu, int* L_out, hipStream_t s) {
+  const int st = cv.stride;
+  const int pt = cv.Kw - st;
+  const int pr = pt / 2, pl = pt - pr;
+  const int L_dst = L_in * st;
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.Wp = cv.Wp; a.bias = cv.bias; a.out_raw = out_raw; a.out_elu = out_elu;
+  a.L_in = L_in; a.T = L_in + 1; a.Ci = cv.Ci; a.Co = cv.Co; a.Kw = 2;
+  a.s_in = 1; a.dil = -1; a.pad = 0; a.reflect = 0;
+  a.s_out = st; a.o_off = -pl; a.L_dst = L_dst; a.w_phase_stride = cv.phase_stride;
+  hipLaunchKernelGGL(conv_gemm_k, dim3((a.T + 127) / 128, (cv.Co + 31) / 32, st), dim3(256), 0, s, a);
+  CCHK(c, hipGetLastError());
+  *L_out = L_dst;
+  return VC_OK;
+}
+
+// EncodecLSTM: y = lstm(x) + x over [T][H]; x is raw, the block output is written raw and/or ELU'd
+int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, float* out_elu, hipStream_t s) {
+  const int H = L.H;
+  const float* in = x;
+  float* seq[2] = {c->HS0, c->HS1};
+  for (int n = 0; n < L.layers; ++n) {
+    int Lo;
+    int rc = run_conv(c, L.Wih[n], in, T, nullptr, c->G, nullptr, &Lo, s);      // G = in W_ih^T + b_ih + b_hh
+    if (rc) return rc;
+    CCHK(c, hipMemsetAsync(c->cstate, 0, (size_t)H * 4, s));
+    float* hs = seq[n & 1];
+    const bool last = (n == L.layers - 1);
+    for (int t = 0; t < T; ++t) {
+      LstmArgs a;
+      memset(&a, 0, sizeof a);
+      a.Whh = L.Whh[n]; a.G = c->G + (size_t)t * 4 * H; a.h_prev = t ? hs + (size_t)(t - 1) * H : c->hzero;
+      a.c = c->cstate; a.h_out = hs + (size_t)t * H; a.H = H;
+      if (last) {
+        a.skip = x + (size_t)t * H;
+        a.out_raw = out_raw ? out_raw + (size_t)t * H : nullptr;
+        a.out_elu = out_elu ? out_elu + (size_t)t * H : nullptr;
+      }
+      hipLaunchKernelGGL(lstm_step_k, dim3((H + 3) / 4), dim3(256), (size_t)H * 4, s, a);
+    }
+    CCHK(c, hipGetLastError());
+    in = hs;
+  }
+  return VC_OK;
+}
+}  // namespace
+
+extern "C" const char* vc_codec_last_error(const vc_codec* c) { return c ? c->err.c_str() : g_codec_create_err.c_str(); }
+
+extern "C" int vc_codec_create(const vc_codec_cfg* cfg, int hip_device, vc_codec** out) {
+  if (!cfg || !out) return cfail(nullptr, VC_EINVAL, "null argument");
+  *out = nullptr;
+  if (cfg->n_ratios < 1 || cfg->n_ratios > VC_CODEC_MAX_RATIOS) return cfail(nullptr, VC_EINVAL, "n_ratios out of range");
+  if (cfg->n_filters % 32 || cfg->hidden % 16) return cfail(nullptr, VC_EINVAL, "n_filters must be a multiple of 32, hidden of 16");
+  if (cfg->compress != 2) return cfail(nullptr, VC_EINVAL, "compress must be 2");
+  if (cfg->n_q < 1 || cfg->n_q > VC_MAX_CODEBOOKS) return cfail(nullptr, VC_EINVAL, "n_q out of range");
+  if (cfg->max_samples < 1) return cfail(nullptr, VC_EINVAL, "max_samples must be positive");
+  hipError_t e = hipSetDevice(hip_device);
+  if (e != hipSuccess) return cfail(nullptr, VC_EHIP, "hipSetDevice(%d): %s", hip_device, hipGetErrorString(e));
+  vc_codec* c = new vc_codec();
+  c->cfg = *cfg; c->device = hip_device;
+  c->hop = 1;
+  for (int i = 0; i < cfg->n_ratios; ++i) c->hop *= cfg->ratios[i];
+  *out = c;
+  return VC_OK;
+}
+
+extern "C" void vc_codec_destroy(vc_codec* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  hipDeviceSynchronize();
+  for (auto& kv : c->raw) if (kv.second.second) hipFree(kv.second.second);
+  for (void* p : c->allocs) hipFree(p);
+  if (c->h_flag) hipHostFree(c->h_flag);
+  for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  delete c;
+}
+
+extern "C" int vc_codec_load_tensor(vc_codec* c, const char* key, const void* data, int on_device,
+                                    const int64_t* shape, int ndim) {
+  if (!c || !key || !data || ndim < 1 || ndim > 3) return cfail(c, VC_EINVAL, "bad argument to vc_codec_load_tensor");
+  if (c->finalized) return cfail(c, VC_ESTATE, "codec already finalized");
+  CCHK(c, hipSetDevice(c->device));
+  std::vector<int64_t> sh(shape, shape + ndim);
+  long n = 1;
+  for (auto v : sh) n *= v;
+  if (n <= 0) return cfail(c, VC_EINVAL, "empty tensor '%s'", key);
+  auto it = c->raw.find(key);
+  if (it != c->raw.end()) { hipFree(it->second.second); c->raw.erase(it); }
+  float* d = nullptr;
+  CCHK(c, hipMalloc((void**)&d, (size_t)n * 4));
+  CCHK(c, hipMemcpy(d, data, (size_t)n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
+  c->raw[key] = {sh, d};
+  return VC_OK;
+}
+
+extern "C" int vc_codec_finalize(vc_codec* c) {
+  if (!c) return VC_EINVAL;
+  if (c->finalized) return cfail(c, VC_ESTATE, "codec already finalized");
+  CCHK(c, hipSetDevice(c->device));
+  const vc_codec_cfg& g = c->cfg;
+  const int F = g.n_filters, R = g.n_ratios;
+  int rc;
+  // ---- encoder: module indices as transformers.EncodecEncoder enumerates them
+  int idx = 0;
+  if ((rc = make_conv(c, "encoder.layers.0.conv", 1, F, g.kernel_size, 1, 0, &c->enc_first, false))) return rc;
+  idx = 1;
+  int ch = F;
+  c->enc_res3.resize(R); c->enc_res1.resize(R); c->enc_down.resize(R);
+  for (int i = 0; i < R; ++i) {
+    const int ratio = g.ratios[R - 1 - i];               // reversed(upsampling_ratios)
+    const std::string rb = "encoder.layers." + std::to_string(idx) + ".block.";
+    if ((rc = make_conv(c, rb + "1.conv", ch, ch / 2, g.residual_kernel_size, 1, 0, &c->enc_res3[i], true))) return rc;
+    if ((rc = make_conv(c, rb + "3.conv", ch / 2, ch, 1, 1, 0, &c->enc_res1[i], true))) return rc;
+    idx += 2;                                            // resblock, ELU
+    if ((rc = make_conv(c, "encoder.layers." + std::to_string(idx) + ".conv", ch, ch * 2, ratio * 2, ratio, 0, &c->enc_down[i], true))) return rc;
+    idx += 1;
+    ch *= 2;
+  }
+  if ((rc = make_lstm(c, "encoder.layers." + std::to_string(idx) + ".lstm", ch, g.lstm_layers, &c->enc_lstm))) return rc;
+  idx += 2;                                              // LSTM, ELU
+  if ((rc = make_conv(c, "encoder.layers." + std::to_string(idx) + ".conv", ch, g.hidden, g.last_kernel_size, 1, 0, &c->enc_last, true))) return rc;
+  const int top = ch;
+  // ---- decoder
+  if ((rc = make_conv(c, "decoder.layers.0.conv", g.hidden, top, g.kernel_size, 1, 0, &c->dec_first, true))) return rc;
+  if ((rc = make_lstm(c, "decoder.layers.1.lstm", top, g.lstm_layers, &c->dec_lstm))) return rc;
+  idx = 2;
+  ch = top;
+  c->dec_up.resize(R); c->dec_res3.resize(R); c->dec_res1.resize(R);
+  for (int i = 0; i < R; ++i) {
+    const int ratio = g.ratios[i];
+    idx += 1;                                            // ELU
+    if ((rc = make_conv(c, "decoder.layers." + std::to_string(idx) + ".conv", ch, ch / 2, ratio * 2, ratio, 1, &c->dec_up[i], true))) return rc;
+    idx += 1;
+    const std::string rb = "decoder.layers." + std::to_string(idx) + ".block.";
+    if ((rc = make_conv(c, rb + "1.conv", ch / 2, ch / 4, g.residual_kernel_size, 1, 0, &c->dec_res3[i], true))) return rc;
+    if ((rc = make_conv(c, rb + "3.conv", ch / 4, ch / 2, 1, 1, 0, &c->dec_res1[i], true))) return rc;
+    idx += 1;
+    ch /= 2;
+  }
+  idx += 1;                                              // ELU
+  if ((rc = make_conv(c, "decoder.layers." + std::to_string(idx) + ".conv", F, 1, g.last_kernel_size, 1, 0, &c->dec_last, false))) return rc;
+  // ---- codebooks
+  const int D = g.hidden, C = g.codebook_size, Q = g.n_q;
+  if ((rc = calloc_dev(c, &c->E, (size_t)Q * C * D))) return rc;
+  if ((rc = calloc_dev(c, &c->Et, (size_t)Q * C * D))) return rc;
+  if ((rc = calloc_dev(c, &c->e2, (size_t)Q * C))) return rc;
+  for (int q = 0; q < Q; ++q) {
+    float* src;
+    if ((rc = get_raw(c, "quantizer.layers." + std::to_string(q) + ".codebook.embed", {C, D}, &src))) return rc;
+    CCHK(c, hipMemcpy(c->E + (size_t)q * C * D, src, (size_t)C * D * 4, hipMemcpyDeviceToDevice));
+    hipLaunchKernelGGL(transpose_k, dim3((unsigned)(((long)C * D + 255) / 256)), dim3(256), 0, 0, src, c->Et + (size_t)q * C * D, C, D);
+  }
+  hipLaunchKernelGGL(rownorm2_k, dim3((Q * C + 255) / 256), dim3(256), 0, 0, c->E, c->e2, Q * C, D);
+  CCHK(c, hipGetLastError());
+  // ---- activation arenas
+  const size_t N = (size_t)g.max_samples;
+  c->T_max = (int)((N + c->hop - 1) / c->hop) + 1;
+  const size_t big = std::max(N * F, (size_t)c->T_max * top) + 1024;
+  if ((rc = calloc_dev(c, &c->A_raw, big))) return rc;
+  if ((rc = calloc_dev(c, &c->A_elu, big))) return rc;
+  if ((rc = calloc_dev(c, &c->B_elu, big))) return rc;
+  if ((rc = calloc_dev(c, &c->H_elu, big / 2 + 1024))) return rc;
+  if ((rc = calloc_dev(c, &c->latent, (size_t)c->T_max * D))) return rc;
+  if ((rc = calloc_dev(c, &c->G, (size_t)c->T_max * 4 * top))) return rc;
+  if ((rc = calloc_dev(c, &c->HS0, (size_t)c->T_max * top))) return rc;
+  if ((rc = calloc_dev(c, &c->HS1, (size_t)c->T_max * top))) return rc;
+  if ((rc = calloc_dev(c, &c->cstate, (size_t)top))) return rc;
+  if ((rc = calloc_dev(c, &c->hzero, (size_t)top))) return rc;
+  if ((rc = calloc_dev(c, &c->err_flag, (size_t)4))) return rc;
+  CCHK(c, hipMemset(c->hzero, 0, (size_t)top * 4));
+  CCHK(c, hipMemset(c->err_flag, 0, 16));
+  CCHK(c, hipHostMalloc((void**)&c->h_flag, 64));
+  for (auto& ev : c->ev) CCHK(c, hipEventCreate(&ev));
+  CCHK(c, hipStreamCreate(&c->own_stream));
+  CCHK(c, hipDeviceSynchronize());
+  // the packed images are all that is needed of the conv weights; first/last convs and the LSTM keep their raw rows
+  c->finalized = true;
+  return VC_OK;
+}
+
+extern "C" int vc_codec_encode(vc_codec* c, const float* wav_dev, int n_samples, int64_t* codes_dev, int codes_cap,
+                               int* n_frames, void* stream) {
+  if (!c || !c->finalized) return cfail(c, VC_ESTATE, "codec not finalized");
+  if (!wav_dev || !codes_dev || !n_frames) return cfail(c, VC_EINVAL, "null argument to vc_codec_encode");
+  if (n_samples < 16 || n_samples > c->cfg.max_samples) return cfail(c, VC_ECAP, "n_samples %d outside [16, %d]", n_samples, c->cfg.max_samples);
+  CCHK(c, hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+  const vc_codec_cfg& g = c->cfg;
+  const int F = g.n_filters;
+  CCHK(c, hipEventRecord(c->ev[0], s));
+  int L = n_samples;
+  {
+    const long tot = (long)L * (F / 4);
+    const int pad = (g.kernel_size - 1) - (g.kernel_size - 1) / 2;
+    hipLaunchKernelGGL(conv_first_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, wav_dev, c->enc_first.w_raw,
+                       c->enc_first.bias, c->A_raw, c->A_elu, L, F, g.kernel_size, pad);
+  }
+  int rc, Lo;
+  const int R = g.n_ratios;
+  for (int i = 0; i < R; ++i) {
+    if ((rc = run_conv(c, c->enc_res3[i], c->A_elu, L, nullptr, nullptr, c->H_elu, &Lo, s))) return rc;
+    if ((rc = run_conv(c, c->enc_res1[i], c->H_elu, L, c->A_raw, nullptr, c->B_elu, &Lo, s))) return rc;
+    const bool last = (i == R - 1);
+    if ((rc = run_conv(c, c->enc_down[i], c->B_elu, L, nullptr, c->A_raw, last ? nullptr : c->A_elu, &Lo, s))) return rc;
+    L = Lo;
+  }
+  const int T = L;
+  if (T > codes_cap) return cfail(c, VC_ECAP, "codes capacity %d < %d frames", codes_cap, T);
+  if ((rc = run_lstm(c, c->enc_lstm, c->A_raw, T, nullptr, c->B_elu, s))) return rc;
+  if ((rc = run_conv(c, c->enc_last, c->B_elu, T, nullptr, c->latent, nullptr, &Lo, s))) return rc;
+  hipLaunchKernelGGL(rvq_encode_k, dim3(T), dim3(256), (size_t)g.hidden * 4, s, c->latent, c->Et, c->E, c->e2, codes_dev, T,
+                     g.hidden, g.codebook_size, g.n_q);
+  CCHK(c, hipGetLastError());
+  CCHK(c, hipEventRecord(c->ev[1], s));
+  CCHK(c, hipStreamSynchronize(s));
+  CCHK(c, hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
+  c->last_T = T;
+  *n_frames = T;
+  return VC_OK;
+}
+
+extern "C" int vc_codec_decode(vc_codec* c, const int64_t* codes_dev, int T, float* wav_dev, int wav_cap, void* stream) {
+  if (!c || !c->finalized) return cfail(c, VC_ESTATE, "codec not finalized");
+  if (!codes_dev || !wav_dev) return cfail(c, VC_EINVAL, "null argument to vc_codec_decode");
+  if (T < 4 || T > c->T_max - 1) return cfail(c, VC_ECAP, "T %d outside [4, %d]", T, c->T_max - 1);
+  if ((long)T * c->hop > wav_cap) return cfail(c, VC_ECAP, "wav capacity %d < %ld", wav_cap, (long)T * c->hop);
+  CCHK(c, hipSetDevice(c->device));
+  hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
+  const vc_codec_cfg& g = c->cfg;
+  CCHK(c, hipEventRecord(c->ev[0], s));
+  {
+    const long tot = (long)T * g.hidden;
+    hipLaunchKernelGGL(rvq_decode_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, codes_dev, c->E, c->latent, T, g.hidden,
+                       g.codebook_size, g.n_q, c->err_flag);
+  }
+  int rc, Lo, L = T;
+  if ((rc = run_conv(c, c->dec_first, c->latent, L, nullptr, c->A_raw, nullptr, &Lo, s))) return rc;
+  if ((rc = run_lstm(c, c->dec_lstm, c->A_raw, L, nullptr, c->B_elu, s))) return rc;
+  for (int i = 0; i < g.n_ratios; ++i) {
+    if ((rc = run_convT(c, c->dec_up[i], c->B_elu, L, c->A_raw, c->A_elu, &Lo, s))) return rc;
+    L = Lo;
+    if ((rc = run_conv(c, c->dec_res3[i], c->A_elu, L, nullptr, nullptr, c->H_elu, &Lo, s))) return rc;
+    if ((rc = run_conv(c, c->dec_res1[i], c->H_elu, L, c->A_raw, nullptr, c->B_elu, &Lo, s))) return rc;
+  }
+  {
+    const int Ci = g.n_filters, Kw = g.last_kernel_size;
+    const int pad = (Kw - 1) - (Kw - 1) / 2;
+    hipLaunchKernelGGL(conv_last_k, dim3((L + 255) / 256), dim3(256), (size_t)Kw * Ci * 4, s, c->B_elu, c->dec_last.w_raw,
+                       c->dec_last.bias, wav_dev, L, Ci, Kw, pad);
+  }
+  CCHK(c, hipGetLastError());
+  CCHK(c, hipEventRecord(c->ev[1], s));
+  CCHK(c, hipMemcpyAsync(c->h_flag, c->err_flag, 4, hipMemcpyDeviceToHost, s));
+  CCHK(c, hipStreamSynchronize(s));
+  CCHK(c, hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
+  if (*c->h_flag) {
+    hipMemset(c->err_flag, 0, 4);
+    return cfail(c, VC_EINVAL, "code index outside [0, %d)", g.codebook_size);
+  }
+  return VC_OK;
+}
+
+extern "C" int vc_codec_debug_latent(vc_codec* c, float* host_dst, int64_t n_floats) {
+  if (!c || !c->finalized || !host_dst) return VC_EINVAL;
+  if (n_floats > (int64_t)c->T_max * c->cfg.hidden) return cfail(c, VC_ECAP, "latent holds %lld floats", (long long)c->T_max * c->cfg.hidden);
+  CCHK(c, hipDeviceSynchronize());
+  CCHK(c, hipMemcpy(host_dst, c->latent, (size_t)n_floats * 4, hipMemcpyDeviceToHost));
+  return VC_OK;
+}
+
+extern "C" int vc_codec_last_ms(const vc_codec* c, float* ms) {
+  if (!c || !ms) return VC_EINVAL;
+  *ms = c->last_ms;
+  return VC_OK;
+}

@@ -274,6 +274,7 @@ struct SampleArgs {
   const float* pe;
   float alpha_audio;
   int max_positions;
+  long long* dbg_ts;        // optional [16] shader-clock stamps of sequence 0 (diagnosis only)
 };
 
 struct AssembleArgs {       // writes res [K][res_cap] from y and the generated spans

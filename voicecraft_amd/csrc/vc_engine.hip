@@ -68,6 +68,7 @@ struct vc_engine {
   float *dec_h = nullptr;               // [VC_ROWS][d]
   int *dec_row_seq = nullptr, *dec_row_pos = nullptr, *logit_row = nullptr;
   SeqState *st = nullptr;
+  long long* dbg_ts = nullptr;
   int *n_active = nullptr, *samp = nullptr, *cond = nullptr, *amax = nullptr, *gen = nullptr, *err_flag = nullptr;
   int gen_cap = 0;
   // pinned host staging
@@ -350,6 +351,7 @@ SampleArgs make_sample_args(vc_engine* e, const vc_sample_cfg* sc, int B, int rp
   a.logit_row = e->logit_row;
   a.audio_emb = e->audio_emb; a.mask_emb = e->mask_emb; a.pe = e->pe; a.alpha_audio = e->alpha_audio;
   a.max_positions = e->S_max;
+  a.dbg_ts = getenv("VC_SAMPLER_TS") ? e->dbg_ts : nullptr;
   return a;
 }
 
@@ -656,6 +658,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->amax, (size_t)VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->dbg_ts, (size_t)16))) return rc;
+  HIPCHK(e, hipMemset(e->dbg_ts, 0, 16 * 8));
   e->gen_cap = e->S_max;
   if ((rc = dalloc(e, &e->gen, (size_t)e->B_max * e->gen_cap * K))) return rc;
   HIPCHK(e, hipMemset(e->err_flag, 0, 16));
@@ -958,6 +962,7 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "kcache0") { src = e->layers[0].kc; avail = (int64_t)e->B_max * e->H * e->S_max * e->hd * e->esz; }
   else if (n == "vcache0") { src = e->layers[0].vc; avail = (int64_t)e->B_max * e->H * e->S_max * e->hd * e->esz; }
   else if (n == "pe") { src = e->pe; avail = (int64_t)e->S_max * e->d * 4; }
+  else if (n == "sampler_ts") { src = e->dbg_ts; avail = 16 * 8; }
   else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
   if (nbytes > avail) return fail(e, VC_ECAP, "debug buffer '%s' holds %lld bytes", n.c_str(), (long long)avail);
   HIPCHK(e, hipDeviceSynchronize());

@@ -158,116 +158,126 @@ __device__ __forceinline__ bool is_silence(const SampleArgs& a, int tok) {
 
 // Phase 1 (one block per sequence, one wave per codebook): logit edits, top-k / top-p filter,
 // categorical draw.  Restates sample_helper + topk_sampling + top_k_top_p_filtering
-// (models/voicecraft.py:1018-1067, :71-86, :26-68).  Writes samp[b][k], cond[b], amax[b].
+// (models/voicecraft.py:1018-1067, :71-86, :26-68).
+// The row lives in LDS and every pass is a short rolled loop: this kernel is one latency-bound
+// block, and a fully unrolled register version (40 KB of straight-line code) spent its time in
+// instruction-cache misses (profiles/r01_rocprof_kernel_stats_v1.txt: 44 us), not in arithmetic.
 // `sp` is the sequence state (in LDS); results go to xs (LDS in the fused kernel, HBM scratch when the
 // keep decision needs the kernel boundary): xs[0..K) tokens, xs[K] arg-max of codebook 0, xs[K+1] cond.
-__device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int* xs) {
+#define VC_TS(i) do { if (a.dbg_ts && b == 0 && threadIdx.x == 0) a.dbg_ts[i] = clock64(); } while (0)
+__device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int* xs, float* s_rows) {
   const SeqState st = *sp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (st.done) return;
   const int step = st.total_steps;
+  const int V = a.V;
+  const int nj = (V + 63) >> 6;
+  const int VP = nj << 6;
   for (int k = wave; k < a.K; k += 4) {
-    const float* row = a.logits + ((long)b * a.K + k) * a.V;
-    float v[VC_VPL];
+    const float* row = a.logits + ((long)b * a.K + k) * V;
+    float* sv = s_rows + k * VP;
+    {   // all loads of the row in flight together (clamped, unconditional), then parked in LDS
+      float t[VC_VPL];
 #pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) {               // unconditional (clamped) loads: all 34 in flight at once
-      const int i = lane + 64 * j;
-      const float t = row[min(i, a.V - 1)];
-      v[j] = (i < a.V) ? t : -INFINITY;
+      for (int j = 0; j < VC_VPL; ++j) t[j] = row[min(lane + 64 * j, V - 1)];
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j)
+        if (j < nj) sv[lane + 64 * j] = (lane + 64 * j < V) ? t[j] : -INFINITY;
     }
+    VC_TS(1);
     if (a.logits_out && b == 0 && step < a.logit_steps) {
-      float* lo = a.logits_out + ((long)step * a.K + k) * a.V;
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) {
-        const int i = lane + 64 * j;
-        if (i < a.V) lo[i] = v[j];
+      float* lo = a.logits_out + ((long)step * a.K + k) * V;
+#pragma unroll 1
+      for (int j = 0; j < nj; ++j) { const int i = lane + 64 * j; if (i < V) lo[i] = sv[i]; }
+    }
+    // ---- logit edits, in the reference's order; each touches at most one element
+    if (lane == 0) {
+      const int term = st.term_token;
+      if (st.kill_token >= 0) sv[st.kill_token] = -10000.f;
+      const bool kill_tl = (st.n_eog == 0) ? (k >= 1) : (k > st.n_eog);      // [term],[empty] on later codebooks
+      if (kill_tl) { sv[term] = -10000.f; sv[a.empty_token] = -10000.f; }
+      if (st.n_eog == 0 && k == 0) {
+        if (st.min_gen >= 0 && st.cur_num_gen <= st.min_gen) sv[term] = -10000.f;
+        if (a.stop_repetition > 0 && st.prev_token >= 0 && is_silence(a, st.prev_token) &&
+            st.consec_silence > a.stop_repetition) {
+          const float f = (float)(st.consec_silence - (a.stop_repetition - 1));
+          const float x = sv[st.prev_token];
+          sv[st.prev_token] = (x < 0.f) ? x * f : x / f;
+        }
       }
     }
-    // ---- logit edits, in the reference's order
-    const int term = st.term_token;
-    const bool kill_tl = (st.n_eog == 0) ? (k >= 1) : (k > st.n_eog);            // [term],[empty] on later codebooks
-    const bool kill_t0 = (st.n_eog == 0 && k == 0 && st.min_gen >= 0 && st.cur_num_gen <= st.min_gen);
-    const bool pen = (st.n_eog == 0 && k == 0 && a.stop_repetition > 0 && st.prev_token >= 0 &&
-                      is_silence(a, st.prev_token) && st.consec_silence > a.stop_repetition);
-    const float pen_f = (float)(st.consec_silence - (a.stop_repetition - 1));
-#pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) {
-      const int i = lane + 64 * j;
-      if (i >= a.V) continue;
-      if (i == st.kill_token) v[j] = -10000.f;
-      if (kill_tl && (i == term || i == a.empty_token)) v[j] = -10000.f;
-      if (kill_t0 && i == term) v[j] = -10000.f;
-      if (pen && i == st.prev_token) v[j] = (v[j] < 0.f) ? v[j] * pen_f : v[j] / pen_f;
-    }
-    // ---- argmax of the edited logits (first index on ties, as torch.argmax)
+    // (single wave: LDS accesses of one wave are ordered, no barrier needed)
+    // ---- arg-max of the edited logits (first index on ties, as torch.argmax)
     float bv = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) bv = fmaxf(bv, v[j]);     // padding lanes hold -inf
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) bv = fmaxf(bv, sv[lane + 64 * j]);
     bv = wave_max(bv);
     int bi = 0x7fffffff;
-#pragma unroll
-    for (int j = VC_VPL - 1; j >= 0; --j)
-      if (v[j] == bv && lane + 64 * j < a.V) bi = lane + 64 * j;
+#pragma unroll 1
+    for (int j = nj - 1; j >= 0; --j) { const int i = lane + 64 * j; if (sv[i] == bv && i < V) bi = i; }
     bi = wave_min_i(bi);
+    VC_TS(2);
     // ---- temperature
+    float mx = bv;
     if (a.temperature != 1.0f) {
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) v[j] = v[j] / a.temperature;
+#pragma unroll 1
+      for (int j = 0; j < nj; ++j) sv[lane + 64 * j] = sv[lane + 64 * j] / a.temperature;
+      mx = bv / a.temperature;                      // filters never remove the maximum
     }
     // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive).
-    // Bitwise binary search for the k-th largest order-preserving key; per-lane counts are
-    // combined on the DPP path.
+    // Bitwise binary search for the k-th largest order-preserving key.
     if (a.top_k > 0) {
-      const int kk = min(max(a.top_k, 1), a.V);
-      uint32_t key[VC_VPL];
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) key[j] = (lane + 64 * j < a.V) ? fkey(v[j]) : 0u;
+      const int kk = min(max(a.top_k, 1), V);
       uint32_t t = 0;
+#pragma unroll 1
       for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = t | (1u << bit);
         int c = 0;
-#pragma unroll
-        for (int j = 0; j < VC_VPL; ++j) c += (key[j] >= cand) ? 1 : 0;
+#pragma unroll 3
+        for (int j = 0; j < nj; ++j) c += (fkey(sv[lane + 64 * j]) >= cand) ? 1 : 0;   // padding = -inf: never counted above 0x007fffff
         if (wave_sum_i(c) >= kk) t = cand;
       }
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j)
-        if (key[j] < t) v[j] = -INFINITY;
+#pragma unroll 1
+      for (int j = 0; j < nj; ++j) { const int i = lane + 64 * j; if (fkey(sv[i]) < t) sv[i] = -INFINITY; }
     }
-    // ---- softmax numerators
-    const float mx = (a.temperature != 1.0f) ? bv / a.temperature : bv;   // filters never remove the maximum
-    float p[VC_VPL];
+    VC_TS(3);
+    // ---- softmax numerators, in place (sv now holds p >= 0; 0 = filtered out)
     float ps = 0.f;
-#pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) { p[j] = (v[j] == -INFINITY) ? 0.f : expf(v[j] - mx); ps += p[j]; }
+#pragma unroll 1
+    for (int j = 0; j < nj; ++j) {
+      const int i = lane + 64 * j;
+      const float x = sv[i];
+      const float e = (x == -INFINITY) ? 0.f : expf(x - mx);
+      sv[i] = e;
+      ps += e;
+    }
     float tot = wave_sum(ps);
-    // ---- top-p: drop a token when the mass of the strictly larger ones already exceeds top_p
+    // ---- top-p: drop a token when the mass of the strictly larger ones already exceeds top_p.
+    // p is monotone in the logit, and the bits of a non-negative float order like the float.
     if (a.top_p < 1.0f) {
       const float lim = a.top_p * tot;
-      // find the largest key t with mass(key > t) > lim; keep keys >= t+1 (all keys if none fails)
-      float m0 = 0.f;
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) m0 += (fkey(v[j]) > 0u) ? p[j] : 0.f;
-      m0 = wave_sum(m0);
-      if (m0 > lim) {
-        uint32_t t = 0;
-        for (int bit = 31; bit >= 0; --bit) {
-          const uint32_t cand = t | (1u << bit);
-          float mm = 0.f;
-#pragma unroll
-          for (int j = 0; j < VC_VPL; ++j) mm += (fkey(v[j]) > cand) ? p[j] : 0.f;
-          mm = wave_sum(mm);
-          if (mm > lim) t = cand;
-        }
-        ps = 0.f;
-#pragma unroll
-        for (int j = 0; j < VC_VPL; ++j) {
-          if (fkey(v[j]) <= t) p[j] = 0.f;
-          ps += p[j];
-        }
-        tot = wave_sum(ps);
+      // t = the largest key whose strictly-larger mass still exceeds lim (key 0 always qualifies:
+      // the whole row weighs tot > lim); exactly the keys <= t are dropped.
+      uint32_t t = 0;
+#pragma unroll 1
+      for (int bit = 30; bit >= 0; --bit) {
+        const uint32_t cand = t | (1u << bit);
+        float mm = 0.f;
+#pragma unroll 3
+        for (int j = 0; j < nj; ++j) { const float e = sv[lane + 64 * j]; mm += (__float_as_uint(e) > cand) ? e : 0.f; }
+        if (wave_sum(mm) > lim) t = cand;
       }
+      ps = 0.f;
+#pragma unroll 1
+      for (int j = 0; j < nj; ++j) {
+        const int i = lane + 64 * j;
+        float e = sv[i];
+        if (__float_as_uint(e) <= t) { e = 0.f; sv[i] = 0.f; }
+        ps += e;
+      }
+      tot = wave_sum(ps);
     }
+    VC_TS(4);
     // ---- categorical draw by inverse CDF, order = (lane, j)
     const float u = philox_uniform(a.seed, (uint32_t)b, (uint32_t)step, (uint32_t)k);
     const float target = u * tot;
@@ -278,7 +288,7 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
     }
     const float excl = incl - ps;
     const bool mine = (ps > 0.f) && (target >= excl) && (target < incl);
-    uint64_t ball = __ballot(mine);
+    const uint64_t ball = __ballot(mine);
     int src_lane;
     if (ball) src_lane = __ffsll((long long)ball) - 1;
     else {     // rounding put target at/after the end: take the last lane with mass
@@ -289,11 +299,12 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
     if (lane == src_lane) {
       float acc = excl;
       int pick = -1, last = -1;
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) {
-        if (p[j] > 0.f) {
+#pragma unroll 1
+      for (int j = 0; j < nj; ++j) {
+        const float e = sv[lane + 64 * j];
+        if (e > 0.f) {
           last = lane + 64 * j;
-          acc += p[j];
+          acc += e;
           if (pick < 0 && target < acc) pick = lane + 64 * j;
         }
       }
@@ -305,6 +316,7 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
       if (k == 0) xs[a.K] = bi;
     }
   }
+  VC_TS(5);
   __syncthreads();
   if (tid == 0) {
     int c = 0;
@@ -402,6 +414,7 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState
   }
   __syncthreads();
   const int mode = s_mode;
+  VC_TS(7);
   if (mode == 0) return;
   // next-step input row(s): sum of the K codebook embeddings of the emitted tokens + alpha*pe
   // (voicecraft.py:1102-1116).  All K gathers of a thread are requested together (float4 columns).
@@ -411,17 +424,23 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState
   const float* pe0 = a.pe + (long)ylen * d;
   const int nq = d >> 2;
   for (int i = tid; i < nq; i += blockDim.x) {
-    float4 e[VC_MAX_CODEBOOKS];
-#pragma unroll
-    for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) {
-      const int kk = (k < K) ? k : 0;
-      e[k] = *reinterpret_cast<const float4*>(a.audio_emb + ((long)kk * a.V + s_tok[kk]) * d + i * 4);
-    }
     const float4 p = *reinterpret_cast<const float4*>(pe0 + i * 4);
-    float4 v = e[0];
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 1
+    for (int k0 = 0; k0 < K; k0 += 4) {            // four gathers in flight per pass; summed in order k = 0..K-1
+      float4 e[4];
 #pragma unroll
-    for (int k = 1; k < VC_MAX_CODEBOOKS; ++k)
-      if (k < K) { v.x += e[k].x; v.y += e[k].y; v.z += e[k].z; v.w += e[k].w; }
+      for (int q = 0; q < 4; ++q) {
+        const int kk = (k0 + q < K) ? k0 + q : 0;
+        e[q] = *reinterpret_cast<const float4*>(a.audio_emb + ((long)kk * a.V + s_tok[kk]) * d + i * 4);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+        if (k0 + q < K) {
+          if (k0 + q == 0) v = e[q];
+          else { v.x += e[q].x; v.y += e[q].y; v.z += e[q].z; v.w += e[q].w; }
+        }
+    }
     v.x += a.alpha_audio * p.x; v.y += a.alpha_audio * p.y; v.z += a.alpha_audio * p.z; v.w += a.alpha_audio * p.w;
     *reinterpret_cast<float4*>(h0 + i * 4) = v;
   }
@@ -430,16 +449,12 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState
       const float4 mk = *reinterpret_cast<const float4*>(a.mask_emb + (long)s_mask * d + i * 4);
       const float4 p1 = *reinterpret_cast<const float4*>(pe0 + d + i * 4);
       const float4 p2 = *reinterpret_cast<const float4*>(pe0 + 2 * d + i * 4);
-      float4 e[VC_MAX_CODEBOOKS];
-#pragma unroll
-      for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) {
-        const int kk = (k < K) ? k : 0;
-        e[k] = *reinterpret_cast<const float4*>(a.audio_emb + ((long)kk * a.V + a.empty_token) * d + i * 4);
+      float4 v = *reinterpret_cast<const float4*>(a.audio_emb + ((long)a.empty_token) * d + i * 4);
+#pragma unroll 1
+      for (int k = 1; k < K; ++k) {
+        const float4 e = *reinterpret_cast<const float4*>(a.audio_emb + ((long)k * a.V + a.empty_token) * d + i * 4);
+        v.x += e.x; v.y += e.y; v.z += e.z; v.w += e.w;
       }
-      float4 v = e[0];
-#pragma unroll
-      for (int k = 1; k < VC_MAX_CODEBOOKS; ++k)
-        if (k < K) { v.x += e[k].x; v.y += e[k].y; v.z += e[k].z; v.w += e[k].w; }
       float4 o1, o2;
       o1.x = mk.x + a.alpha_audio * p1.x; o1.y = mk.y + a.alpha_audio * p1.y; o1.z = mk.z + a.alpha_audio * p1.z; o1.w = mk.w + a.alpha_audio * p1.w;
       o2.x = v.x + a.alpha_audio * p2.x; o2.y = v.y + a.alpha_audio * p2.y; o2.z = v.z + a.alpha_audio * p2.z; o2.w = v.w + a.alpha_audio * p2.w;
@@ -459,21 +474,27 @@ __device__ __forceinline__ void store_state(const SampleArgs& a, int b, const Se
   __syncthreads();
   if (threadIdx.x < W) reinterpret_cast<int*>(a.st + b)[threadIdx.x] = reinterpret_cast<const int*>(sp)[threadIdx.x];
 }
+extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // K rows of 64*ceil(V/64) logits
 __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   __shared__ SeqState s_st;
   __shared__ int s_xs[VC_MAX_CODEBOOKS + 2];
   if (*a.n_active == 0) return;
+  const int b = blockIdx.x;
+  VC_TS(0);
   load_state(a, blockIdx.x, &s_st);
-  sample_phase(a, blockIdx.x, &s_st, s_xs);
+  sample_phase(a, blockIdx.x, &s_st, s_xs, s_dyn);
   __syncthreads();
+  VC_TS(6);
   advance_phase(a, blockIdx.x, false, &s_st, s_xs);
+  VC_TS(8);
   store_state(a, blockIdx.x, &s_st);
+  VC_TS(9);
 }
 __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
   if (*a.n_active == 0) return;
   load_state(a, blockIdx.x, &s_st);
-  sample_phase(a, blockIdx.x, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2));
+  sample_phase(a, blockIdx.x, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2), s_dyn);
 }
 __global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
@@ -483,11 +504,12 @@ __global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
   store_state(a, blockIdx.x, &s_st);
 }
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
+  const size_t lds = (size_t)a.K * (((a.V + 63) >> 6) << 6) * sizeof(float);
   if (!grouped) {
-    hipLaunchKernelGGL(sample_fused_k, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sample_fused_k, dim3(a.B), dim3(256), lds, s, a);
   } else {
     // the keep decision reads every sample's cond flag, so it needs the kernel boundary
-    hipLaunchKernelGGL(sample_only_k, dim3(a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(sample_only_k, dim3(a.B), dim3(256), lds, s, a);
     hipLaunchKernelGGL(advance_only_k, dim3(a.B), dim3(256), 0, s, a);
   }
   return hipGetLastError();

@@ -112,3 +112,60 @@ def random_prompt(args: Namespace, Lx: int, T: int, seed: int = 1):
     x = torch.from_numpy(rs.randint(0, args.text_vocab_size, size=(1, Lx)).astype(np.int64))
     y = torch.from_numpy(rs.randint(0, args.audio_vocab_size, size=(1, T, args.n_codebooks)).astype(np.int64))
     return x, torch.tensor([Lx], dtype=torch.int64), y
+
+
+def make_codec_state_dict(seed: int = 0) -> dict[str, torch.Tensor]:
+    """Synthetic EnCodec weights in transformers.EncodecModel naming (weight-norm g/v pairs, LSTM,
+    codebooks) at the VoiceCraft codec shape.  Magnitudes keep activations O(1) through 16 layers."""
+    rs = np.random.RandomState(seed)
+    sd: dict[str, torch.Tensor] = {}
+
+    def t(a):
+        return torch.from_numpy(np.ascontiguousarray(a).astype(np.float32))
+
+    def conv(prefix, co, ci, k, transposed=False):
+        shape = (ci, co, k) if transposed else (co, ci, k)
+        fan_in = ci * k if not transposed else ci * k / max(1, k // 2)
+        v = rs.standard_normal(size=shape)
+        g = np.sqrt((v.reshape(shape[0], -1) ** 2).sum(1)) * (1.4 / np.sqrt(fan_in)) * (0.8 + 0.4 * rs.rand(shape[0]))
+        sd[prefix + ".conv.parametrizations.weight.original0"] = t(g.reshape(-1, 1, 1))
+        sd[prefix + ".conv.parametrizations.weight.original1"] = t(v)
+        sd[prefix + ".conv.bias"] = t(0.05 * rs.standard_normal(size=(co,)))
+
+    def lstm(prefix, h, layers=2):
+        for n in range(layers):
+            b = h ** -0.5
+            sd[f"{prefix}.lstm.weight_ih_l{n}"] = t(rs.uniform(-b, b, size=(4 * h, h)))
+            sd[f"{prefix}.lstm.weight_hh_l{n}"] = t(rs.uniform(-b, b, size=(4 * h, h)))
+            sd[f"{prefix}.lstm.bias_ih_l{n}"] = t(rs.uniform(-b, b, size=(4 * h,)))
+            sd[f"{prefix}.lstm.bias_hh_l{n}"] = t(rs.uniform(-b, b, size=(4 * h,)))
+
+    F, ratios, hidden = 64, [8, 5, 4, 2], 128
+    conv("encoder.layers.0", F, 1, 7)
+    idx, ch = 1, F
+    for r in reversed(ratios):
+        conv(f"encoder.layers.{idx}.block.1", ch // 2, ch, 3)
+        conv(f"encoder.layers.{idx}.block.3", ch, ch // 2, 1)
+        idx += 2
+        conv(f"encoder.layers.{idx}", ch * 2, ch, 2 * r)
+        idx += 1
+        ch *= 2
+    lstm(f"encoder.layers.{idx}", ch)
+    idx += 2
+    conv(f"encoder.layers.{idx}", hidden, ch, 7)
+    conv("decoder.layers.0", ch, hidden, 7)
+    lstm("decoder.layers.1", ch)
+    idx = 2
+    for r in ratios:
+        idx += 1
+        conv(f"decoder.layers.{idx}", ch // 2, ch, 2 * r, transposed=True)
+        idx += 1
+        conv(f"decoder.layers.{idx}.block.1", ch // 4, ch // 2, 3)
+        conv(f"decoder.layers.{idx}.block.3", ch // 2, ch // 4, 1)
+        idx += 1
+        ch //= 2
+    idx += 1
+    conv(f"decoder.layers.{idx}", 1, F, 7)
+    for q in range(4):
+        sd[f"quantizer.layers.{q}.codebook.embed"] = t(rs.standard_normal(size=(2048, hidden)) * (0.6 ** q))
+    return sd
