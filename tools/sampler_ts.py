@@ -1,0 +1,18 @@
+"""Reads the shader-clock stamps of the sampler kernel (VC_SAMPLER_TS=1) after a short run."""
+import os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+os.environ["VC_SAMPLER_TS"] = "1"
+from voicecraft_amd import synth
+from voicecraft_amd.engine import VoiceCraftEngine
+a = synth.make_args("giga830M")
+sd = synth.make_state_dict(a, seed=0, perturb=False, fast=True)
+eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024)
+x, xl, y = synth.random_prompt(a, 20, 150, seed=1)
+for rep in range(2):
+    eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, _seed=1)
+    ts = eng.debug_read("sampler_ts", (16,), dtype=torch.int64).numpy()
+    d = np.diff(ts[:10])
+    names = ["load_state+rows->LDS", "logits_out/edits/argmax", "temperature+top-k", "exp/softmax(+top-p)", "draw", "cond+sync", "advance(thread0)", "embedding", "store_state"]
+    print("sampler stamps (shader clocks, last step):", {n: int(v) for n, v in zip(names, d)}, "total", int(ts[9] - ts[0]), flush=True)

@@ -7,6 +7,7 @@
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define VC_ROWS 16          // rows (token positions) one forward pass carries = MFMA N dimension
 #define VC_MAX_NSPLIT 16    // split-S factor cap of the decode attention
@@ -158,6 +159,7 @@ struct GemmArgs {
   int n_tiles, KT;          // ceil(N/16), K / KW
   int nchunk;               // k-chunks per block; a chunk = 4 waves * KTW tiles
   int r_lds;                // rows of X staged in LDS
+  int nt;                   // 1: stream the weights with non-temporal loads
   long w_group_stride;      // in uint4 units
   int bias_group_stride;
   // rows

@@ -78,6 +78,7 @@ struct vc_engine {
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
   hipStream_t pf_stream = nullptr;      // side stream of the Infinity-Cache weight prefetch
   std::vector<hipEvent_t> pf_ev;        // fork/join events, one pair per stage
+  int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
   int prefetch = 0;                     // VC_PREFETCH=1: overlap next-stage weight streaming
   std::vector<PrefetchArgs> pf_args;    // stage i: layer i (i < L), stage L: the heads
   hipEvent_t ev[3]{};
@@ -192,6 +193,7 @@ struct RowSrc {
   int n_rows;       // rows carried (upper bound when n_rows_ptr is set)
   int nsplit;
   const int* n_active;
+  int nt;           // force the streaming-load policy (microbenchmarks)
 };
 
 GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdim) {
@@ -201,6 +203,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.r_lds = rs.n_rows;
   g.row_seq = rs.row_seq; g.row_pos = rs.row_pos; g.n_rows_ptr = rs.n_rows_ptr; g.n_rows = rs.n_rows;
   g.n_active = rs.n_active;
+  g.nt = (rs.n_active != nullptr || rs.nt) ? e->nt_decode : 0;   // decode steps (and the kernel microbenchmarks) stream once
   g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   return g;
@@ -675,6 +678,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   {
     const char* pv = getenv("VC_PREFETCH");
     e->prefetch = pv ? atoi(pv) : 0;
+    const char* nv = getenv("VC_NT");
+    e->nt_decode = nv ? atoi(nv) : 1;
     const long KWb = 1;   // sizes below are in 16-byte units = packed fragments
     e->pf_args.resize((size_t)L + 1);
     auto units = [&](int N, int Kd) { const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16; return (long)((N + 15) / 16) * (Kd / KW) * 64 * KWb; };
@@ -1002,7 +1007,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   HIPCHK(e, hipMemsetAsync(e->logit_row, 0, VC_ROWS * 4, s));
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
-  rs.n_rows = n_rows; rs.nsplit = attn_nsplit(e, n_rows);
+  rs.n_rows = n_rows; rs.nsplit = attn_nsplit(e, n_rows); rs.nt = 1;
   bool hot = false, pre = false;
   std::string w2 = w;
   if (w.size() > 4 && w.substr(w.size() - 4) == "_hot") { hot = true; w2 = w.substr(0, w.size() - 4); }

@@ -127,10 +127,17 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   // Issue order matters: a wave's loads return in order, so anything the prologue needs is
   // requested BEFORE the weight burst and consumed behind a counted vmcnt while the weights
   // (which do not depend on X) are still streaming.
+  // a.nt: non-temporal loads for a weight stream that is read exactly once per launch (decode);
+  // prefill re-reads the same weights for every 16-row group and wants them cached.
 #define VC_ISSUE_WEIGHTS()                                              \
   {                                                                     \
     const int kt_ = kt0 + wave * KTW;                                   \
-    _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt_ + i) * 64]; \
+    if (a.nt) {                                                         \
+      _Pragma("unroll") for (int i = 0; i < KTW; ++i)                   \
+        wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (long)(kt_ + i) * 64))); \
+    } else {                                                            \
+      _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt_ + i) * 64]; \
+    }                                                                   \
   }
 
   // (2) prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.  n_rows >= 1 (host contract).
@@ -293,8 +300,14 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     }
     if (c + 1 < a.nchunk) {   // refill the same registers; co-resident blocks cover the latency
       const int kt = kt0 + ((c + 1) * 4 + wave) * KTW;
+      if (a.nt) {
 #pragma unroll
-      for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt + i) * 64];
+        for (int i = 0; i < KTW; ++i)
+          wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (long)(kt + i) * 64)));
+      } else {
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt + i) * 64];
+      }
     }
   }
 

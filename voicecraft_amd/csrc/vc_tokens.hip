@@ -159,9 +159,9 @@ __device__ __forceinline__ bool is_silence(const SampleArgs& a, int tok) {
 // Phase 1 (one block per sequence, one wave per codebook): logit edits, top-k / top-p filter,
 // categorical draw.  Restates sample_helper + topk_sampling + top_k_top_p_filtering
 // (models/voicecraft.py:1018-1067, :71-86, :26-68).
-// The row lives in LDS and every pass is a short rolled loop: this kernel is one latency-bound
-// block, and a fully unrolled register version (40 KB of straight-line code) spent its time in
-// instruction-cache misses (profiles/r01_rocprof_kernel_stats_v1.txt: 44 us), not in arithmetic.
+// The row is held in registers (34 per lane); LDS is only the scratchpad where lane 0 applies the
+// reference's point edits.  Measured alternatives (profiles/r01_sampler_notes.md): an all-LDS version
+// with rolled loops spends 34 us in the 32-step threshold search alone (LDS latency per element).
 // `sp` is the sequence state (in LDS); results go to xs (LDS in the fused kernel, HBM scratch when the
 // keep decision needs the kernel boundary): xs[0..K) tokens, xs[K] arg-max of codebook 0, xs[K+1] cond.
 #define VC_TS(i) do { if (a.dbg_ts && b == 0 && threadIdx.x == 0) a.dbg_ts[i] = clock64(); } while (0)
@@ -171,26 +171,22 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
   if (st.done) return;
   const int step = st.total_steps;
   const int V = a.V;
-  const int nj = (V + 63) >> 6;
-  const int VP = nj << 6;
+  const int VP = ((V + 63) >> 6) << 6;
   for (int k = wave; k < a.K; k += 4) {
     const float* row = a.logits + ((long)b * a.K + k) * V;
     float* sv = s_rows + k * VP;
-    {   // all loads of the row in flight together (clamped, unconditional), then parked in LDS
-      float t[VC_VPL];
+    float v[VC_VPL];
 #pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) t[j] = row[min(lane + 64 * j, V - 1)];
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j)
-        if (j < nj) sv[lane + 64 * j] = (lane + 64 * j < V) ? t[j] : -INFINITY;
-    }
-    VC_TS(1);
+    for (int j = 0; j < VC_VPL; ++j) v[j] = row[min(lane + 64 * j, V - 1)];   // all loads in flight together
     if (a.logits_out && b == 0 && step < a.logit_steps) {
       float* lo = a.logits_out + ((long)step * a.K + k) * V;
-#pragma unroll 1
-      for (int j = 0; j < nj; ++j) { const int i = lane + 64 * j; if (i < V) lo[i] = sv[i]; }
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) if (lane + 64 * j < V) lo[lane + 64 * j] = v[j];
     }
-    // ---- logit edits, in the reference's order; each touches at most one element
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) if (lane + 64 * j < VP) sv[lane + 64 * j] = v[j];
+    VC_TS(1);
+    // ---- logit edits, in the reference's order; each touches one element, so lane 0 does them in LDS
     if (lane == 0) {
       const int term = st.term_token;
       if (st.kill_token >= 0) sv[st.kill_token] = -10000.f;
@@ -206,51 +202,54 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
         }
       }
     }
-    // (single wave: LDS accesses of one wave are ordered, no barrier needed)
+    // one wave: its LDS accesses are ordered, no barrier needed
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) {
+      const int i = lane + 64 * j;
+      const float t = sv[min(i, VP - 1)];
+      v[j] = (i < V) ? t : -INFINITY;
+    }
     // ---- arg-max of the edited logits (first index on ties, as torch.argmax)
     float bv = -INFINITY;
-#pragma unroll 1
-    for (int j = 0; j < nj; ++j) bv = fmaxf(bv, sv[lane + 64 * j]);
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) bv = fmaxf(bv, v[j]);
     bv = wave_max(bv);
     int bi = 0x7fffffff;
-#pragma unroll 1
-    for (int j = nj - 1; j >= 0; --j) { const int i = lane + 64 * j; if (sv[i] == bv && i < V) bi = i; }
+#pragma unroll
+    for (int j = VC_VPL - 1; j >= 0; --j) bi = (v[j] == bv) ? lane + 64 * j : bi;     // padding is -inf, never equal
     bi = wave_min_i(bi);
     VC_TS(2);
     // ---- temperature
     float mx = bv;
     if (a.temperature != 1.0f) {
-#pragma unroll 1
-      for (int j = 0; j < nj; ++j) sv[lane + 64 * j] = sv[lane + 64 * j] / a.temperature;
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) v[j] = v[j] / a.temperature;
       mx = bv / a.temperature;                      // filters never remove the maximum
     }
     // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive).
-    // Bitwise binary search for the k-th largest order-preserving key.
+    // Bitwise binary search for the k-th largest order-preserving key, on registers.
     if (a.top_k > 0) {
       const int kk = min(max(a.top_k, 1), V);
+      uint32_t key[VC_VPL];
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) key[j] = fkey(v[j]);       // padding: key(-inf) = 0x007fffff, below every finite key
       uint32_t t = 0;
 #pragma unroll 1
       for (int bit = 31; bit >= 0; --bit) {
         const uint32_t cand = t | (1u << bit);
         int c = 0;
-#pragma unroll 3
-        for (int j = 0; j < nj; ++j) c += (fkey(sv[lane + 64 * j]) >= cand) ? 1 : 0;   // padding = -inf: never counted above 0x007fffff
+#pragma unroll
+        for (int j = 0; j < VC_VPL; ++j) c += (key[j] >= cand) ? 1 : 0;
         if (wave_sum_i(c) >= kk) t = cand;
       }
-#pragma unroll 1
-      for (int j = 0; j < nj; ++j) { const int i = lane + 64 * j; if (fkey(sv[i]) < t) sv[i] = -INFINITY; }
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) v[j] = (key[j] < t) ? -INFINITY : v[j];
     }
     VC_TS(3);
-    // ---- softmax numerators, in place (sv now holds p >= 0; 0 = filtered out)
+    // ---- softmax numerators (v now holds p >= 0; 0 = filtered out)
     float ps = 0.f;
-#pragma unroll 1
-    for (int j = 0; j < nj; ++j) {
-      const int i = lane + 64 * j;
-      const float x = sv[i];
-      const float e = (x == -INFINITY) ? 0.f : expf(x - mx);
-      sv[i] = e;
-      ps += e;
-    }
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) { v[j] = __expf(v[j] - mx); ps += v[j]; }        // exp(-inf) = 0
     float tot = wave_sum(ps);
     // ---- top-p: drop a token when the mass of the strictly larger ones already exceeds top_p.
     // p is monotone in the logit, and the bits of a non-negative float order like the float.
@@ -263,18 +262,13 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
       for (int bit = 30; bit >= 0; --bit) {
         const uint32_t cand = t | (1u << bit);
         float mm = 0.f;
-#pragma unroll 3
-        for (int j = 0; j < nj; ++j) { const float e = sv[lane + 64 * j]; mm += (__float_as_uint(e) > cand) ? e : 0.f; }
+#pragma unroll
+        for (int j = 0; j < VC_VPL; ++j) mm += (__float_as_uint(v[j]) > cand) ? v[j] : 0.f;
         if (wave_sum(mm) > lim) t = cand;
       }
       ps = 0.f;
-#pragma unroll 1
-      for (int j = 0; j < nj; ++j) {
-        const int i = lane + 64 * j;
-        float e = sv[i];
-        if (__float_as_uint(e) <= t) { e = 0.f; sv[i] = 0.f; }
-        ps += e;
-      }
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) { v[j] = (__float_as_uint(v[j]) <= t) ? 0.f : v[j]; ps += v[j]; }
       tot = wave_sum(ps);
     }
     VC_TS(4);
@@ -295,21 +289,17 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
       const uint64_t nz = __ballot(ps > 0.f);
       src_lane = nz ? 63 - __clzll((long long)nz) : 0;
     }
-    int tok = 0;
-    if (lane == src_lane) {
-      float acc = excl;
-      int pick = -1, last = -1;
-#pragma unroll 1
-      for (int j = 0; j < nj; ++j) {
-        const float e = sv[lane + 64 * j];
-        if (e > 0.f) {
-          last = lane + 64 * j;
-          acc += e;
-          if (pick < 0 && target < acc) pick = lane + 64 * j;
-        }
-      }
-      tok = (pick >= 0) ? pick : last;
+    // every lane walks its own elements (cheap, branch-free); the owner's result is broadcast
+    float acc = excl;
+    int pick = -1, last = -1;
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) {
+      const bool nz = v[j] > 0.f;
+      acc += v[j];
+      last = nz ? lane + 64 * j : last;
+      pick = (pick < 0 && nz && target < acc) ? lane + 64 * j : pick;
     }
+    int tok = (pick >= 0) ? pick : last;
     tok = __shfl(tok, src_lane, 64);
     if (lane == 0) {
       xs[k] = tok;
