@@ -197,6 +197,10 @@ struct GemmArgs {
   long cache_seq_stride;    // H*S_max*hd
   int S_max;
   float* part_out;          // PART: [ksplit][VC_ROWS][N]
+  // cross-kernel software pipelining: the NEXT kernel's packed weights (null = off)
+  const uint4* pf_base;
+  long pf_group_stride;     // uint4 units between groups of the next kernel
+  int pf_n_tiles, pf_KT, pf_ks, pf_ktblk, pf_G;   // its n-tiles, k-tiles per row, split-K, k-tiles per block, grid size
 };
 
 struct AttnArgs {

@@ -78,6 +78,7 @@ struct vc_engine {
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
   hipStream_t pf_stream = nullptr;      // side stream of the Infinity-Cache weight prefetch
   std::vector<hipEvent_t> pf_ev;        // fork/join events, one pair per stage
+  int xpf = 1;                          // VC_XPF=0 disables cross-kernel weight prefetch in the decode step
   int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
   int prefetch = 0;                     // VC_PREFETCH=1: overlap next-stage weight streaming
   std::vector<PrefetchArgs> pf_args;    // stage i: layer i (i < L), stage L: the heads
@@ -223,6 +224,17 @@ int join_prefetch(vc_engine* e, hipStream_t s) {
   return VC_OK;
 }
 
+// Cross-kernel software pipelining (vc_gemm.hip, PF): tell a rows-GEMM which packed weights the NEXT
+// rows-GEMM of the step will stream, so that it requests them behind its own burst.
+void set_next(vc_engine* e, GemmArgs& g, const RowSrc& rs, const uint4* Wp, const Plan& p, int groups = 1, long group_stride = 0) {
+  if (!e->xpf || rs.n_active == nullptr) return;          // decode steps only
+  const int ktblk = p.KT / p.ksplit;
+  if ((ktblk >> 2) < 1 || (ktblk >> 2) > 16) return;
+  g.pf_base = Wp; g.pf_group_stride = group_stride;
+  g.pf_n_tiles = p.n_tiles; g.pf_KT = p.KT; g.pf_ks = p.ksplit; g.pf_ktblk = ktblk;
+  g.pf_G = p.n_tiles * p.ksplit * groups;
+}
+
 int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = false) {
   const int d = e->d;
   for (int l = 0; l < e->L; ++l) {
@@ -239,6 +251,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = 
       g.has_prev_bias = (l == 0) ? 0 : 1;
       g.ln_w = ly.ln1w; g.ln_b = ly.ln1b;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      set_next(e, g, rs, ly.Wo, e->p_o);
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
     }
     {
@@ -258,6 +271,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = 
       g.Wp = ly.Wo;
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
+      set_next(e, g, rs, ly.W1, e->p_f1);
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)
@@ -267,6 +281,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = 
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.ln_w = ly.ln2w; g.ln_b = ly.ln2b;
       g.out = e->act; g.out_ld = 4 * d;
+      set_next(e, g, rs, ly.W2, e->p_f2);
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
     }
     {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
@@ -274,6 +289,8 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = 
       g.Wp = ly.W2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.part_out = e->parts;
+      if (l + 1 < e->L) set_next(e, g, rs, e->layers[l + 1].Wqkv, e->p_qkv);
+      else set_next(e, g, rs, e->Wh1, e->p_h1);
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     }
   }
@@ -292,6 +309,7 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
     g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     g.ln_w = e->lnf_w; g.ln_b = e->lnf_b; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
+    set_next(e, g, rs, e->Wh2, e->p_h2, e->K, e->wh2_group_stride);
     HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, s));
   }
   {
@@ -300,6 +318,7 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
     g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
     g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits + (size_t)out_row0 * e->K * e->V;
+    set_next(e, g, rs, e->layers[0].Wqkv, e->p_qkv);       // the next step starts with layer 0
     HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
   }
   return VC_OK;
@@ -680,6 +699,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     e->prefetch = pv ? atoi(pv) : 0;
     const char* nv = getenv("VC_NT");
     e->nt_decode = nv ? atoi(nv) : 1;
+    const char* xv = getenv("VC_XPF");
+    e->xpf = xv ? atoi(xv) : 1;
     const long KWb = 1;   // sizes below are in 16-byte units = packed fragments
     e->pf_args.resize((size_t)L + 1);
     auto units = [&](int N, int Kd) { const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16; return (long)((N + 15) / 16) * (Kd / KW) * 64 * KWb; };

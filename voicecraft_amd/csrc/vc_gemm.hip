@@ -105,7 +105,9 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
-template <typename WT, int KTW, int PRO, int EPI>
+#define VC_PFN 16   // prefetch loads (1 KiB each) a wave keeps in flight per round
+
+template <typename WT, int KTW, int PRO, int EPI, int PF>
 __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -124,6 +126,26 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 
   const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * 64 + lane;
   uint4 wf[KTW];
+  // PF: software pipelining ACROSS kernels.  Behind its own weight burst every wave requests its share
+  // of the NEXT kernel's weights (a dependency-free stream that lands in L2 / Infinity Cache) and only
+  // retires those loads after its epilogue: the HBM pipe keeps streaming through this kernel's
+  // dependent tail and the next kernel's launch + prologue, and the next kernel finds its weights
+  // cached.  Next-kernel block j is fetched by block j mod G here (same XCD under round-robin placement).
+  uint4 pfr[PF ? VC_PFN : 1];
+  const int lin_block = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+  const int lin_grid = gridDim.x * gridDim.y * gridDim.z;
+#define VC_PF_ISSUE(round)                                                                     \
+  if constexpr (PF) {                                                                           \
+    const int j_ = min(lin_block + (round) * lin_grid, a.pf_G - 1);                             \
+    const int per_ = a.pf_n_tiles * a.pf_ks;                                                    \
+    const int g_ = j_ / per_, r_ = j_ - g_ * per_;                                              \
+    const int ks_ = r_ / a.pf_n_tiles, nt_ = r_ - ks_ * a.pf_n_tiles;                           \
+    const uint4* p_ = a.pf_base + (long)g_ * a.pf_group_stride + ((long)nt_ * a.pf_KT + (long)ks_ * a.pf_ktblk) * 64 + lane; \
+    const int tpw_ = a.pf_ktblk >> 2;                                                           \
+    _Pragma("unroll") for (int i = 0; i < VC_PFN; ++i) pfr[i] = p_[(long)(wave * tpw_ + min(i, tpw_ - 1)) * 64]; \
+  }
+#define VC_PF_RETIRE()                                                                          \
+  if constexpr (PF) { _Pragma("unroll") for (int i = 0; i < VC_PFN; ++i) asm volatile("" ::"v"(pfr[i].x)); }
   // Issue order matters: a wave's loads return in order, so anything the prologue needs is
   // requested BEFORE the weight burst and consumed behind a counted vmcnt while the weights
   // (which do not depend on X) are still streaming.
@@ -138,6 +160,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     } else {                                                            \
       _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt_ + i) * 64]; \
     }                                                                   \
+    VC_PF_ISSUE(0);                                                     \
   }
 
   // (2) prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.  n_rows >= 1 (host contract).
@@ -314,52 +337,63 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   // (4) 4-way in-block K reduction, then the epilogue on wave 0
   red[wave * 64 + lane] = acc;
   __syncthreads();
-  if (wave != 0) return;
-  {
-    const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
-    acc = (acc + a1) + (a2 + a3);
-  }
   const int m = lane & 15;
   const int n = nt * 16 + 4 * (lane >> 4);
-  if (m >= n_rows) return;
-
-  if constexpr (EPI == EPI_PART) {
-    if (n < a.N) store4(a.part_out + ((long)(ks * VC_ROWS + m)) * a.N + n, acc);
-  } else if constexpr (EPI == EPI_QKV) {
-    if (n >= a.N) return;
-    const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-    acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
-    const int d = a.d;
-    if (n < d) {
-      store4(a.q_out + (long)m * d + n, acc);
-    } else {
-      const int which = (n - d) / d;
-      const int c = (n - d) - which * d;
-      const int h = c / a.hd, e = c - h * a.hd;
-      const int pos = a.row_pos[m];
-      if (pos >= 0) {
-        WT* base = reinterpret_cast<WT*>(which ? a.vcache : a.kcache) +
-                   (long)a.row_seq[m] * a.cache_seq_stride + ((long)h * a.S_max + pos) * a.hd + e;
-        store4(base, acc);
+  if (wave == 0 && m < n_rows) {
+    {
+      const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
+      acc = (acc + a1) + (a2 + a3);
+    }
+    if constexpr (EPI == EPI_PART) {
+      if (n < a.N) store4(a.part_out + ((long)(ks * VC_ROWS + m)) * a.N + n, acc);
+    } else if constexpr (EPI == EPI_QKV) {
+      if (n < a.N) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+        acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
+        const int d = a.d;
+        if (n < d) {
+          store4(a.q_out + (long)m * d + n, acc);
+        } else {
+          const int which = (n - d) / d;
+          const int c = (n - d) - which * d;
+          const int h = c / a.hd, e = c - h * a.hd;
+          const int pos = a.row_pos[m];
+          if (pos >= 0) {
+            WT* base = reinterpret_cast<WT*>(which ? a.vcache : a.kcache) +
+                       (long)a.row_seq[m] * a.cache_seq_stride + ((long)h * a.S_max + pos) * a.hd + e;
+            store4(base, acc);
+          }
+        }
       }
-    }
-  } else if constexpr (EPI == EPI_RELU || EPI == EPI_GELU) {
-    if (n >= a.N) return;
-    const float4 b = *reinterpret_cast<const float4*>(a.bias + (long)grp * a.bias_group_stride + n);
-    acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
+    } else if constexpr (EPI == EPI_RELU || EPI == EPI_GELU) {
+      if (n < a.N) {
+        const float4 b = *reinterpret_cast<const float4*>(a.bias + (long)grp * a.bias_group_stride + n);
+        acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (EPI == EPI_RELU) acc[j] = fmaxf(acc[j], 0.f);
-      else acc[j] = 0.5f * acc[j] * (1.0f + erff(acc[j] * 0.70710678118654752440f));  // nn.GELU() exact erf
-    }
-    store4(reinterpret_cast<WT*>(a.out) + (long)m * a.out_ld + (long)grp * a.out_group_stride + n, acc);
-  } else {  // EPI_LOGITS: float [row][group][N], N need not be a multiple of 4
-    float* o = reinterpret_cast<float*>(a.out) + ((long)m * gridDim.z + grp) * a.N;
-    const float* b = a.bias + (long)grp * a.bias_group_stride;
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (EPI == EPI_RELU) acc[j] = fmaxf(acc[j], 0.f);
+          else acc[j] = 0.5f * acc[j] * (1.0f + erff(acc[j] * 0.70710678118654752440f));  // nn.GELU() exact erf
+        }
+        store4(reinterpret_cast<WT*>(a.out) + (long)m * a.out_ld + (long)grp * a.out_group_stride + n, acc);
+      }
+    } else {  // EPI_LOGITS: float [row][group][N], N need not be a multiple of 4
+      float* o = reinterpret_cast<float*>(a.out) + ((long)m * gridDim.z + grp) * a.N;
+      const float* b = a.bias + (long)grp * a.bias_group_stride;
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (n + j < a.N) o[n + j] = acc[j] + b[n + j];
+      for (int j = 0; j < 4; ++j)
+        if (n + j < a.N) o[n + j] = acc[j] + b[n + j];
+    }
   }
+  // (5) retire the next-kernel prefetch; further rounds when the next grid is larger than this one
+  if constexpr (PF) {
+    VC_PF_RETIRE();
+    for (int round = 1; round * lin_grid < a.pf_G; ++round) {
+      VC_PF_ISSUE(round);
+      VC_PF_RETIRE();
+    }
+  }
+#undef VC_PF_ISSUE
+#undef VC_PF_RETIRE
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -369,9 +403,9 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4);
 }
 
-template <typename WT, int KTW, int PRO, int EPI>
-static hipError_t launch_one(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI>;
+template <typename WT, int KTW, int PRO, int EPI, int PF>
+static hipError_t launch_pf(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, PF>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit);
   if (lds > 64 * 1024) {
     static size_t granted = 0;   // per instantiation
@@ -384,6 +418,12 @@ static hipError_t launch_one(const GemmArgs& a, int dtype, int ksplit, int group
   }
   hipLaunchKernelGGL(kern, dim3(a.n_tiles, ksplit, groups), dim3(256), lds, s, a);
   return hipGetLastError();
+}
+
+template <typename WT, int KTW, int PRO, int EPI>
+static hipError_t launch_one(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  if (a.pf_base) return launch_pf<WT, KTW, PRO, EPI, 1>(a, dtype, ksplit, groups, s);
+  return launch_pf<WT, KTW, PRO, EPI, 0>(a, dtype, ksplit, groups, s);
 }
 
 template <typename WT, int KTW>
