@@ -78,7 +78,7 @@ struct vc_engine {
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
   hipStream_t pf_stream = nullptr;      // side stream of the Infinity-Cache weight prefetch
   std::vector<hipEvent_t> pf_ev;        // fork/join events, one pair per stage
-  int xpf = 1;                          // VC_XPF=0 disables cross-kernel weight prefetch in the decode step
+  int xpf = 0;                          // VC_XPF=1: cross-kernel weight prefetch (measured: -20 %, profiles/README.md)
   int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
   int prefetch = 0;                     // VC_PREFETCH=1: overlap next-stage weight streaming
   std::vector<PrefetchArgs> pf_args;    // stage i: layer i (i < L), stage L: the heads
@@ -700,7 +700,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     const char* nv = getenv("VC_NT");
     e->nt_decode = nv ? atoi(nv) : 1;
     const char* xv = getenv("VC_XPF");
-    e->xpf = xv ? atoi(xv) : 1;
+    e->xpf = xv ? atoi(xv) : 0;
     const long KWb = 1;   // sizes below are in 16-byte units = packed fragments
     e->pf_args.resize((size_t)L + 1);
     auto units = [&](int N, int Kd) { const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16; return (long)((N + 15) / 16) * (Kd / KW) * 64 * KWb; };
@@ -1067,6 +1067,18 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+    } else if (w == "pair" || w == "pair_serial") {
+      // two independent weight-streaming kernels (FFN-up of layer i, FFN-down of layer i+1): on two
+      // streams ("pair") or back to back on one ("pair_serial") - does the chip overlap them?
+      GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
+      g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = nullptr; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
+      g.prev_bias = ly.bo; g.has_prev_bias = 1; g.ln_w = ly.ln2w; g.ln_b = ly.ln2b; g.out = e->act; g.out_ld = 4 * d;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
+      Layer& l2 = e->layers[(i + 1) % e->L];
+      GemmArgs g2 = base_args(e, rs, e->p_f2, d, 4 * d);
+      g2.Wp = l2.W2; g2.x_in = e->hh; g2.x_ld = 4 * d; g2.part_out = e->att_o;   // scratch in/out: values are irrelevant
+      hipStream_t s2 = (w == "pair") ? e->pf_stream : s;
+      HIPCHK(e, vc_launch_gemm(g2, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s2));
     } else if (w == "attn") {
       AttnArgs a;
       memset(&a, 0, sizeof a);
@@ -1084,8 +1096,13 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     return VC_OK;
   };
   for (int i = 0; i < 3; ++i) { rc = one(i); if (rc) return rc; }
+  HIPCHK(e, hipStreamSynchronize(e->pf_stream));
   HIPCHK(e, hipEventRecord(e->ev[0], s));
   for (int i = 0; i < iters; ++i) { rc = one(i); if (rc) return rc; }
+  if (w2 == "pair") {   // join the side stream into the timed one
+    HIPCHK(e, hipEventRecord(e->pf_ev[0], e->pf_stream));
+    HIPCHK(e, hipStreamWaitEvent(s, e->pf_ev[0], 0));
+  }
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   HIPCHK(e, hipStreamSynchronize(s));
   float ms = 0;
