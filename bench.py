@@ -48,6 +48,17 @@ def parse():
     return p.parse_args()
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in its own
+    run, x2-corrected for gfx950 as the microarchitecture guide prescribes); None when no pass is on file
+    or the preset/dtype differs from the one profiled."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return int(json.load(f)["kernels"][kernel]["fetch_bytes_per_launch"])
+    except Exception:
+        return None
+
+
 def cpu_baseline(args, sd, a, x, x_lens, y):
     """The oracle (a port of the reference's CPU path, same ATen ops incl. the per-step KV torch.cat)
     timed on this box's host cores over a bounded sample of the same workload."""
@@ -160,7 +171,7 @@ def main():
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
         roof = {"bound": "hbm", "kernel": "rows_gemm_k<LN,ReLU> (FFN up-projection)",
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn1") if (args.preset == "giga830M" and args.dtype == "bf16") else None,
                 "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
         dec_step_ms = dec_ms / max(1, steps_run)
         out = {
