@@ -122,6 +122,50 @@ __device__ __forceinline__ int wave_min_i(int v) {
              min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// ---------------------------------------------------------------- agent-scope hand-off between launches
+// A consumer launch may start before its producer has finished.  Hand-off recipe of
+// cdna_hip_programming.md §6 G16 (R1): payload stored write-through (global_store ... sc1 = relaxed
+// agent-scope atomic stores, 8 bytes each), every storing wave drains vmcnt, one lane bumps a counter;
+// the consumer polls the counter relaxed and reads the payload with agent-scope (sc1) loads.
+__device__ __forceinline__ void st8_coh(void* p, uint2 v) {
+  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED,
+                     __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st4_coh(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint2 ld8_coh(const void* p) {
+  const unsigned long long x = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT);
+  return make_uint2((unsigned)x, (unsigned)(x >> 32));
+}
+template <int COH>
+__device__ __forceinline__ uint4 ld_u4(const void* p) {
+  if constexpr (COH) {
+    const uint2 a = ld8_coh(p), b = ld8_coh(reinterpret_cast<const char*>(p) + 8);
+    return make_uint4(a.x, a.y, b.x, b.y);
+  } else {
+    return *reinterpret_cast<const uint4*>(p);
+  }
+}
+template <int COH>
+__device__ __forceinline__ float4 ld_f4(const float* p) {
+  const uint4 u = ld_u4<COH>(p);
+  return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
+}
+template <int COH>
+__device__ __forceinline__ float2 ld_f2(const float2* p) {
+  if constexpr (COH) { const uint2 a = ld8_coh(p); return make_float2(__uint_as_float(a.x), __uint_as_float(a.y)); }
+  else return *p;
+}
+__device__ __forceinline__ bool wait_count(const int* cnt, int target) {   // ONE lane; bounded
+  for (unsigned spins = 0; spins < (1u << 21); ++spins) {
+    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
+    __builtin_amdgcn_s_sleep(2);
+  }
+  return false;
+}
+
 // ---------------------------------------------------------------- per-sequence decode state (device)
 // Mirrors the Python locals of the reference's generation loop (models/voicecraft.py:994-1013,
 // :1037-1067): codebook_eog -> n_eog (always a prefix), cur_num_gen, prev_token,
@@ -197,10 +241,11 @@ struct GemmArgs {
   long cache_seq_stride;    // H*S_max*hd
   int S_max;
   float* part_out;          // PART: [ksplit][VC_ROWS][N]
-  // cross-kernel software pipelining: the NEXT kernel's packed weights (null = off)
-  const uint4* pf_base;
-  long pf_group_stride;     // uint4 units between groups of the next kernel
-  int pf_n_tiles, pf_KT, pf_ks, pf_ktblk, pf_G;   // its n-tiles, k-tiles per row, split-K, k-tiles per block, grid size
+  // overlapped decode chain (COH instantiation): producer/consumer counters
+  const int* wait_cnt;      // null = the input is ordered by the stream; else wait until *wait_cnt >= wait_target
+  int wait_target;
+  int* sig_cnt;             // null = nobody waits on this launch through a counter
+  int* sync_err;            // set to 1 when a bounded wait gives up
 };
 
 struct AttnArgs {
@@ -217,6 +262,7 @@ struct AttnArgs {
   const int* n_active;
   float* att_o;
   float* att_ml;
+  int* sig_cnt;             // overlapped chain: bumped once per block after write-through stores (null = off)
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence
@@ -305,7 +351,5 @@ hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s);
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s);
 hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s);
 hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStream_t s);
-struct PrefetchArgs { const uint4* p[6]; long n[6]; int n_seg; };   // n in 16-byte units
-hipError_t vc_launch_prefetch(const PrefetchArgs& a, hipStream_t s);
 hipError_t vc_launch_copy_kv(void* cache, long seq_stride, int H, int S_max, int hd, int len,
                              int src_seq, int dst_seq0, int n_dst, int dtype, hipStream_t s);

@@ -76,12 +76,12 @@ struct vc_engine {
   int *h_flag = nullptr;
 
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
-  hipStream_t pf_stream = nullptr;      // side stream of the Infinity-Cache weight prefetch
-  std::vector<hipEvent_t> pf_ev;        // fork/join events, one pair per stage
-  int xpf = 0;                          // VC_XPF=1: cross-kernel weight prefetch (measured: -20 %, profiles/README.md)
+  hipStream_t pf_stream = nullptr;      // second stream of the overlapped decode chain
+  std::vector<hipEvent_t> pf_ev;        // cross-stream edges of one decode step
   int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
-  int prefetch = 0;                     // VC_PREFETCH=1: overlap next-stage weight streaming
-  std::vector<PrefetchArgs> pf_args;    // stage i: layer i (i < L), stage L: the heads
+  int overlap = 0;                      // VC_OVERLAP bit mask of counter-synchronised edges (0 = plain single stream)
+  int* sync_cnt = nullptr;              // completion counters, one per launch slot of a step
+  int* sync_err = nullptr;              // set when a bounded wait gave up
   hipEvent_t ev[3]{};
   float ms[3]{0, 0, 0};
   double bytes_total = 0;               // HBM bytes owned by the engine
@@ -210,37 +210,52 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   return g;
 }
 
-// Fork: the side stream starts streaming stage (st+1)'s weights once stage st begins.
-int fork_prefetch(vc_engine* e, int st, hipStream_t s) {
-  const int nxt = (st + 1) % (e->L + 1);
-  HIPCHK(e, hipEventRecord(e->pf_ev[2 * st], s));
-  HIPCHK(e, hipStreamWaitEvent(e->pf_stream, e->pf_ev[2 * st], 0));
-  HIPCHK(e, vc_launch_prefetch(e->pf_args[nxt], e->pf_stream));
-  return VC_OK;
-}
-int join_prefetch(vc_engine* e, hipStream_t s) {
-  HIPCHK(e, hipEventRecord(e->pf_ev[1], e->pf_stream));
-  HIPCHK(e, hipStreamWaitEvent(s, e->pf_ev[1], 0));
-  return VC_OK;
-}
+// ---------------------------------------------------------------------------------------------
+// One decode/prefill pass.  Plain mode: every launch on stream s.
+//
+// Overlapped mode (decode only, VC_OVERLAP bit mask): the five launches of a layer
+// alternate between two streams (A: QKV, attention, FFN-up; B: out-projection, FFN-down), so a launch
+// starts as soon as the launch TWO places before it has finished and streams its weights while its
+// direct producer is still running.  The true data dependency of each cross-stream edge is enforced
+// either by a completion counter polled inside the consumer (bit set) or by an event (bit clear).
+//   bit 0: FFN-up -> FFN-down   bit 1: out-proj -> FFN-up   bit 2: FFN-down -> next QKV / heads
+//   bit 3: attention -> out-proj   bit 4: head hidden -> head logits
+// Every buffer reused across launches is only rewritten by a launch that has (transitively) waited for
+// all of its readers; see the hazard table in DESIGN.md §4.1.
+struct Chain {
+  vc_engine* e;
+  hipStream_t sA, sB;
+  bool on;
+  int mask;
+  int ev_i = 0;
+  int* cnt(int slot) const { return e->sync_cnt + slot; }
+  int edge(hipStream_t from, hipStream_t to) {           // classic dependency across the two streams
+    if (from == to) return VC_OK;
+    hipEvent_t ev = e->pf_ev[ev_i++ % e->pf_ev.size()];
+    HIPCHK(e, hipEventRecord(ev, from));
+    HIPCHK(e, hipStreamWaitEvent(to, ev, 0));
+    return VC_OK;
+  }
+  // dependency producer(slot, stream from, nblocks) -> consumer launch g on stream `to`
+  int dep(GemmArgs& g, int bit, int slot, int nblocks, hipStream_t from, hipStream_t to) {
+    if (!on || from == to) return VC_OK;
+    if (mask & (1 << bit)) { g.wait_cnt = cnt(slot); g.wait_target = nblocks; g.sync_err = e->sync_err; return VC_OK; }
+    return edge(from, to);
+  }
+  int* sig(int bit, int slot) const { return (on && (mask & (1 << bit))) ? cnt(slot) : nullptr; }
+};
 
-// Cross-kernel software pipelining (vc_gemm.hip, PF): tell a rows-GEMM which packed weights the NEXT
-// rows-GEMM of the step will stream, so that it requests them behind its own burst.
-void set_next(vc_engine* e, GemmArgs& g, const RowSrc& rs, const uint4* Wp, const Plan& p, int groups = 1, long group_stride = 0) {
-  if (!e->xpf || rs.n_active == nullptr) return;          // decode steps only
-  const int ktblk = p.KT / p.ksplit;
-  if ((ktblk >> 2) < 1 || (ktblk >> 2) > 16) return;
-  g.pf_base = Wp; g.pf_group_stride = group_stride;
-  g.pf_n_tiles = p.n_tiles; g.pf_KT = p.KT; g.pf_ks = p.ksplit; g.pf_ktblk = ktblk;
-  g.pf_G = p.n_tiles * p.ksplit * groups;
-}
-
-int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = false) {
+int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, Chain* ch = nullptr) {
   const int d = e->d;
+  Chain none{e, s, s, false, 0};
+  Chain& c = ch ? *ch : none;
+  const hipStream_t sA = c.sA, sB = c.sB;
+  const int nb_o = e->p_o.n_tiles * e->p_o.ksplit, nb_f1 = e->p_f1.n_tiles, nb_f2 = e->p_f2.n_tiles * e->p_f2.ksplit;
+  const int nb_attn = rs.n_rows * e->H * rs.nsplit;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
-    if (prefetch) { int rc = fork_prefetch(e, l, s); if (rc) return rc; }
-    {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache
+    const int slot = 5 * l;
+    {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache                    [stream A]
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; g.bias = ly.bqkv;
       g.h_in = (l == 0) ? rs.h_in : e->hB;
@@ -251,10 +266,10 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = 
       g.has_prev_bias = (l == 0) ? 0 : 1;
       g.ln_w = ly.ln1w; g.ln_b = ly.ln1b;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      set_next(e, g, rs, ly.Wo, e->p_o);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
+      if (l > 0) { int rc = c.dep(g, 2, slot - 1, nb_f2, sB, sA); if (rc) return rc; }
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, sA));
     }
-    {
+    {  //                                                                                     [stream A]
       AttnArgs a;
       memset(&a, 0, sizeof a);
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc;
@@ -264,34 +279,40 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = 
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows_ptr = rs.n_rows_ptr; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active;
       a.att_o = e->att_o; a.att_ml = e->att_ml;
-      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
+      a.sig_cnt = c.sig(3, slot + 1);
+      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, sA));
     }
-    {  // out-projection of the merged attention output -> split-K partial slabs
+    {  // out-projection of the merged attention output -> split-K partial slabs             [stream B]
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo;
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
-      set_next(e, g, rs, ly.W1, e->p_f1);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+      int rc = c.dep(g, 3, slot + 1, nb_attn, sA, sB);
+      if (rc) return rc;
+      g.sig_cnt = c.sig(1, slot + 2);
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, sB));
     }
-    {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)
+    {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                                      [stream A]
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1;
       g.h_in = e->hA; g.h_out = e->hB;
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.ln_w = ly.ln2w; g.ln_b = ly.ln2b;
       g.out = e->act; g.out_ld = 4 * d;
-      set_next(e, g, rs, ly.W2, e->p_f2);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
+      int rc = c.dep(g, 1, slot + 2, nb_o, sB, sA);
+      if (rc) return rc;
+      g.sig_cnt = c.sig(0, slot + 3);
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, sA));
     }
-    {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
+    {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2     [stream B]
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.part_out = e->parts;
-      if (l + 1 < e->L) set_next(e, g, rs, e->layers[l + 1].Wqkv, e->p_qkv);
-      else set_next(e, g, rs, e->Wh1, e->p_h1);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
+      int rc = c.dep(g, 0, slot + 3, nb_f1, sA, sB);
+      if (rc) return rc;
+      g.sig_cnt = c.sig(2, slot + 4);
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, sB));
     }
   }
   return VC_OK;
@@ -299,27 +320,33 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, bool prefetch = 
 
 // final LayerNorm + the K prediction heads (voicecraft.py:181-185, :1084-1086) for n rows;
 // row r reads hidden row gather[r] and writes logits row (out_row0 + r).
-int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s) {
+int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s, Chain* ch = nullptr) {
   RowSrc rs{};
   rs.n_rows = n; rs.n_active = n_active;
-  {
+  Chain none{e, s, s, false, 0};
+  Chain& c = ch ? *ch : none;
+  const int slot = 5 * e->L;
+  {  //                                                                                       [stream A]
     GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
     g.Wp = e->Wh1; g.bias = e->bh1;
     g.h_in = e->hB; g.h_out = nullptr;
     g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     g.ln_w = e->lnf_w; g.ln_b = e->lnf_b; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
-    set_next(e, g, rs, e->Wh2, e->p_h2, e->K, e->wh2_group_stride);
-    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, s));
+    int rc = c.dep(g, 2, slot - 1, e->p_f2.n_tiles * e->p_f2.ksplit, c.sB, c.sA);
+    if (rc) return rc;
+    g.sig_cnt = c.sig(4, slot);
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, c.sA));
   }
-  {
+  {  //                                                                                       [stream B]
     GemmArgs g = base_args(e, rs, e->p_h2, e->V, e->P);
     g.Wp = e->Wh2; g.bias = e->bh2;
     g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
     g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits + (size_t)out_row0 * e->K * e->V;
-    set_next(e, g, rs, e->layers[0].Wqkv, e->p_qkv);       // the next step starts with layer 0
-    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
+    int rc = c.dep(g, 4, slot, e->p_h1.n_tiles, c.sA, c.sB);
+    if (rc) return rc;
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, c.sB));
   }
   return VC_OK;
 }
@@ -381,14 +408,16 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = B * rps; rs.nsplit = attn_nsplit(e, B * rps); rs.n_active = e->n_active;
-  const bool pf = e->prefetch != 0;
-  int rc = forward_rows(e, rs, s, pf);
-  if (rc) return rc;
-  if (pf) { rc = fork_prefetch(e, e->L, s); if (rc) return rc; }
-  rc = run_heads(e, e->logit_row, B, 0, e->n_active, s);
-  if (rc) return rc;
+  Chain ch{e, s, e->overlap ? e->pf_stream : s, e->overlap != 0, e->overlap};
+  int rc;
+  if (ch.on) {   // counters back to zero, then let stream B see everything stream A has seen so far
+    HIPCHK(e, hipMemsetAsync(e->sync_cnt, 0, (size_t)(5 * e->L + 2) * sizeof(int), s));
+    if ((rc = ch.edge(ch.sA, ch.sB))) return rc;
+  }
+  if ((rc = forward_rows(e, rs, s, &ch))) return rc;
+  if ((rc = run_heads(e, e->logit_row, B, 0, e->n_active, s, &ch))) return rc;
+  if ((rc = ch.edge(ch.sB, ch.sA))) return rc;          // join: the sampler needs the logits
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
-  if (pf) { rc = join_prefetch(e, s); if (rc) return rc; }
   return VC_OK;
 }
 
@@ -455,6 +484,19 @@ int check_ready(vc_engine* e) {
   if (!e->finalized) return fail(e, VC_ESTATE, "weights are not finalized (call vc_finalize_weights)");
   hipError_t err = hipSetDevice(e->device);
   if (err != hipSuccess) return fail(e, VC_EHIP, "hipSetDevice: %s", hipGetErrorString(err));
+  return VC_OK;
+}
+
+// after a decode loop in overlapped mode: did any bounded counter wait give up?
+int check_sync_err(vc_engine* e, hipStream_t s) {
+  if (!e->overlap) return VC_OK;
+  HIPCHK(e, hipMemcpyAsync(e->h_flag + 2, e->sync_err, sizeof(int), hipMemcpyDeviceToHost, s));
+  HIPCHK(e, hipStreamSynchronize(s));
+  if (e->h_flag[2]) {
+    hipMemsetAsync(e->sync_err, 0, sizeof(int), s);
+    return fail(e, VC_EHIP, "overlapped decode chain: a completion-counter wait timed out (VC_OVERLAP=%d); "
+                            "the two streams did not run concurrently as assumed", e->overlap);
+  }
   return VC_OK;
 }
 
@@ -692,33 +734,18 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   // a blocking stream: implicitly ordered after work the caller queued on the null stream
   HIPCHK(e, hipStreamCreate(&e->own_stream));
   HIPCHK(e, hipStreamCreateWithFlags(&e->pf_stream, hipStreamNonBlocking));
-  e->pf_ev.resize(2 * (size_t)(L + 1));
+  e->pf_ev.resize(8 * (size_t)(L + 2));
   for (auto& ev : e->pf_ev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   {
-    const char* pv = getenv("VC_PREFETCH");
-    e->prefetch = pv ? atoi(pv) : 0;
     const char* nv = getenv("VC_NT");
     e->nt_decode = nv ? atoi(nv) : 1;
-    const char* xv = getenv("VC_XPF");
-    e->xpf = xv ? atoi(xv) : 0;
-    const long KWb = 1;   // sizes below are in 16-byte units = packed fragments
-    e->pf_args.resize((size_t)L + 1);
-    auto units = [&](int N, int Kd) { const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16; return (long)((N + 15) / 16) * (Kd / KW) * 64 * KWb; };
-    for (int l = 0; l < L; ++l) {
-      PrefetchArgs& pa = e->pf_args[l];
-      memset(&pa, 0, sizeof pa);
-      pa.n_seg = 4;
-      pa.p[0] = e->layers[l].Wqkv; pa.n[0] = units(3 * d, d);
-      pa.p[1] = e->layers[l].Wo; pa.n[1] = units(d, d);
-      pa.p[2] = e->layers[l].W1; pa.n[2] = units(4 * d, d);
-      pa.p[3] = e->layers[l].W2; pa.n[3] = units(d, 4 * d);
-    }
-    PrefetchArgs& ph = e->pf_args[L];
-    memset(&ph, 0, sizeof ph);
-    ph.n_seg = 2;
-    ph.p[0] = e->Wh1; ph.n[0] = units(K * P, d);
-    ph.p[1] = e->Wh2; ph.n[1] = e->wh2_group_stride * K;
+    const char* ov = getenv("VC_OVERLAP");
+    e->overlap = ov ? atoi(ov) : 0;
   }
+  if ((rc = dalloc(e, &e->sync_cnt, (size_t)8 * (L + 2)))) return rc;
+  if ((rc = dalloc(e, &e->sync_err, (size_t)4))) return rc;
+  HIPCHK(e, hipMemset(e->sync_cnt, 0, (size_t)8 * (L + 2) * 4));
+  HIPCHK(e, hipMemset(e->sync_err, 0, 16));
   HIPCHK(e, hipDeviceSynchronize());
   e->finalized = true;
   return VC_OK;
@@ -789,6 +816,7 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   int steps_run = 0;
   rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s);
   if (rc) return rc;
+  if ((rc = check_sync_err(e, s))) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
@@ -939,6 +967,7 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   int steps_run = 0;
   rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, &steps_run, s);
   if (rc) return rc;
+  if ((rc = check_sync_err(e, s))) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
@@ -1029,26 +1058,12 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = n_rows; rs.nsplit = attn_nsplit(e, n_rows); rs.nt = 1;
-  bool hot = false, pre = false;
+  bool hot = false;
   std::string w2 = w;
   if (w.size() > 4 && w.substr(w.size() - 4) == "_hot") { hot = true; w2 = w.substr(0, w.size() - 4); }
-  // "<k>_pf": a dependency-free streaming read of the same weights runs right before the kernel
-  // (same stream); "pf_<k>": that read alone.  t(<k>_pf) - t(pf_<k>) = the kernel on cache-warm weights.
-  if (w.size() > 3 && w.substr(w.size() - 3) == "_pf") { pre = true; w2 = w.substr(0, w.size() - 3); }
-  bool only_pf = false;
-  if (w.size() > 3 && w.substr(0, 3) == "pf_") { only_pf = true; pre = true; w2 = w.substr(3); }
   auto one = [&](int i) -> int {
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
-    if (pre) {
-      PrefetchArgs pa;
-      memset(&pa, 0, sizeof pa);
-      const PrefetchArgs& full = e->pf_args[i % e->L];
-      const int sg = w == "qkv" ? 0 : w == "oproj" ? 1 : w == "ffn1" ? 2 : 3;
-      pa.n_seg = 1; pa.p[0] = full.p[sg]; pa.n[0] = full.n[sg];
-      HIPCHK(e, vc_launch_prefetch(pa, s));
-      if (only_pf) return VC_OK;
-    }
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;

@@ -68,31 +68,6 @@ hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStr
   return hipGetLastError();
 }
 
-// ------------------------------------------------------------------ Infinity-Cache prefetch
-// A dependency-free streaming read of the NEXT stage's weights, launched on a side stream while the
-// current stage's (dependent, latency-bound) kernels run: it pulls the bytes through HBM into the
-// 256 MiB memory-side cache, so the consumer's weight burst is served from there.  It never waits on
-// anything, so it cannot deadlock; one 256-thread block per CU leaves the consumers their slots.
-__global__ __launch_bounds__(256) void prefetch_k(const PrefetchArgs a) {
-  uint32_t acc = 0;
-  const long stride = (long)gridDim.x * blockDim.x;
-  for (int sg = 0; sg < a.n_seg; ++sg) {
-    const uint4* p = a.p[sg];
-    const long n = a.n[sg];
-    long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-      const uint4 v0 = p[i], v1 = p[i + stride], v2 = p[i + 2 * stride], v3 = p[i + 3 * stride];
-      acc ^= v0.x ^ v1.x ^ v2.x ^ v3.x;
-    }
-    for (; i < n; i += stride) acc ^= p[i].x;
-  }
-  asm volatile("" ::"v"(acc));   // keep the loads alive without storing anything
-}
-hipError_t vc_launch_prefetch(const PrefetchArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(prefetch_k, dim3(256), dim3(256), 0, s, a);
-  return hipGetLastError();
-}
-
 // ------------------------------------------------------------------ rows GEMM
 
 __device__ __forceinline__ void store4(float* p, const f32x4& v) {
@@ -105,9 +80,31 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
-#define VC_PFN 16   // prefetch loads (1 KiB each) a wave keeps in flight per round
+// COH = 1: this launch takes part in the overlapped decode chain: it may have been
+// started before its producer finished, so it waits on the producer's completion counter and reads
+// the producer's output with agent-scope (sc1) loads; its own consumer-facing stores are sc1
+// write-through and it bumps its own counter when they have drained.
+template <int COH, typename T>
+__device__ __forceinline__ void store4c(T* p, const f32x4& v) {
+  if constexpr (!COH) { store4(p, v); }
+  else if constexpr (sizeof(T) == 4) {
+    st8_coh(p, make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1])));
+    st8_coh(reinterpret_cast<float*>(p) + 2, make_uint2(__float_as_uint(v[2]), __float_as_uint(v[3])));
+  } else {
+    st8_coh(p, make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
+                          (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)));
+  }
+}
+// one lane polls the producer's counter (bounded: a scheduling assumption gone wrong becomes an error
+// flag, never a hang), then the block proceeds together
+__device__ __forceinline__ void block_wait(const int* cnt, int target, int* err) {
+  if (cnt) {
+    if (threadIdx.x == 0 && !wait_count(cnt, target)) *err = 1;
+    __syncthreads();
+  }
+}
 
-template <typename WT, int KTW, int PRO, int EPI, int PF>
+template <typename WT, int KTW, int PRO, int EPI, int COH>
 __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -126,26 +123,6 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 
   const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * 64 + lane;
   uint4 wf[KTW];
-  // PF: software pipelining ACROSS kernels.  Behind its own weight burst every wave requests its share
-  // of the NEXT kernel's weights (a dependency-free stream that lands in L2 / Infinity Cache) and only
-  // retires those loads after its epilogue: the HBM pipe keeps streaming through this kernel's
-  // dependent tail and the next kernel's launch + prologue, and the next kernel finds its weights
-  // cached.  Next-kernel block j is fetched by block j mod G here (same XCD under round-robin placement).
-  uint4 pfr[PF ? VC_PFN : 1];
-  const int lin_block = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-  const int lin_grid = gridDim.x * gridDim.y * gridDim.z;
-#define VC_PF_ISSUE(round)                                                                     \
-  if constexpr (PF) {                                                                           \
-    const int j_ = min(lin_block + (round) * lin_grid, a.pf_G - 1);                             \
-    const int per_ = a.pf_n_tiles * a.pf_ks;                                                    \
-    const int g_ = j_ / per_, r_ = j_ - g_ * per_;                                              \
-    const int ks_ = r_ / a.pf_n_tiles, nt_ = r_ - ks_ * a.pf_n_tiles;                           \
-    const uint4* p_ = a.pf_base + (long)g_ * a.pf_group_stride + ((long)nt_ * a.pf_KT + (long)ks_ * a.pf_ktblk) * 64 + lane; \
-    const int tpw_ = a.pf_ktblk >> 2;                                                           \
-    _Pragma("unroll") for (int i = 0; i < VC_PFN; ++i) pfr[i] = p_[(long)(wave * tpw_ + min(i, tpw_ - 1)) * 64]; \
-  }
-#define VC_PF_RETIRE()                                                                          \
-  if constexpr (PF) { _Pragma("unroll") for (int i = 0; i < VC_PFN; ++i) asm volatile("" ::"v"(pfr[i].x)); }
   // Issue order matters: a wave's loads return in order, so anything the prologue needs is
   // requested BEFORE the weight burst and consumed behind a counted vmcnt while the weights
   // (which do not depend on X) are still streaming.
@@ -160,7 +137,6 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     } else {                                                            \
       _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt_ + i) * 64]; \
     }                                                                   \
-    VC_PF_ISSUE(0);                                                     \
   }
 
   // (2) prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.  n_rows >= 1 (host contract).
@@ -191,8 +167,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       x1 = *reinterpret_cast<const float4*>(hp_ + c1);                                           \
       _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_KSPLIT; ++s_) {                             \
         const float* pp_ = a.parts + ((long)(s_ * VC_ROWS + sr)) * d;                            \
-        p0[s_] = *reinterpret_cast<const float4*>(pp_ + c0);                                     \
-        p1[s_] = *reinterpret_cast<const float4*>(pp_ + c1);                                     \
+        p0[s_] = ld_f4<COH>(pp_ + c0);                                                           \
+        p1[s_] = ld_f4<COH>(pp_ + c1);                                                           \
       }                                                                                          \
     }
 #define VC_FINISH_ROW(r)                                                                         \
@@ -237,8 +213,14 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
         store4(xr_ + c1, y_);                                                                    \
       }                                                                                          \
     }
-    VC_LOAD_ROW(0);
-    VC_ISSUE_WEIGHTS();
+    if constexpr (COH) {          // the row's slabs do not exist yet: request the weights, then wait for the producer
+      VC_ISSUE_WEIGHTS();
+      block_wait(a.wait_cnt, a.wait_target, a.sync_err);
+      VC_LOAD_ROW(0);
+    } else {
+      VC_LOAD_ROW(0);
+      VC_ISSUE_WEIGHTS();
+    }
     VC_FINISH_ROW(0);
     for (int r = 1; r < n_rows; ++r) {
       VC_LOAD_ROW(r);
@@ -248,12 +230,13 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 #undef VC_FINISH_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
     VC_ISSUE_WEIGHTS();
+    if constexpr (COH) block_wait(a.wait_cnt, a.wait_target, a.sync_err);
     const int upr = kblk * (int)sizeof(WT) / 16;  // 16-byte units per row
     const char* src = reinterpret_cast<const char*>(a.x_in);
     for (int idx = tid; idx < n_rows * upr; idx += 256) {
       const int r = idx / upr, u = idx - r * upr;
       const long off = ((long)r * a.x_ld + (long)grp * a.x_group_stride + k0) * (long)sizeof(WT) + (long)u * 16;
-      *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + off);
+      *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) = ld_u4<COH>(src + off);
     }
   } else {  // PRO_ATT: merge the split-S partials of the decode attention (softmax denominators)
     // item = (row, 4 columns of one head); its 2*VC_MAX_NSPLIT loads are requested before the
@@ -275,8 +258,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       const float* op_ = a.att_o + ((long)(r_ * a.H + h_) * a.nsplit) * a.hd + e_;               \
       _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
         const int se_ = (s_ < a.nsplit) ? s_ : 0;                                                \
-        mls[s_] = ml_[se_];                                                                      \
-        os[s_] = *reinterpret_cast<const float4*>(op_ + (long)se_ * a.hd);                       \
+        mls[s_] = ld_f2<COH>(ml_ + se_);                                                         \
+        os[s_] = ld_f4<COH>(op_ + (long)se_ * a.hd);                                             \
       }                                                                                          \
     }
 #define VC_FINISH_ITEMS()                                                                        \
@@ -297,8 +280,14 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       o_[0] *= inv_; o_[1] *= inv_; o_[2] *= inv_; o_[3] *= inv_;                                \
       if (on_) store4(reinterpret_cast<WT*>(xl + (size_t)r_ * xs) + (c_ - k0), o_);              \
     }
-    VC_LOAD_ITEMS(0);
-    VC_ISSUE_WEIGHTS();
+    if constexpr (COH) {
+      VC_ISSUE_WEIGHTS();
+      block_wait(a.wait_cnt, a.wait_target, a.sync_err);
+      VC_LOAD_ITEMS(0);
+    } else {
+      VC_LOAD_ITEMS(0);
+      VC_ISSUE_WEIGHTS();
+    }
     VC_FINISH_ITEMS();
     for (int base = 256; base < n_items; base += 256) {
       VC_LOAD_ITEMS(base);
@@ -345,7 +334,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       acc = (acc + a1) + (a2 + a3);
     }
     if constexpr (EPI == EPI_PART) {
-      if (n < a.N) store4(a.part_out + ((long)(ks * VC_ROWS + m)) * a.N + n, acc);
+      if (n < a.N) store4c<COH>(a.part_out + ((long)(ks * VC_ROWS + m)) * a.N + n, acc);
     } else if constexpr (EPI == EPI_QKV) {
       if (n < a.N) {
         const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
@@ -374,7 +363,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
           if constexpr (EPI == EPI_RELU) acc[j] = fmaxf(acc[j], 0.f);
           else acc[j] = 0.5f * acc[j] * (1.0f + erff(acc[j] * 0.70710678118654752440f));  // nn.GELU() exact erf
         }
-        store4(reinterpret_cast<WT*>(a.out) + (long)m * a.out_ld + (long)grp * a.out_group_stride + n, acc);
+        store4c<COH>(reinterpret_cast<WT*>(a.out) + (long)m * a.out_ld + (long)grp * a.out_group_stride + n, acc);
       }
     } else {  // EPI_LOGITS: float [row][group][N], N need not be a multiple of 4
       float* o = reinterpret_cast<float*>(a.out) + ((long)m * gridDim.z + grp) * a.N;
@@ -384,16 +373,14 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
         if (n + j < a.N) o[n + j] = acc[j] + b[n + j];
     }
   }
-  // (5) retire the next-kernel prefetch; further rounds when the next grid is larger than this one
-  if constexpr (PF) {
-    VC_PF_RETIRE();
-    for (int round = 1; round * lin_grid < a.pf_G; ++round) {
-      VC_PF_ISSUE(round);
-      VC_PF_RETIRE();
+  // (5) publish: wave 0 made every consumer-facing store of this block (write-through); once they have
+  // drained, one agent-scope increment tells the consumer kernel that this block is done.
+  if constexpr (COH) {
+    if (a.sig_cnt && wave == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if (lane == 0) __hip_atomic_fetch_add(a.sig_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-#undef VC_PF_ISSUE
-#undef VC_PF_RETIRE
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -403,9 +390,9 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4);
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int PF>
-static hipError_t launch_pf(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, PF>;
+template <typename WT, int KTW, int PRO, int EPI, int COH>
+static hipError_t launch_coh(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, COH>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit);
   if (lds > 64 * 1024) {
     static size_t granted = 0;   // per instantiation
@@ -422,8 +409,8 @@ static hipError_t launch_pf(const GemmArgs& a, int dtype, int ksplit, int groups
 
 template <typename WT, int KTW, int PRO, int EPI>
 static hipError_t launch_one(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  if (a.pf_base) return launch_pf<WT, KTW, PRO, EPI, 1>(a, dtype, ksplit, groups, s);
-  return launch_pf<WT, KTW, PRO, EPI, 0>(a, dtype, ksplit, groups, s);
+  if (a.wait_cnt || a.sig_cnt) return launch_coh<WT, KTW, PRO, EPI, 1>(a, dtype, ksplit, groups, s);
+  return launch_coh<WT, KTW, PRO, EPI, 0>(a, dtype, ksplit, groups, s);
 }
 
 template <typename WT, int KTW>
