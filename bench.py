@@ -165,8 +165,7 @@ def main():
         k_ms, k_bytes = eng.bench_kernel("ffn1", n_rows=B, iters=64)
         step_ms, _ = eng.bench_kernel("step", n_rows=B, iters=8)
         kernels = {}
-        for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot",
-                   "pair", "pair_serial"):
+        for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
             ms_, by_ = eng.bench_kernel(kn, n_rows=B, iters=64)
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
         roof = {"bound": "hbm", "kernel": "rows_gemm_k<LN,ReLU> (FFN up-projection)",

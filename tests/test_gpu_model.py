@@ -136,3 +136,39 @@ def test_input_validation_mirrors_reference_asserts():
         eng.inference_tts(x, x_lens, bad)                       # token id outside the vocabulary
     with pytest.raises(IndexError):
         eng.inference(x, x_lens, y, torch.tensor([[[0, 3]]]))   # span at frame 0: the reference raises too
+
+
+@pytest.mark.parametrize("Lx,T", [(30, 180), (25, 103), (40, 260)])
+def test_fp32_multi_pass_prefill_equals_oracle(Lx, T):
+    """Prompts longer than one 128-row prefill pass (and one that ends exactly on a pass boundary:
+    25 + 103 = 128 rows): greedy tokens must still equal the CPU oracle's, fp32 mode."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("tiny")
+    sd = synth.make_state_dict(a, seed=9)
+    x, xl, y = synth.random_prompt(a, Lx, T, seed=100 + Lx)
+    want = VoiceCraftOracle(a, sd).inference_tts(x, xl, y, top_k=1, stop_repetition=3)[0].numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=1, max_positions=1024)
+    got = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+def test_bf16_long_edit_prefill_teacher_forced():
+    """Editing with a 300-frame utterance (prefill of ~330 rows = 3 passes), bf16, teacher-forced logits."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("tiny128")
+    sd = synth.make_state_dict(a, seed=10)
+    x, xl, y = synth.random_prompt(a, 36, 300, seed=77)
+    mi = torch.tensor([[[100, 140], [220, 230]]], dtype=torch.int64)
+    trace = []
+    want_res = VoiceCraftOracle(a, sd).inference(x, xl, y, mi, top_k=1, trace=trace)
+    want = torch.stack([t["logits"][0] for t in trace]).numpy()
+    forced = torch.stack([t["tokens"] for t in trace]).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024)
+    res, lg = eng.inference(x.cuda(), xl.cuda(), y.cuda(), mi, top_k=1, _forced=forced, _logit_steps=len(trace))
+    assert np.array_equal(res.cpu().numpy(), want_res.numpy())
+    rel = rel_l2(lg.cpu().numpy(), want)
+    assert rel.max() <= 2e-2, rel.max()

@@ -127,18 +127,8 @@ __global__ __launch_bounds__(256) void rows_attn_k(const AttnArgs a) {
       O += c * s_o[w][tid];
     }
     const long pi = ((long)(r * a.H + h) * a.nsplit + sp);
-    if (a.sig_cnt) {            // overlapped chain: write-through, the out-projection may already be polling
-      st4_coh(a.att_o + pi * hd + tid, O);
-      if (tid == 0) st8_coh(a.att_ml + pi * 2, make_uint2(__float_as_uint(M), __float_as_uint(L)));
-    } else {
-      a.att_o[pi * hd + tid] = O;
-      if (tid == 0) { a.att_ml[pi * 2] = M; a.att_ml[pi * 2 + 1] = L; }
-    }
-  }
-  if (a.sig_cnt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_fetch_add(a.sig_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.att_o[pi * hd + tid] = O;
+    if (tid == 0) { a.att_ml[pi * 2] = M; a.att_ml[pi * 2 + 1] = L; }
   }
 }
 

@@ -9,7 +9,8 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
-#define VC_ROWS 16          // rows (token positions) one forward pass carries = MFMA N dimension
+#define VC_ROWS 16          // rows (token positions) of one MFMA tile = the N dimension of the rows-GEMM
+#define VC_MAX_ROWS 128     // rows one forward pass may carry (prefill: 8 row tiles per weight burst)
 #define VC_MAX_NSPLIT 16    // split-S factor cap of the decode attention
 #define VC_MAX_KSPLIT 4     // cross-block split-K cap of the rows-GEMM (the LN prologue prefetches this many slabs)
 #define VC_MAX_SEG 32       // prompt segments (2*spans+1 pieces + placeholders)
@@ -122,50 +123,6 @@ __device__ __forceinline__ int wave_min_i(int v) {
              min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
-// ---------------------------------------------------------------- agent-scope hand-off between launches
-// A consumer launch may start before its producer has finished.  Hand-off recipe of
-// cdna_hip_programming.md §6 G16 (R1): payload stored write-through (global_store ... sc1 = relaxed
-// agent-scope atomic stores, 8 bytes each), every storing wave drains vmcnt, one lane bumps a counter;
-// the consumer polls the counter relaxed and reads the payload with agent-scope (sc1) loads.
-__device__ __forceinline__ void st8_coh(void* p, uint2 v) {
-  __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), ((unsigned long long)v.y << 32) | v.x, __ATOMIC_RELAXED,
-                     __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st4_coh(float* p, float v) {
-  __hip_atomic_store(reinterpret_cast<unsigned int*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint2 ld8_coh(const void* p) {
-  const unsigned long long x = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED,
-                                                 __HIP_MEMORY_SCOPE_AGENT);
-  return make_uint2((unsigned)x, (unsigned)(x >> 32));
-}
-template <int COH>
-__device__ __forceinline__ uint4 ld_u4(const void* p) {
-  if constexpr (COH) {
-    const uint2 a = ld8_coh(p), b = ld8_coh(reinterpret_cast<const char*>(p) + 8);
-    return make_uint4(a.x, a.y, b.x, b.y);
-  } else {
-    return *reinterpret_cast<const uint4*>(p);
-  }
-}
-template <int COH>
-__device__ __forceinline__ float4 ld_f4(const float* p) {
-  const uint4 u = ld_u4<COH>(p);
-  return make_float4(__uint_as_float(u.x), __uint_as_float(u.y), __uint_as_float(u.z), __uint_as_float(u.w));
-}
-template <int COH>
-__device__ __forceinline__ float2 ld_f2(const float2* p) {
-  if constexpr (COH) { const uint2 a = ld8_coh(p); return make_float2(__uint_as_float(a.x), __uint_as_float(a.y)); }
-  else return *p;
-}
-__device__ __forceinline__ bool wait_count(const int* cnt, int target) {   // ONE lane; bounded
-  for (unsigned spins = 0; spins < (1u << 21); ++spins) {
-    if (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= target) return true;
-    __builtin_amdgcn_s_sleep(2);
-  }
-  return false;
-}
-
 // ---------------------------------------------------------------- per-sequence decode state (device)
 // Mirrors the Python locals of the reference's generation loop (models/voicecraft.py:994-1013,
 // :1037-1067): codebook_eog -> n_eog (always a prefix), cur_num_gen, prev_token,
@@ -202,8 +159,10 @@ struct GemmArgs {
   int N, K;                 // logical out / in features per group
   int n_tiles, KT;          // ceil(N/16), K / KW
   int nchunk;               // k-chunks per block; a chunk = 4 waves * KTW tiles
-  int r_lds;                // rows of X staged in LDS
+  int r_lds;                // rows of X staged in LDS (<= VC_ROWS)
+  int rows_cap;             // row stride of the split-K slabs: parts[s][rows_cap][N]
   int nt;                   // 1: stream the weights with non-temporal loads
+  int mt;                   // 1: multi-tile pass (rows_gemm_mt_k): n_rows may reach VC_MAX_ROWS, no LN prologue
   long w_group_stride;      // in uint4 units
   int bias_group_stride;
   // rows
@@ -215,7 +174,7 @@ struct GemmArgs {
   // prologue LN:   hn = h_in[src] + prev_bias + sum_s parts[s][r]; X = LN(hn) ; h_out[r] = hn
   const float* h_in;
   float* h_out;
-  const float* parts;       // [VC_MAX_KSPLIT][VC_ROWS][d], always readable; the first n_parts slabs are summed
+  const float* parts;       // [VC_MAX_KSPLIT][rows_cap][d], always readable; the first n_parts slabs are summed
   int n_parts;
   const float* prev_bias;   // always a readable [d] vector; added only when has_prev_bias
   int has_prev_bias;
@@ -240,12 +199,8 @@ struct GemmArgs {
   void* vcache;
   long cache_seq_stride;    // H*S_max*hd
   int S_max;
-  float* part_out;          // PART: [ksplit][VC_ROWS][N]
-  // overlapped decode chain (COH instantiation): producer/consumer counters
-  const int* wait_cnt;      // null = the input is ordered by the stream; else wait until *wait_cnt >= wait_target
-  int wait_target;
-  int* sig_cnt;             // null = nobody waits on this launch through a counter
-  int* sync_err;            // set to 1 when a bounded wait gives up
+  float* part_out;          // PART: [ksplit][rows_cap][N]
+  void* x_out;              // ln_rows_k: normalised rows, WT [rows][d]
 };
 
 struct AttnArgs {
@@ -262,7 +217,6 @@ struct AttnArgs {
   const int* n_active;
   float* att_o;
   float* att_ml;
-  int* sig_cnt;             // overlapped chain: bumped once per block after write-through stores (null = off)
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence
@@ -346,6 +300,7 @@ hipError_t vc_launch_pack(const float* src, void* dst, int N, int K, int dtype, 
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s);
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
+hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);
 hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s);
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s);

@@ -63,7 +63,7 @@ struct vc_engine {
   float *emb = nullptr;                 // prefill rows [S_max][d]
   int *pre_row_seq = nullptr, *pre_row_pos = nullptr;
   float *hA = nullptr, *hB = nullptr, *q = nullptr, *parts = nullptr, *att_o = nullptr, *att_ml = nullptr;
-  void *act = nullptr, *hh = nullptr;
+  void *act = nullptr, *hh = nullptr, *xn = nullptr;
   float *logits = nullptr;              // [B_max][K][V]
   float *dec_h = nullptr;               // [VC_ROWS][d]
   int *dec_row_seq = nullptr, *dec_row_pos = nullptr, *logit_row = nullptr;
@@ -76,12 +76,8 @@ struct vc_engine {
   int *h_flag = nullptr;
 
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
-  hipStream_t pf_stream = nullptr;      // second stream of the overlapped decode chain
-  std::vector<hipEvent_t> pf_ev;        // cross-stream edges of one decode step
   int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
-  int overlap = 0;                      // VC_OVERLAP bit mask of counter-synchronised edges (0 = plain single stream)
-  int* sync_cnt = nullptr;              // completion counters, one per launch slot of a step
-  int* sync_err = nullptr;              // set when a bounded wait gave up
+  int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
   float ms[3]{0, 0, 0};
   double bytes_total = 0;               // HBM bytes owned by the engine
@@ -201,7 +197,8 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   GemmArgs g;
   memset(&g, 0, sizeof g);
   g.N = N; g.K = Kdim; g.n_tiles = p.n_tiles; g.KT = p.KT; g.nchunk = p.nchunk;
-  g.r_lds = rs.n_rows;
+  g.r_lds = std::min(rs.n_rows, VC_ROWS);
+  g.rows_cap = VC_MAX_ROWS;
   g.row_seq = rs.row_seq; g.row_pos = rs.row_pos; g.n_rows_ptr = rs.n_rows_ptr; g.n_rows = rs.n_rows;
   g.n_active = rs.n_active;
   g.nt = (rs.n_active != nullptr || rs.nt) ? e->nt_decode : 0;   // decode steps (and the kernel microbenchmarks) stream once
@@ -210,52 +207,12 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   return g;
 }
 
-// ---------------------------------------------------------------------------------------------
-// One decode/prefill pass.  Plain mode: every launch on stream s.
-//
-// Overlapped mode (decode only, VC_OVERLAP bit mask): the five launches of a layer
-// alternate between two streams (A: QKV, attention, FFN-up; B: out-projection, FFN-down), so a launch
-// starts as soon as the launch TWO places before it has finished and streams its weights while its
-// direct producer is still running.  The true data dependency of each cross-stream edge is enforced
-// either by a completion counter polled inside the consumer (bit set) or by an event (bit clear).
-//   bit 0: FFN-up -> FFN-down   bit 1: out-proj -> FFN-up   bit 2: FFN-down -> next QKV / heads
-//   bit 3: attention -> out-proj   bit 4: head hidden -> head logits
-// Every buffer reused across launches is only rewritten by a launch that has (transitively) waited for
-// all of its readers; see the hazard table in DESIGN.md §4.1.
-struct Chain {
-  vc_engine* e;
-  hipStream_t sA, sB;
-  bool on;
-  int mask;
-  int ev_i = 0;
-  int* cnt(int slot) const { return e->sync_cnt + slot; }
-  int edge(hipStream_t from, hipStream_t to) {           // classic dependency across the two streams
-    if (from == to) return VC_OK;
-    hipEvent_t ev = e->pf_ev[ev_i++ % e->pf_ev.size()];
-    HIPCHK(e, hipEventRecord(ev, from));
-    HIPCHK(e, hipStreamWaitEvent(to, ev, 0));
-    return VC_OK;
-  }
-  // dependency producer(slot, stream from, nblocks) -> consumer launch g on stream `to`
-  int dep(GemmArgs& g, int bit, int slot, int nblocks, hipStream_t from, hipStream_t to) {
-    if (!on || from == to) return VC_OK;
-    if (mask & (1 << bit)) { g.wait_cnt = cnt(slot); g.wait_target = nblocks; g.sync_err = e->sync_err; return VC_OK; }
-    return edge(from, to);
-  }
-  int* sig(int bit, int slot) const { return (on && (mask & (1 << bit))) ? cnt(slot) : nullptr; }
-};
-
-int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, Chain* ch = nullptr) {
+// One pass of up to 16 rows through every layer (decode step, 3-row span switch, short prompts).
+int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
-  Chain none{e, s, s, false, 0};
-  Chain& c = ch ? *ch : none;
-  const hipStream_t sA = c.sA, sB = c.sB;
-  const int nb_o = e->p_o.n_tiles * e->p_o.ksplit, nb_f1 = e->p_f1.n_tiles, nb_f2 = e->p_f2.n_tiles * e->p_f2.ksplit;
-  const int nb_attn = rs.n_rows * e->H * rs.nsplit;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
-    const int slot = 5 * l;
-    {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache                    [stream A]
+    {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; g.bias = ly.bqkv;
       g.h_in = (l == 0) ? rs.h_in : e->hB;
@@ -266,10 +223,9 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, Chain* ch = null
       g.has_prev_bias = (l == 0) ? 0 : 1;
       g.ln_w = ly.ln1w; g.ln_b = ly.ln1b;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      if (l > 0) { int rc = c.dep(g, 2, slot - 1, nb_f2, sB, sA); if (rc) return rc; }
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, sA));
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
     }
-    {  //                                                                                     [stream A]
+    {  //                                                                 
       AttnArgs a;
       memset(&a, 0, sizeof a);
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc;
@@ -279,40 +235,30 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, Chain* ch = null
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows_ptr = rs.n_rows_ptr; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active;
       a.att_o = e->att_o; a.att_ml = e->att_ml;
-      a.sig_cnt = c.sig(3, slot + 1);
-      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, sA));
+      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
-    {  // out-projection of the merged attention output -> split-K partial slabs             [stream B]
+    {  // out-projection of the merged attention output -> split-K partial slabs
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo;
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
-      int rc = c.dep(g, 3, slot + 1, nb_attn, sA, sB);
-      if (rc) return rc;
-      g.sig_cnt = c.sig(1, slot + 2);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, sB));
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     }
-    {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                                      [stream A]
+    {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1;
       g.h_in = e->hA; g.h_out = e->hB;
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.ln_w = ly.ln2w; g.ln_b = ly.ln2b;
       g.out = e->act; g.out_ld = 4 * d;
-      int rc = c.dep(g, 1, slot + 2, nb_o, sB, sA);
-      if (rc) return rc;
-      g.sig_cnt = c.sig(0, slot + 3);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, sA));
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
     }
-    {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2     [stream B]
+    {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.part_out = e->parts;
-      int rc = c.dep(g, 0, slot + 3, nb_f1, sA, sB);
-      if (rc) return rc;
-      g.sig_cnt = c.sig(2, slot + 4);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, sB));
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     }
   }
   return VC_OK;
@@ -320,33 +266,72 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s, Chain* ch = null
 
 // final LayerNorm + the K prediction heads (voicecraft.py:181-185, :1084-1086) for n rows;
 // row r reads hidden row gather[r] and writes logits row (out_row0 + r).
-int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s, Chain* ch = nullptr) {
+int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s) {
   RowSrc rs{};
   rs.n_rows = n; rs.n_active = n_active;
-  Chain none{e, s, s, false, 0};
-  Chain& c = ch ? *ch : none;
-  const int slot = 5 * e->L;
-  {  //                                                                                       [stream A]
+  {  //                                                                   
     GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
     g.Wp = e->Wh1; g.bias = e->bh1;
     g.h_in = e->hB; g.h_out = nullptr;
     g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     g.ln_w = e->lnf_w; g.ln_b = e->lnf_b; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
-    int rc = c.dep(g, 2, slot - 1, e->p_f2.n_tiles * e->p_f2.ksplit, c.sB, c.sA);
-    if (rc) return rc;
-    g.sig_cnt = c.sig(4, slot);
-    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, c.sA));
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, s));
   }
-  {  //                                                                                       [stream B]
+  {  //                                                                          
     GemmArgs g = base_args(e, rs, e->p_h2, e->V, e->P);
     g.Wp = e->Wh2; g.bias = e->bh2;
     g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
     g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits + (size_t)out_row0 * e->K * e->V;
-    int rc = c.dep(g, 4, slot, e->p_h1.n_tiles, c.sA, c.sB);
-    if (rc) return rc;
-    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, c.sB));
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
+  }
+  return VC_OK;
+}
+
+// Prefill pass over up to VC_MAX_ROWS prompt rows: LayerNorm once per row (ln_rows_k), then the
+// multi-tile rows-GEMM (weights streamed once per pass).  Same buffers and slabs as the decode pass.
+int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
+  const int d = e->d;
+  for (int l = 0; l < e->L; ++l) {
+    Layer& ly = e->layers[l];
+    {
+      GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
+      g.h_in = (l == 0) ? rs.h_in : e->hB; g.h_out = e->hA; g.parts = e->parts;
+      g.n_parts = (l == 0) ? 0 : e->p_f2.ksplit;
+      g.prev_bias = (l == 0) ? ly.ln1b : e->layers[l - 1].b2; g.has_prev_bias = (l == 0) ? 0 : 1;
+      g.ln_w = ly.ln1w; g.ln_b = ly.ln1b; g.x_out = e->xn;
+      HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
+      g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = 1;
+      g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
+    }
+    {
+      AttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
+      a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
+      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
+    }
+    {
+      GemmArgs g = base_args(e, rs, e->p_o, d, d);
+      g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts; g.mt = 1;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+    }
+    {
+      GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
+      g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
+      g.ln_w = ly.ln2w; g.ln_b = ly.ln2b; g.x_out = e->xn;
+      HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
+      g.Wp = ly.W1; g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = 1;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
+    }
+    {
+      GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
+      g.Wp = ly.W2; g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts; g.mt = 1;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
+    }
   }
   return VC_OK;
 }
@@ -362,15 +347,16 @@ int prefill_seq(vc_engine* e, PromptArgs& pa, int slot, hipStream_t s) {
   pa.seq = slot; pa.row0 = 0;
   pa.emb = e->emb; pa.row_seq = e->pre_row_seq; pa.row_pos = e->pre_row_pos; pa.err = e->err_flag;
   pa.logit_row = e->logit_row + slot;
-  pa.logit_row_val = (rows - 1) % VC_ROWS;
+  const int chunk = e->prefill_rows_per_pass;
+  pa.logit_row_val = (rows - 1) % chunk;
   HIPCHK(e, vc_launch_prompt(pa, s));
-  for (int r0 = 0; r0 < rows; r0 += VC_ROWS) {
+  for (int r0 = 0; r0 < rows; r0 += chunk) {
     RowSrc rs{};
     rs.h_in = e->emb + (size_t)r0 * e->d;
     rs.row_seq = e->pre_row_seq + r0; rs.row_pos = e->pre_row_pos + r0;
-    rs.n_rows = std::min(VC_ROWS, rows - r0);
+    rs.n_rows = std::min(chunk, rows - r0);
     rs.nsplit = attn_nsplit(e, rs.n_rows);
-    int rc = forward_rows(e, rs, s);
+    int rc = (chunk > VC_ROWS) ? prefill_rows(e, rs, s) : forward_rows(e, rs, s);
     if (rc) return rc;
   }
   return run_heads(e, e->logit_row + slot, 1, slot, nullptr, s);
@@ -408,15 +394,9 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = B * rps; rs.nsplit = attn_nsplit(e, B * rps); rs.n_active = e->n_active;
-  Chain ch{e, s, e->overlap ? e->pf_stream : s, e->overlap != 0, e->overlap};
   int rc;
-  if (ch.on) {   // counters back to zero, then let stream B see everything stream A has seen so far
-    HIPCHK(e, hipMemsetAsync(e->sync_cnt, 0, (size_t)(5 * e->L + 2) * sizeof(int), s));
-    if ((rc = ch.edge(ch.sA, ch.sB))) return rc;
-  }
-  if ((rc = forward_rows(e, rs, s, &ch))) return rc;
-  if ((rc = run_heads(e, e->logit_row, B, 0, e->n_active, s, &ch))) return rc;
-  if ((rc = ch.edge(ch.sB, ch.sA))) return rc;          // join: the sampler needs the logits
+  if ((rc = forward_rows(e, rs, s))) return rc;
+  if ((rc = run_heads(e, e->logit_row, B, 0, e->n_active, s))) return rc;
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
   return VC_OK;
 }
@@ -487,19 +467,6 @@ int check_ready(vc_engine* e) {
   return VC_OK;
 }
 
-// after a decode loop in overlapped mode: did any bounded counter wait give up?
-int check_sync_err(vc_engine* e, hipStream_t s) {
-  if (!e->overlap) return VC_OK;
-  HIPCHK(e, hipMemcpyAsync(e->h_flag + 2, e->sync_err, sizeof(int), hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipStreamSynchronize(s));
-  if (e->h_flag[2]) {
-    hipMemsetAsync(e->sync_err, 0, sizeof(int), s);
-    return fail(e, VC_EHIP, "overlapped decode chain: a completion-counter wait timed out (VC_OVERLAP=%d); "
-                            "the two streams did not run concurrently as assumed", e->overlap);
-  }
-  return VC_OK;
-}
-
 int check_err_flag(vc_engine* e, hipStream_t s) {
   HIPCHK(e, hipMemcpyAsync(e->h_flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
@@ -557,8 +524,6 @@ extern "C" void vc_destroy(vc_engine* e) {
   if (e->h_flag) hipHostFree(e->h_flag);
   for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
-  if (e->pf_stream) hipStreamDestroy(e->pf_stream);
-  for (auto& ev : e->pf_ev) if (ev) hipEventDestroy(ev);
   delete e;
 }
 
@@ -698,17 +663,19 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   e->p_h2 = make_plan(V, P, e->dtype, false, nullptr);
   // ---- scratch arenas
   if ((rc = dalloc(e, &e->emb, (size_t)e->S_max * d))) return rc;
-  if ((rc = dalloc(e, &e->pre_row_seq, (size_t)e->S_max + VC_ROWS))) return rc;
-  if ((rc = dalloc(e, &e->pre_row_pos, (size_t)e->S_max + VC_ROWS))) return rc;
-  if ((rc = dalloc(e, &e->hA, (size_t)VC_ROWS * d))) return rc;
-  if ((rc = dalloc(e, &e->hB, (size_t)VC_ROWS * d))) return rc;
-  if ((rc = dalloc(e, &e->q, (size_t)VC_ROWS * d))) return rc;
-  if ((rc = dalloc(e, &e->parts, (size_t)VC_MAX_KSPLIT * VC_ROWS * d))) return rc;
-  if ((rc = dalloc(e, &e->att_o, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * e->hd))) return rc;
-  if ((rc = dalloc(e, &e->att_ml, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * 2))) return rc;
+  if ((rc = dalloc(e, &e->pre_row_seq, (size_t)e->S_max + VC_MAX_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->pre_row_pos, (size_t)e->S_max + VC_MAX_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->hA, (size_t)VC_MAX_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->hB, (size_t)VC_MAX_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->q, (size_t)VC_MAX_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->parts, (size_t)VC_MAX_KSPLIT * VC_MAX_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->att_o, (size_t)VC_MAX_ROWS * e->H * VC_MAX_NSPLIT * e->hd))) return rc;
+  if ((rc = dalloc(e, &e->att_ml, (size_t)VC_MAX_ROWS * e->H * VC_MAX_NSPLIT * 2))) return rc;
   char* tmp;
-  if ((rc = dalloc(e, &tmp, (size_t)VC_ROWS * 4 * d * e->esz))) return rc;
+  if ((rc = dalloc(e, &tmp, (size_t)VC_MAX_ROWS * 4 * d * e->esz))) return rc;
   e->act = tmp;
+  if ((rc = dalloc(e, &tmp, (size_t)VC_MAX_ROWS * d * e->esz))) return rc;
+  e->xn = tmp;
   if ((rc = dalloc(e, &tmp, (size_t)VC_ROWS * K * P * e->esz))) return rc;
   e->hh = tmp;
   if ((rc = dalloc(e, &e->logits, (size_t)VC_ROWS * K * V))) return rc;
@@ -733,19 +700,12 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
   // a blocking stream: implicitly ordered after work the caller queued on the null stream
   HIPCHK(e, hipStreamCreate(&e->own_stream));
-  HIPCHK(e, hipStreamCreateWithFlags(&e->pf_stream, hipStreamNonBlocking));
-  e->pf_ev.resize(8 * (size_t)(L + 2));
-  for (auto& ev : e->pf_ev) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   {
     const char* nv = getenv("VC_NT");
     e->nt_decode = nv ? atoi(nv) : 1;
-    const char* ov = getenv("VC_OVERLAP");
-    e->overlap = ov ? atoi(ov) : 0;
+    const char* pr = getenv("VC_PREFILL_ROWS");
+    if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));
   }
-  if ((rc = dalloc(e, &e->sync_cnt, (size_t)8 * (L + 2)))) return rc;
-  if ((rc = dalloc(e, &e->sync_err, (size_t)4))) return rc;
-  HIPCHK(e, hipMemset(e->sync_cnt, 0, (size_t)8 * (L + 2) * 4));
-  HIPCHK(e, hipMemset(e->sync_err, 0, 16));
   HIPCHK(e, hipDeviceSynchronize());
   e->finalized = true;
   return VC_OK;
@@ -816,7 +776,6 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   int steps_run = 0;
   rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s);
   if (rc) return rc;
-  if ((rc = check_sync_err(e, s))) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
@@ -967,7 +926,6 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   int steps_run = 0;
   rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, &steps_run, s);
   if (rc) return rc;
-  if ((rc = check_sync_err(e, s))) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
@@ -1009,7 +967,7 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "hA") { src = e->hA; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "hB") { src = e->hB; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "q") { src = e->q; avail = (int64_t)VC_ROWS * e->d * 4; }
-  else if (n == "parts") { src = e->parts; avail = (int64_t)VC_MAX_KSPLIT * VC_ROWS * e->d * 4; }
+  else if (n == "parts") { src = e->parts; avail = (int64_t)VC_MAX_KSPLIT * VC_MAX_ROWS * e->d * 4; }
   else if (n == "emb") { src = e->emb; avail = (int64_t)e->S_max * e->d * 4; }
   else if (n == "dec_h") { src = e->dec_h; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "gen") { src = e->gen; avail = (int64_t)e->B_max * e->gen_cap * e->K * 4; }
@@ -1050,7 +1008,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   HIPCHK(e, hipMemsetAsync(e->dec_h, 0, (size_t)VC_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->hA, 0, (size_t)VC_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->hB, 0, (size_t)VC_ROWS * d * 4, s));
-  HIPCHK(e, hipMemsetAsync(e->parts, 0, (size_t)VC_MAX_KSPLIT * VC_ROWS * d * 4, s));
+  HIPCHK(e, hipMemsetAsync(e->parts, 0, (size_t)VC_MAX_KSPLIT * VC_MAX_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->act, 0, (size_t)VC_ROWS * 4 * d * e->esz, s));
   HIPCHK(e, hipMemsetAsync(e->att_o, 0, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * e->hd * 4, s));
   HIPCHK(e, hipMemsetAsync(e->att_ml, 0, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * 2 * 4, s));
@@ -1082,18 +1040,6 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
-    } else if (w == "pair" || w == "pair_serial") {
-      // two independent weight-streaming kernels (FFN-up of layer i, FFN-down of layer i+1): on two
-      // streams ("pair") or back to back on one ("pair_serial") - does the chip overlap them?
-      GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
-      g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = nullptr; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
-      g.prev_bias = ly.bo; g.has_prev_bias = 1; g.ln_w = ly.ln2w; g.ln_b = ly.ln2b; g.out = e->act; g.out_ld = 4 * d;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
-      Layer& l2 = e->layers[(i + 1) % e->L];
-      GemmArgs g2 = base_args(e, rs, e->p_f2, d, 4 * d);
-      g2.Wp = l2.W2; g2.x_in = e->hh; g2.x_ld = 4 * d; g2.part_out = e->att_o;   // scratch in/out: values are irrelevant
-      hipStream_t s2 = (w == "pair") ? e->pf_stream : s;
-      HIPCHK(e, vc_launch_gemm(g2, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s2));
     } else if (w == "attn") {
       AttnArgs a;
       memset(&a, 0, sizeof a);
@@ -1111,13 +1057,8 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     return VC_OK;
   };
   for (int i = 0; i < 3; ++i) { rc = one(i); if (rc) return rc; }
-  HIPCHK(e, hipStreamSynchronize(e->pf_stream));
   HIPCHK(e, hipEventRecord(e->ev[0], s));
   for (int i = 0; i < iters; ++i) { rc = one(i); if (rc) return rc; }
-  if (w2 == "pair") {   // join the side stream into the timed one
-    HIPCHK(e, hipEventRecord(e->pf_ev[0], e->pf_stream));
-    HIPCHK(e, hipStreamWaitEvent(s, e->pf_ev[0], 0));
-  }
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   HIPCHK(e, hipStreamSynchronize(s));
   float ms = 0;

@@ -80,31 +80,51 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
-// COH = 1: this launch takes part in the overlapped decode chain: it may have been
-// started before its producer finished, so it waits on the producer's completion counter and reads
-// the producer's output with agent-scope (sc1) loads; its own consumer-facing stores are sc1
-// write-through and it bumps its own counter when they have drained.
-template <int COH, typename T>
-__device__ __forceinline__ void store4c(T* p, const f32x4& v) {
-  if constexpr (!COH) { store4(p, v); }
-  else if constexpr (sizeof(T) == 4) {
-    st8_coh(p, make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1])));
-    st8_coh(reinterpret_cast<float*>(p) + 2, make_uint2(__float_as_uint(v[2]), __float_as_uint(v[3])));
-  } else {
-    st8_coh(p, make_uint2((uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16),
-                          (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16)));
-  }
-}
-// one lane polls the producer's counter (bounded: a scheduling assumption gone wrong becomes an error
-// flag, never a hang), then the block proceeds together
-__device__ __forceinline__ void block_wait(const int* cnt, int target, int* err) {
-  if (cnt) {
-    if (threadIdx.x == 0 && !wait_count(cnt, target)) *err = 1;
-    __syncthreads();
+// fused epilogue of one lane: output channels n..n+3 of row mg (mg = global row index of the pass)
+template <typename WT, int EPI>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int mg, int n, int ks, int grp, int ngroups) {
+  if constexpr (EPI == EPI_PART) {
+    if (n < a.N) store4(a.part_out + ((long)(ks * a.rows_cap + mg)) * a.N + n, acc);
+  } else if constexpr (EPI == EPI_QKV) {
+    if (n < a.N) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
+      acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
+      const int d = a.d;
+      if (n < d) {
+        store4(a.q_out + (long)mg * d + n, acc);
+      } else {
+        const int which = (n - d) / d;
+        const int c = (n - d) - which * d;
+        const int h = c / a.hd, e = c - h * a.hd;
+        const int pos = a.row_pos[mg];
+        if (pos >= 0) {
+          WT* base = reinterpret_cast<WT*>(which ? a.vcache : a.kcache) +
+                     (long)a.row_seq[mg] * a.cache_seq_stride + ((long)h * a.S_max + pos) * a.hd + e;
+          store4(base, acc);
+        }
+      }
+    }
+  } else if constexpr (EPI == EPI_RELU || EPI == EPI_GELU) {
+    if (n < a.N) {
+      const float4 b = *reinterpret_cast<const float4*>(a.bias + (long)grp * a.bias_group_stride + n);
+      acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (EPI == EPI_RELU) acc[j] = fmaxf(acc[j], 0.f);
+        else acc[j] = 0.5f * acc[j] * (1.0f + erff(acc[j] * 0.70710678118654752440f));  // nn.GELU() exact erf
+      }
+      store4(reinterpret_cast<WT*>(a.out) + (long)mg * a.out_ld + (long)grp * a.out_group_stride + n, acc);
+    }
+  } else {  // EPI_LOGITS: float [row][group][N], N need not be a multiple of 4
+    float* o = reinterpret_cast<float*>(a.out) + ((long)mg * ngroups + grp) * a.N;
+    const float* b = a.bias + (long)grp * a.bias_group_stride;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (n + j < a.N) o[n + j] = acc[j] + b[n + j];
   }
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int COH>
+template <typename WT, int KTW, int PRO, int EPI>
 __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -166,9 +186,9 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       x0 = *reinterpret_cast<const float4*>(hp_ + c0);                                           \
       x1 = *reinterpret_cast<const float4*>(hp_ + c1);                                           \
       _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_KSPLIT; ++s_) {                             \
-        const float* pp_ = a.parts + ((long)(s_ * VC_ROWS + sr)) * d;                            \
-        p0[s_] = ld_f4<COH>(pp_ + c0);                                                           \
-        p1[s_] = ld_f4<COH>(pp_ + c1);                                                           \
+        const float* pp_ = a.parts + ((long)(s_ * a.rows_cap + sr)) * d;                            \
+        p0[s_] = *reinterpret_cast<const float4*>(pp_ + c0);                                                           \
+        p1[s_] = *reinterpret_cast<const float4*>(pp_ + c1);                                                           \
       }                                                                                          \
     }
 #define VC_FINISH_ROW(r)                                                                         \
@@ -213,14 +233,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
         store4(xr_ + c1, y_);                                                                    \
       }                                                                                          \
     }
-    if constexpr (COH) {          // the row's slabs do not exist yet: request the weights, then wait for the producer
-      VC_ISSUE_WEIGHTS();
-      block_wait(a.wait_cnt, a.wait_target, a.sync_err);
-      VC_LOAD_ROW(0);
-    } else {
-      VC_LOAD_ROW(0);
-      VC_ISSUE_WEIGHTS();
-    }
+    VC_LOAD_ROW(0);
+    VC_ISSUE_WEIGHTS();
     VC_FINISH_ROW(0);
     for (int r = 1; r < n_rows; ++r) {
       VC_LOAD_ROW(r);
@@ -230,13 +244,12 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 #undef VC_FINISH_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
     VC_ISSUE_WEIGHTS();
-    if constexpr (COH) block_wait(a.wait_cnt, a.wait_target, a.sync_err);
     const int upr = kblk * (int)sizeof(WT) / 16;  // 16-byte units per row
     const char* src = reinterpret_cast<const char*>(a.x_in);
     for (int idx = tid; idx < n_rows * upr; idx += 256) {
       const int r = idx / upr, u = idx - r * upr;
       const long off = ((long)r * a.x_ld + (long)grp * a.x_group_stride + k0) * (long)sizeof(WT) + (long)u * 16;
-      *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) = ld_u4<COH>(src + off);
+      *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + off);
     }
   } else {  // PRO_ATT: merge the split-S partials of the decode attention (softmax denominators)
     // item = (row, 4 columns of one head); its 2*VC_MAX_NSPLIT loads are requested before the
@@ -258,8 +271,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       const float* op_ = a.att_o + ((long)(r_ * a.H + h_) * a.nsplit) * a.hd + e_;               \
       _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
         const int se_ = (s_ < a.nsplit) ? s_ : 0;                                                \
-        mls[s_] = ld_f2<COH>(ml_ + se_);                                                         \
-        os[s_] = ld_f4<COH>(op_ + (long)se_ * a.hd);                                             \
+        mls[s_] = ml_[se_];                                                                      \
+        os[s_] = *reinterpret_cast<const float4*>(op_ + (long)se_ * a.hd);                                           \
       }                                                                                          \
     }
 #define VC_FINISH_ITEMS()                                                                        \
@@ -280,14 +293,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       o_[0] *= inv_; o_[1] *= inv_; o_[2] *= inv_; o_[3] *= inv_;                                \
       if (on_) store4(reinterpret_cast<WT*>(xl + (size_t)r_ * xs) + (c_ - k0), o_);              \
     }
-    if constexpr (COH) {
-      VC_ISSUE_WEIGHTS();
-      block_wait(a.wait_cnt, a.wait_target, a.sync_err);
-      VC_LOAD_ITEMS(0);
-    } else {
-      VC_LOAD_ITEMS(0);
-      VC_ISSUE_WEIGHTS();
-    }
+    VC_LOAD_ITEMS(0);
+    VC_ISSUE_WEIGHTS();
     VC_FINISH_ITEMS();
     for (int base = 256; base < n_items; base += 256) {
       VC_LOAD_ITEMS(base);
@@ -333,54 +340,151 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
     }
-    if constexpr (EPI == EPI_PART) {
-      if (n < a.N) store4c<COH>(a.part_out + ((long)(ks * VC_ROWS + m)) * a.N + n, acc);
-    } else if constexpr (EPI == EPI_QKV) {
-      if (n < a.N) {
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
-        acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
-        const int d = a.d;
-        if (n < d) {
-          store4(a.q_out + (long)m * d + n, acc);
-        } else {
-          const int which = (n - d) / d;
-          const int c = (n - d) - which * d;
-          const int h = c / a.hd, e = c - h * a.hd;
-          const int pos = a.row_pos[m];
-          if (pos >= 0) {
-            WT* base = reinterpret_cast<WT*>(which ? a.vcache : a.kcache) +
-                       (long)a.row_seq[m] * a.cache_seq_stride + ((long)h * a.S_max + pos) * a.hd + e;
-            store4(base, acc);
-          }
-        }
-      }
-    } else if constexpr (EPI == EPI_RELU || EPI == EPI_GELU) {
-      if (n < a.N) {
-        const float4 b = *reinterpret_cast<const float4*>(a.bias + (long)grp * a.bias_group_stride + n);
-        acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          if constexpr (EPI == EPI_RELU) acc[j] = fmaxf(acc[j], 0.f);
-          else acc[j] = 0.5f * acc[j] * (1.0f + erff(acc[j] * 0.70710678118654752440f));  // nn.GELU() exact erf
-        }
-        store4c<COH>(reinterpret_cast<WT*>(a.out) + (long)m * a.out_ld + (long)grp * a.out_group_stride + n, acc);
-      }
-    } else {  // EPI_LOGITS: float [row][group][N], N need not be a multiple of 4
-      float* o = reinterpret_cast<float*>(a.out) + ((long)m * gridDim.z + grp) * a.N;
-      const float* b = a.bias + (long)grp * a.bias_group_stride;
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (n + j < a.N) o[n + j] = acc[j] + b[n + j];
-    }
+    gemm_epilogue<WT, EPI>(a, acc, m, n, ks, grp, (int)gridDim.z);
   }
-  // (5) publish: wave 0 made every consumer-facing store of this block (write-through); once they have
-  // drained, one agent-scope increment tells the consumer kernel that this block is done.
-  if constexpr (COH) {
-    if (a.sig_cnt && wave == 0) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      if (lane == 0) __hip_atomic_fetch_add(a.sig_cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+}
+
+// ------------------------------------------------------------------ prefill: up to VC_MAX_ROWS rows per pass
+// Same weight burst, same fragments, but the block walks the pass's rows in tiles of 16 with the weights
+// held in registers, so W is streamed once per 128 rows instead of once per 16.  LayerNorm is hoisted
+// into ln_rows_k (one block per row) - recomputing it in every one of the 384..512 GEMM blocks is only
+// sensible for the 1..16 rows of a decode step.
+template <typename WT, int KTW, int PRO, int EPI>
+__global__ __launch_bounds__(256) void rows_gemm_mt_k(const GemmArgs a) {
+  using T = WTr<WT>;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = blockIdx.x, ks = blockIdx.y, grp = blockIdx.z;
+  const int n_rows = a.n_rows;
+  const int kt_blk = a.nchunk * 4 * KTW;
+  const int kt0 = ks * kt_blk;
+  const int kblk = kt_blk * T::KW;
+  const int k0 = kt0 * T::KW;
+  const int xs = kblk * (int)sizeof(WT) + 16;
+  char* xl = smem;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)VC_ROWS * xs);
+  const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * 64 + lane;
+  uint4 wf[KTW];
+  {
+    const int kt = kt0 + wave * KTW;
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt + i) * 64];
   }
+  const int m = lane & 15;
+  const int n = nt * 16 + 4 * (lane >> 4);
+  for (int row0 = 0; row0 < n_rows; row0 += VC_ROWS) {
+    const int nr = min(VC_ROWS, n_rows - row0);
+    if constexpr (PRO == PRO_PLAIN) {
+      const int upr = kblk * (int)sizeof(WT) / 16;
+      const char* src = reinterpret_cast<const char*>(a.x_in);
+      for (int idx = tid; idx < nr * upr; idx += 256) {
+        const int r = idx / upr, u = idx - r * upr;
+        const long off = ((long)(row0 + r) * a.x_ld + (long)grp * a.x_group_stride + k0) * (long)sizeof(WT) + (long)u * 16;
+        *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + off);
+      }
+    } else {   // PRO_ATT
+      const int q4 = kblk >> 2;
+      for (int idx = tid; idx < nr * q4; idx += 256) {
+        const int r = idx / q4, c = k0 + (idx - r * q4) * 4;
+        const int h = c / a.hd, e = c - h * a.hd;
+        const float2* ml = reinterpret_cast<const float2*>(a.att_ml) + (long)((row0 + r) * a.H + h) * a.nsplit;
+        const float* op = a.att_o + ((long)((row0 + r) * a.H + h) * a.nsplit) * a.hd + e;
+        float M = -INFINITY;
+        for (int sp = 0; sp < a.nsplit; ++sp) M = fmaxf(M, ml[sp].x);
+        float L = 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < a.nsplit; ++sp) {
+          const float2 v = ml[sp];
+          const float w = (v.x == -INFINITY) ? 0.f : expf(v.x - M);
+          const float4 os = *reinterpret_cast<const float4*>(op + (long)sp * a.hd);
+          L += w * v.y;
+          o[0] += w * os.x; o[1] += w * os.y; o[2] += w * os.z; o[3] += w * os.w;
+        }
+        const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+        o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+        store4(reinterpret_cast<WT*>(xl + (size_t)r * xs) + (c - k0), o);
+      }
+    }
+    __syncthreads();
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int mrow = (m < nr) ? m : 0;
+    const char* xrow = xl + (size_t)mrow * xs + (size_t)(lane >> 4) * 16;
+    for (int c = 0; c < a.nchunk; ++c) {
+      if (a.nchunk > 1) {       // several chunks: the registers only ever hold one of them
+        const int kt = kt0 + (c * 4 + wave) * KTW;
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt + i) * 64];
+      }
+      const int ktl = (c * 4 + wave) * KTW;
+#pragma unroll
+      for (int i = 0; i < KTW; ++i) {
+        const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)(ktl + i) * 64);
+        acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);
+      }
+    }
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && m < nr) {
+      const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
+      acc = (acc + a1) + (a2 + a3);
+      gemm_epilogue<WT, EPI>(a, acc, row0 + m, n, ks, grp, (int)gridDim.z);
+    }
+    __syncthreads();            // x and red are rewritten by the next tile
+  }
+}
+
+// h_new = h + prev_bias + sum of split-K slabs ; x = LayerNorm(h_new) as WT.  One block per row.
+template <typename WT>
+__global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
+  __shared__ float s_sum[4], s_sq[4];
+  const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int d = a.d;
+  const int nq = d >> 2;
+  const bool on0 = tid < nq, on1 = tid + 256 < nq;
+  const int c0 = on0 ? tid * 4 : 0, c1 = on1 ? (tid + 256) * 4 : 0;
+  const float* hp = a.h_in + (long)r * d;
+  float4 x0 = *reinterpret_cast<const float4*>(hp + c0), x1 = *reinterpret_cast<const float4*>(hp + c1);
+  if (a.has_prev_bias) {
+    const float4 b0 = *reinterpret_cast<const float4*>(a.prev_bias + c0), b1 = *reinterpret_cast<const float4*>(a.prev_bias + c1);
+    x0.x += b0.x; x0.y += b0.y; x0.z += b0.z; x0.w += b0.w;
+    x1.x += b1.x; x1.y += b1.y; x1.z += b1.z; x1.w += b1.w;
+  }
+  for (int s = 0; s < a.n_parts; ++s) {
+    const float* pp = a.parts + ((long)(s * a.rows_cap + r)) * d;
+    const float4 p0 = *reinterpret_cast<const float4*>(pp + c0), p1 = *reinterpret_cast<const float4*>(pp + c1);
+    x0.x += p0.x; x0.y += p0.y; x0.z += p0.z; x0.w += p0.w;
+    x1.x += p1.x; x1.y += p1.y; x1.z += p1.z; x1.w += p1.w;
+  }
+  const float t0 = on0 ? ((x0.x + x0.y) + (x0.z + x0.w)) : 0.f, t1 = on1 ? ((x1.x + x1.y) + (x1.z + x1.w)) : 0.f;
+  const float ws = wave_sum(t0 + t1);
+  if (lane == 0) s_sum[wave] = ws;
+  __syncthreads();
+  const float mean = ((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) / (float)d;
+  const float dx = x0.x - mean, dy = x0.y - mean, dz = x0.z - mean, dw = x0.w - mean;
+  const float ex = x1.x - mean, ey = x1.y - mean, ez = x1.z - mean, ew = x1.w - mean;
+  const float q0 = on0 ? ((dx * dx + dy * dy) + (dz * dz + dw * dw)) : 0.f, q1 = on1 ? ((ex * ex + ey * ey) + (ez * ez + ew * ew)) : 0.f;
+  const float wq = wave_sum(q0 + q1);
+  if (lane == 0) s_sq[wave] = wq;
+  __syncthreads();
+  const float rstd = 1.0f / sqrtf(((s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3])) / (float)d + 1e-5f);
+  WT* xo = reinterpret_cast<WT*>(a.x_out) + (long)r * d;
+  if (on0) {
+    if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (long)r * d + c0) = x0;
+    const float4 g = *reinterpret_cast<const float4*>(a.ln_w + c0), b = *reinterpret_cast<const float4*>(a.ln_b + c0);
+    f32x4 y = {dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w};
+    store4(xo + c0, y);
+  }
+  if (on1) {
+    if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (long)r * d + c1) = x1;
+    const float4 g = *reinterpret_cast<const float4*>(a.ln_w + c1), b = *reinterpret_cast<const float4*>(a.ln_b + c1);
+    f32x4 y = {ex * rstd * g.x + b.x, ey * rstd * g.y + b.y, ez * rstd * g.z + b.z, ew * rstd * g.w + b.w};
+    store4(xo + c1, y);
+  }
+}
+hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s) {
+  if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(ln_rows_k<bf16_t>, dim3(a.n_rows), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(ln_rows_k<float>, dim3(a.n_rows), dim3(256), 0, s, a);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------ dispatch
@@ -390,9 +494,9 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4);
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int COH>
-static hipError_t launch_coh(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, COH>;
+template <typename WT, int KTW, int PRO, int EPI>
+static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit);
   if (lds > 64 * 1024) {
     static size_t granted = 0;   // per instantiation
@@ -408,9 +512,31 @@ static hipError_t launch_coh(const GemmArgs& a, int dtype, int ksplit, int group
 }
 
 template <typename WT, int KTW, int PRO, int EPI>
+static hipError_t launch_mt(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  if constexpr (PRO == PRO_LN) {
+    return hipErrorInvalidValue;       // multi-tile passes take their LayerNorm from ln_rows_k
+  } else {
+    auto kern = rows_gemm_mt_k<WT, KTW, PRO, EPI>;
+    GemmArgs b = a;
+    b.r_lds = VC_ROWS;
+    const size_t lds = vc_gemm_lds_bytes(b, dtype, ksplit);
+    if (lds > 64 * 1024) {
+      static size_t granted = 0;
+      if (lds > granted) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        granted = lds;
+      }
+    }
+    hipLaunchKernelGGL(kern, dim3(a.n_tiles, ksplit, groups), dim3(256), lds, s, b);
+    return hipGetLastError();
+  }
+}
+
+template <typename WT, int KTW, int PRO, int EPI>
 static hipError_t launch_one(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  if (a.wait_cnt || a.sig_cnt) return launch_coh<WT, KTW, PRO, EPI, 1>(a, dtype, ksplit, groups, s);
-  return launch_coh<WT, KTW, PRO, EPI, 0>(a, dtype, ksplit, groups, s);
+  if (a.mt) return launch_mt<WT, KTW, PRO, EPI>(a, dtype, ksplit, groups, s);
+  return launch_dec<WT, KTW, PRO, EPI>(a, dtype, ksplit, groups, s);
 }
 
 template <typename WT, int KTW>
@@ -422,6 +548,8 @@ static hipError_t launch_ktw(const GemmArgs& a, int dtype, int pro, int epi, int
   if (pro == PRO_ATT && epi == EPI_PART) return launch_one<WT, KTW, PRO_ATT, EPI_PART>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_PART) return launch_one<WT, KTW, PRO_PLAIN, EPI_PART>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_LOGITS) return launch_one<WT, KTW, PRO_PLAIN, EPI_LOGITS>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_PLAIN && epi == EPI_QKV) return launch_one<WT, KTW, PRO_PLAIN, EPI_QKV>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_PLAIN && epi == EPI_RELU) return launch_one<WT, KTW, PRO_PLAIN, EPI_RELU>(a, dtype, ksplit, groups, s);
   return hipErrorInvalidValue;
 }
 
