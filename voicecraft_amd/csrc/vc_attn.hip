@@ -6,7 +6,7 @@
 // (SURVEY.md §0), so a row at cache position p simply attends to positions 0..p of its sequence; no
 // mask tensor exists here.  K/V of the row itself were written by the QKV epilogue of the same pass.
 //
-// grid = (rows, heads, nsplit): split-S so that one decode row still covers the chip; every block
+// grid = (rows, heads, nsplit <= 8), 8 waves per block: split-S so that one decode row still covers the chip; every block
 // leaves an un-normalised (max, sum, acc[hd]) partial that the out-projection's prologue merges.
 // A cached row (hd elements) is spread over LPR = hd*sizeof/16 lanes with 16-byte loads, so a wave
 // reads 64/LPR consecutive positions = one contiguous 1 KiB burst per K (and V) instruction.
@@ -27,53 +27,67 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
   f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 
+#define VC_ATT_WAVES 8
 template <typename WT>
-__global__ __launch_bounds__(256) void rows_attn_k(const AttnArgs a) {
+__global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;
-  __shared__ float s_m[4], s_l[4];
-  __shared__ float s_o[4][128];
-  if (a.n_active && *a.n_active == 0) return;
-  const int r = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;
-  const int n_rows = a.n_rows_ptr ? *a.n_rows_ptr : a.n_rows;
-  if (r >= n_rows) return;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = VC_ATT_WAVES;
+  __shared__ float s_m[NW], s_l[NW];
+  __shared__ float s_o[NW][128];
+  const int r = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;     // grid.x == n_rows
+  // one scalar round trip for everything the addresses depend on (no early exit in between: a
+  // branch would let the compiler serialise these three loads)
+  const int active = *a.n_active;
+  const int pos = a.row_pos[r];
+  const int seq = a.row_seq[r];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hd = a.hd;
   const int LPR = hd / EPL;            // lanes per cached row: 8, 16 or 32
   const int PPW = 64 / LPR;            // positions per wave per step
   const int sub = lane / LPR, li = lane - sub * LPR;
-  const int pos = a.row_pos[r];
 
   float m = -INFINITY, l = 0.f;
   float o[EPL];
 #pragma unroll
   for (int j = 0; j < EPL; ++j) o[j] = 0.f;
 
-  if (pos >= 0) {
+  if (active != 0 && pos >= 0 && seq >= 0) {   // a finished step / an inactive row leaves an empty partial (seq is
+                                               // tested only so that its load is not sunk behind the branch)
     const int S = pos + 1;
     const int chunk = (S + a.nsplit - 1) / a.nsplit;
     const int p0 = sp * chunk;
     const int p1 = min(S, p0 + chunk);
-    float q[EPL];
+    const int step = 4 * NW * PPW;
+    // q, then K and V of the first 4 visits per wave, are requested together (clamped,
+    // unconditional); q is only touched once all of them are on their way.
+    float4 qv[EPL / 4];
     {
-      const float* qp = a.q + (long)r * a.d + h * hd + li * EPL;
+      const float4* qp = reinterpret_cast<const float4*>(a.q + (long)r * a.d + h * hd + li * EPL);
 #pragma unroll
-      for (int j = 0; j < EPL; ++j) q[j] = qp[j] * a.scale;
+      for (int j = 0; j < EPL / 4; ++j) qv[j] = qp[j];
     }
-    const long base = (long)a.row_seq[r] * a.cache_seq_stride + (long)h * a.S_max * hd + li * EPL;
+    const long base = (long)seq * a.cache_seq_stride + (long)h * a.S_max * hd + li * EPL;
     const WT* kb = reinterpret_cast<const WT*>(a.kcache) + base;
     const WT* vb = reinterpret_cast<const WT*>(a.vcache) + base;
-    // 4 visits per wave are requested at once (clamped, unconditional) so that K and V of up to
-    // 16*PPW positions are in flight together; the online-softmax update then runs on registers.
-    for (int pb = p0; pb < p1; pb += 16 * PPW) {
-      uint4 ku[4], vu[4];
-      int pp[4];
+    uint4 ku[4], vu[4];
+    int pp[4];
+#define VC_KV_LOADS(pb_)                                                     \
+    _Pragma("unroll") for (int it = 0; it < 4; ++it) {                       \
+      pp[it] = (pb_) + (it * NW + wave) * PPW + sub;                         \
+      const long pc = max(min(pp[it], p1 - 1), 0);                           \
+      ku[it] = *reinterpret_cast<const uint4*>(kb + pc * hd);                \
+      vu[it] = *reinterpret_cast<const uint4*>(vb + pc * hd);                \
+    }
+    VC_KV_LOADS(p0);
+    __builtin_amdgcn_sched_barrier(0);
+    float q[EPL];
 #pragma unroll
-      for (int it = 0; it < 4; ++it) {
-        pp[it] = pb + (it * 4 + wave) * PPW + sub;
-        const long pc = min(pp[it], p1 - 1);
-        ku[it] = *reinterpret_cast<const uint4*>(kb + pc * hd);
-        vu[it] = *reinterpret_cast<const uint4*>(vb + pc * hd);
-      }
+    for (int j = 0; j < EPL / 4; ++j) {
+      q[4 * j] = qv[j].x * a.scale; q[4 * j + 1] = qv[j].y * a.scale;
+      q[4 * j + 2] = qv[j].z * a.scale; q[4 * j + 3] = qv[j].w * a.scale;
+    }
+    for (int pb = p0;;) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         float kf[EPL], vf[EPL];
@@ -94,7 +108,11 @@ __global__ __launch_bounds__(256) void rows_attn_k(const AttnArgs a) {
           m = mn;
         }
       }
+      pb += step;
+      if (pb >= p1) break;
+      VC_KV_LOADS(pb);
     }
+#undef VC_KV_LOADS
   }
   // merge the PPW position groups of this wave (same li, different sub)
   for (int off = LPR; off < 64; off <<= 1) {
@@ -118,10 +136,12 @@ __global__ __launch_bounds__(256) void rows_attn_k(const AttnArgs a) {
   }
   __syncthreads();
   if (tid < hd) {
-    const float M = fmaxf(fmaxf(s_m[0], s_m[1]), fmaxf(s_m[2], s_m[3]));
+    float M = s_m[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) M = fmaxf(M, s_m[w]);
     float L = 0.f, O = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < NW; ++w) {
       const float c = (s_m[w] == -INFINITY) ? 0.f : expf(s_m[w] - M);
       L += c * s_l[w];
       O += c * s_o[w][tid];
@@ -134,8 +154,8 @@ __global__ __launch_bounds__(256) void rows_attn_k(const AttnArgs a) {
 
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s) {
   dim3 grid(rows_cap, a.H, a.nsplit);
-  if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(rows_attn_k<bf16_t>, grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(rows_attn_k<float>, grid, dim3(256), 0, s, a);
+  if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(rows_attn_k<bf16_t>, grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
+  else hipLaunchKernelGGL(rows_attn_k<float>, grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
   return hipGetLastError();
 }
 

@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define VC_ROWS 16          // rows (token positions) of one MFMA tile = the N dimension of the rows-GEMM
 #define VC_MAX_ROWS 128     // rows one forward pass may carry (prefill: 8 row tiles per weight burst)
-#define VC_MAX_NSPLIT 16    // split-S factor cap of the decode attention
+#define VC_MAX_NSPLIT 8     // split-S factor cap of the decode attention (the out-projection prologue loads this many partials)
 #define VC_MAX_KSPLIT 4     // cross-block split-K cap of the rows-GEMM (the LN prologue prefetches this many slabs)
 #define VC_MAX_SEG 32       // prompt segments (2*spans+1 pieces + placeholders)
 #define VC_VPL 34           // logits per lane in the sampler: V <= 64*34
@@ -168,9 +168,8 @@ struct GemmArgs {
   // rows
   const int* row_seq;
   const int* row_pos;
-  const int* n_rows_ptr;
   int n_rows;
-  const int* n_active;      // early exit when *n_active == 0 (null = never)
+  const int* n_active;      // never null: the launch is a no-op when *n_active == 0
   // prologue LN:   hn = h_in[src] + prev_bias + sum_s parts[s][r]; X = LN(hn) ; h_out[r] = hn
   const float* h_in;
   float* h_out;
@@ -186,6 +185,7 @@ struct GemmArgs {
   const void* x_in;
   int x_ld;
   int x_group_stride;
+  int x_upr_shift;          // log2 of the 16-byte units per X row slice when that is a power of two, else -1 (set by the launcher)
   // prologue ATT: X = combine of attention split partials
   const float* att_o;       // [VC_ROWS][H][nsplit][hd]
   const float* att_ml;      // [VC_ROWS][H][nsplit][2]
@@ -212,9 +212,8 @@ struct AttnArgs {
   float scale;
   const int* row_seq;
   const int* row_pos;
-  const int* n_rows_ptr;
   int n_rows;
-  const int* n_active;
+  const int* n_active;      // never null
   float* att_o;
   float* att_ml;
 };

@@ -69,6 +69,7 @@ struct vc_engine {
   int *dec_row_seq = nullptr, *dec_row_pos = nullptr, *logit_row = nullptr;
   SeqState *st = nullptr;
   long long* dbg_ts = nullptr;
+  int *one = nullptr;                   // device word holding 1: the "always active" flag of prefill launches
   int *n_active = nullptr, *samp = nullptr, *cond = nullptr, *amax = nullptr, *gen = nullptr, *err_flag = nullptr;
   int gen_cap = 0;
   // pinned host staging
@@ -186,8 +187,7 @@ struct RowSrc {
   const float* h_in;
   const int* row_seq;
   const int* row_pos;
-  const int* n_rows_ptr;
-  int n_rows;       // rows carried (upper bound when n_rows_ptr is set)
+  int n_rows;       // rows carried
   int nsplit;
   const int* n_active;
   int nt;           // force the streaming-load policy (microbenchmarks)
@@ -199,8 +199,8 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.N = N; g.K = Kdim; g.n_tiles = p.n_tiles; g.KT = p.KT; g.nchunk = p.nchunk;
   g.r_lds = std::min(rs.n_rows, VC_ROWS);
   g.rows_cap = VC_MAX_ROWS;
-  g.row_seq = rs.row_seq; g.row_pos = rs.row_pos; g.n_rows_ptr = rs.n_rows_ptr; g.n_rows = rs.n_rows;
-  g.n_active = rs.n_active;
+  g.row_seq = rs.row_seq; g.row_pos = rs.row_pos; g.n_rows = rs.n_rows;
+  g.n_active = rs.n_active ? rs.n_active : e->one;
   g.nt = (rs.n_active != nullptr || rs.nt) ? e->nt_decode : 0;   // decode steps (and the kernel microbenchmarks) stream once
   g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
@@ -232,8 +232,8 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit;
       a.scale = 1.0f / sqrtf((float)e->hd);
-      a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows_ptr = rs.n_rows_ptr; a.n_rows = rs.n_rows;
-      a.n_active = rs.n_active;
+      a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
+      a.n_active = rs.n_active ? rs.n_active : e->one;
       a.att_o = e->att_o; a.att_ml = e->att_ml;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -267,6 +267,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
 // final LayerNorm + the K prediction heads (voicecraft.py:181-185, :1084-1086) for n rows;
 // row r reads hidden row gather[r] and writes logits row (out_row0 + r).
 int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s) {
+  if (gather && n > 1) return fail(e, VC_EINVAL, "internal: a gathered head pass carries one row");
   RowSrc rs{};
   rs.n_rows = n; rs.n_active = n_active;
   {  //                                                                   
@@ -312,6 +313,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
+      a.n_active = e->one;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {
@@ -337,7 +339,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
 }
 
 int attn_nsplit(vc_engine* e, int rows) {
-  int ns = 512 / std::max(1, rows * e->H);
+  int ns = 256 / std::max(1, rows * e->H);   // 8-wave blocks: ~256 of them cover the chip
   return std::max(1, std::min(ns, VC_MAX_NSPLIT));
 }
 
@@ -396,7 +398,8 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   rs.n_rows = B * rps; rs.nsplit = attn_nsplit(e, B * rps); rs.n_active = e->n_active;
   int rc;
   if ((rc = forward_rows(e, rs, s))) return rc;
-  if ((rc = run_heads(e, e->logit_row, B, 0, e->n_active, s))) return rc;
+  // rps == 1: logit_row[b] == b (vc_tokens.hip advance_phase); the 3-row span switch is single-sequence
+  if ((rc = run_heads(e, rps == 1 ? nullptr : e->logit_row, B, 0, e->n_active, s))) return rc;
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
   return VC_OK;
 }
@@ -686,6 +689,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->st, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
+  if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->amax, (size_t)VC_ROWS))) return rc;
@@ -695,6 +699,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->gen, (size_t)e->B_max * e->gen_cap * K))) return rc;
   HIPCHK(e, hipMemset(e->err_flag, 0, 16));
   HIPCHK(e, hipMemset(e->n_active, 0, 16));
+  { const int one[4] = {1, 1, 1, 1}; HIPCHK(e, hipMemcpy(e->one, one, 16, hipMemcpyHostToDevice)); }
   HIPCHK(e, hipHostMalloc((void**)&e->h_st, sizeof(SeqState) * VC_ROWS));
   HIPCHK(e, hipHostMalloc((void**)&e->h_flag, 64));
   for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
@@ -1003,6 +1008,8 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   // neutral rows: sequence 0, positions 0..n_rows-1 (position only matters to attention/caches)
   std::vector<int> seq(VC_ROWS, 0), pos(VC_ROWS, 0);
   for (int i = 0; i < VC_ROWS; ++i) pos[i] = i;
+  if (std::string(which).rfind("attn", 0) == 0)          // attention: a 16 s utterance's worth of cached positions
+    for (int i = 0; i < VC_ROWS; ++i) pos[i] = std::min(e->S_max - 1, 883);
   HIPCHK(e, hipMemcpyAsync(e->dec_row_seq, seq.data(), VC_ROWS * 4, hipMemcpyHostToDevice, s));
   HIPCHK(e, hipMemcpyAsync(e->dec_row_pos, pos.data(), VC_ROWS * 4, hipMemcpyHostToDevice, s));
   HIPCHK(e, hipMemsetAsync(e->dec_h, 0, (size_t)VC_ROWS * d * 4, s));
@@ -1046,11 +1053,12 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
+      a.n_active = e->one;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);
       if (r) return r;
-      return run_heads(e, e->logit_row, n_rows, 0, nullptr, s);
+      return run_heads(e, nullptr, n_rows, 0, nullptr, s);
     } else {
       return fail(e, VC_EINVAL, "unknown kernel '%s'", which);
     }
@@ -1072,6 +1080,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     else if (w == "ffn2") b = 4.0 * d * d * es + n_rows * (4.0 * d * es + d * 4.0);
     else if (w == "qkv") b = 3.0 * d * d * es + n_rows * (d * 4.0 + 3.0 * d * es);
     else if (w == "oproj") b = 1.0 * d * d * es + n_rows * (d * 4.0 * 2);
+    else if (w == "attn") b = n_rows * 2.0 * d * es * (std::min(e->S_max - 1, 883) + 1);   // K and V of every cached position
     else b = (double)e->L * (12.0 * d * d + 13.0 * d) * es + 2.0 * d * es +
              (double)e->K * ((double)d * e->P + e->P + (double)e->P * e->V + e->V) * es;
     *alg_bytes = b;

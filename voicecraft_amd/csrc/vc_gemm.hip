@@ -80,14 +80,36 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
+// Operands of the fused epilogue that live in HBM (bias, the row's cache slot).  Requested by every
+// lane at the very top of the kernel - a dependent load at the END of a 10 us kernel is a full
+// round trip on the critical path.  mg < n_rows (host contract), n is clamped here.
+template <typename WT, int EPI>
+__device__ __forceinline__ void epi_preload(const GemmArgs& a, int mg, int n, int grp, float4& b, int& pos, int& seq) {
+  b = make_float4(0.f, 0.f, 0.f, 0.f);
+  pos = -1;
+  seq = 0;
+  const int nc = (n < a.N) ? n : 0;
+  if constexpr (EPI == EPI_QKV) {
+    b = *reinterpret_cast<const float4*>(a.bias + nc);
+    pos = a.row_pos[mg];
+    seq = a.row_seq[mg];
+  } else if constexpr (EPI == EPI_RELU || EPI == EPI_GELU) {
+    b = *reinterpret_cast<const float4*>(a.bias + (long)grp * a.bias_group_stride + nc);
+  } else if constexpr (EPI == EPI_LOGITS) {   // N need not be a multiple of 4
+    const float* bp = a.bias + (long)grp * a.bias_group_stride;
+    const int last = a.N - 1;
+    b.x = bp[min(n, last)]; b.y = bp[min(n + 1, last)]; b.z = bp[min(n + 2, last)]; b.w = bp[min(n + 3, last)];
+  }
+}
+
 // fused epilogue of one lane: output channels n..n+3 of row mg (mg = global row index of the pass)
 template <typename WT, int EPI>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int mg, int n, int ks, int grp, int ngroups) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int mg, int n, int ks, int grp, int ngroups,
+                                              const float4& b, int pos, int seq) {
   if constexpr (EPI == EPI_PART) {
     if (n < a.N) store4(a.part_out + ((long)(ks * a.rows_cap + mg)) * a.N + n, acc);
   } else if constexpr (EPI == EPI_QKV) {
     if (n < a.N) {
-      const float4 b = *reinterpret_cast<const float4*>(a.bias + n);
       acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
       const int d = a.d;
       if (n < d) {
@@ -96,17 +118,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int 
         const int which = (n - d) / d;
         const int c = (n - d) - which * d;
         const int h = c / a.hd, e = c - h * a.hd;
-        const int pos = a.row_pos[mg];
         if (pos >= 0) {
           WT* base = reinterpret_cast<WT*>(which ? a.vcache : a.kcache) +
-                     (long)a.row_seq[mg] * a.cache_seq_stride + ((long)h * a.S_max + pos) * a.hd + e;
+                     (long)seq * a.cache_seq_stride + ((long)h * a.S_max + pos) * a.hd + e;
           store4(base, acc);
         }
       }
     }
   } else if constexpr (EPI == EPI_RELU || EPI == EPI_GELU) {
     if (n < a.N) {
-      const float4 b = *reinterpret_cast<const float4*>(a.bias + (long)grp * a.bias_group_stride + n);
       acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -115,24 +135,31 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int 
       }
       store4(reinterpret_cast<WT*>(a.out) + (long)mg * a.out_ld + (long)grp * a.out_group_stride + n, acc);
     }
-  } else {  // EPI_LOGITS: float [row][group][N], N need not be a multiple of 4
+  } else {  // EPI_LOGITS: float [row][group][N]
     float* o = reinterpret_cast<float*>(a.out) + ((long)mg * ngroups + grp) * a.N;
-    const float* b = a.bias + (long)grp * a.bias_group_stride;
+    const float bb[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      if (n + j < a.N) o[n + j] = acc[j] + b[n + j];
+      if (n + j < a.N) o[n + j] = acc[j] + bb[j];
   }
 }
 
+// Decode-step kernel.  The dependency chain of a launch is what the ~80 launches of a step pay for, so
+// the kernel is written around it: (1) everything any later stage needs from HBM - epilogue operands,
+// the first row's prologue operands, the "any sequence still active" word - is requested first, in the
+// order it will be consumed (a wave's loads return in order); (2) the weight burst follows immediately
+// behind from a wave-uniform base (SGPR addressing: no per-load VALU address arithmetic, no register
+// reuse that would make the compiler wait mid-burst); (3) a scheduling barrier keeps the prologue
+// arithmetic from being hoisted into the burst; (4) only then is anything waited for.
 template <typename WT, int KTW, int PRO, int EPI>
 __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (a.n_active && *a.n_active == 0) return;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x, ks = blockIdx.y, grp = blockIdx.z;
-  const int n_rows = a.n_rows_ptr ? *a.n_rows_ptr : a.n_rows;
+  const int n_rows = a.n_rows;                    // >= 1 (host contract)
   const int kt_blk = a.nchunk * 4 * KTW;          // k-tiles this block covers
   const int kt0 = ks * kt_blk;                    // first of them
   const int kblk = kt_blk * T::KW;                // K elements this block covers
@@ -141,31 +168,37 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   char* xl = smem;
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
 
-  const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * 64 + lane;
-  uint4 wf[KTW];
-  // Issue order matters: a wave's loads return in order, so anything the prologue needs is
-  // requested BEFORE the weight burst and consumed behind a counted vmcnt while the weights
-  // (which do not depend on X) are still streaming.
-  // a.nt: non-temporal loads for a weight stream that is read exactly once per launch (decode);
-  // prefill re-reads the same weights for every 16-row group and wants them cached.
-#define VC_ISSUE_WEIGHTS()                                              \
-  {                                                                     \
-    const int kt_ = kt0 + wave * KTW;                                   \
-    if (a.nt) {                                                         \
-      _Pragma("unroll") for (int i = 0; i < KTW; ++i)                   \
-        wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (long)(kt_ + i) * 64))); \
-    } else {                                                            \
-      _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt_ + i) * 64]; \
-    }                                                                   \
-  }
+  const int active = *a.n_active;                 // scalar; looked at once the burst is on its way
+  const int m = lane & 15;
+  const int n = nt * 16 + 4 * (lane >> 4);
+  float4 eb;
+  int epos, eseq;
+  epi_preload<WT, EPI>(a, (m < n_rows) ? m : 0, n, grp, eb, epos, eseq);
 
-  // (2) prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.  n_rows >= 1 (host contract).
-  // Every prologue load is unconditional and branch-free (out-of-range lanes re-read column 0,
-  // unused split slabs are read and discarded by a select): a load inside a branch makes the
-  // compiler drain the whole queue (vmcnt(0)) and the weight burst with it.
+  const uint4* wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * 64;   // wave-uniform
+  uint4 wf[KTW];
+  // a.nt: non-temporal loads for a weight stream that is read exactly once per launch (decode)
+#define VC_ISSUE_WEIGHTS(c_)                                                                     \
+  {                                                                                              \
+    const uint4* wb_ = wbase + (long)(c_) * (4 * KTW * 64);                                       \
+    if (a.nt) {                                                                                  \
+      _Pragma("unroll") for (int i = 0; i < KTW; ++i)                                            \
+        wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb_ + i * 64 + lane))); \
+    } else {                                                                                     \
+      _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wb_[i * 64 + lane];                \
+    }                                                                                            \
+  }
+#define VC_BURST_OUT()                                                                           \
+  __builtin_amdgcn_sched_barrier(0);                                                             \
+  if (active == 0) return;   /* every sequence finished: the replayed step is a no-op */
+
+  // prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.  Every load is unconditional and
+  // branch-free (out-of-range lanes re-read a valid address, unused split slabs are read and discarded
+  // by a select): a load inside a branch makes the compiler drain the whole queue (vmcnt(0)).
   if constexpr (PRO == PRO_LN) {
-    // LayerNorm of hn = h + prev_bias + sum(parts) (eps 1e-5, transformer.py:30), two-pass, the
-    // whole block on one row at a time: thread t owns float4 columns t and t+256.
+    // LayerNorm of hn = h + prev_bias + sum(parts) (eps 1e-5, transformer.py:30), two-pass, the whole
+    // block on one row at a time: thread t owns float4 columns t and t+256.  Rows beyond the first are
+    // software-pipelined through two register sets (the next row's loads fly during this row's math).
     float* s_sum = reinterpret_cast<float*>(red);        // [4] wave partials (the reduce area is free until step 4)
     float* s_sq = s_sum + 4;
     const int d = a.d;
@@ -176,31 +209,32 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + c0), b1 = *reinterpret_cast<const float4*>(a.ln_b + c1);
     const float4 pb0 = *reinterpret_cast<const float4*>(a.prev_bias + c0), pb1 = *reinterpret_cast<const float4*>(a.prev_bias + c1);
     const bool use_pb = a.has_prev_bias != 0;
-    float4 x0, x1, p0[VC_MAX_KSPLIT], p1[VC_MAX_KSPLIT];
-    int sr;
-#define VC_LOAD_ROW(r)                                                                          \
+    float4 x0A, x1A, p0A[VC_MAX_KSPLIT], p1A[VC_MAX_KSPLIT];
+    float4 x0B, x1B, p0B[VC_MAX_KSPLIT], p1B[VC_MAX_KSPLIT];
+#define VC_LOAD_ROW(S, r, G)   /* G: honour a.gather_rows (single-row launches only, host contract) */ \
     {                                                                                            \
-      sr = (r);                                                                                  \
-      if (a.gather_rows) sr = a.gather_rows[(r)];                                                \
-      const float* hp_ = a.h_in + (long)sr * d;                                                  \
-      x0 = *reinterpret_cast<const float4*>(hp_ + c0);                                           \
-      x1 = *reinterpret_cast<const float4*>(hp_ + c1);                                           \
+      int sr_ = (r);                                                                             \
+      if (G && a.gather_rows) sr_ = a.gather_rows[sr_];                                          \
+      const float* hp_ = a.h_in + (long)sr_ * d;                                                 \
+      x0##S = *reinterpret_cast<const float4*>(hp_ + c0);                                        \
+      x1##S = *reinterpret_cast<const float4*>(hp_ + c1);                                        \
       _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_KSPLIT; ++s_) {                             \
-        const float* pp_ = a.parts + ((long)(s_ * a.rows_cap + sr)) * d;                            \
-        p0[s_] = *reinterpret_cast<const float4*>(pp_ + c0);                                                           \
-        p1[s_] = *reinterpret_cast<const float4*>(pp_ + c1);                                                           \
+        const float* pp_ = a.parts + ((long)(s_ * a.rows_cap + sr_)) * d;                        \
+        p0##S[s_] = *reinterpret_cast<const float4*>(pp_ + c0);                                  \
+        p1##S[s_] = *reinterpret_cast<const float4*>(pp_ + c1);                                  \
       }                                                                                          \
     }
-#define VC_FINISH_ROW(r)                                                                         \
+#define VC_FINISH_ROW(S, r)                                                                      \
     {                                                                                            \
+      float4 x0 = x0##S, x1 = x1##S;                                                             \
       if (use_pb) {                                                                              \
         x0.x += pb0.x; x0.y += pb0.y; x0.z += pb0.z; x0.w += pb0.w;                              \
         x1.x += pb1.x; x1.y += pb1.y; x1.z += pb1.z; x1.w += pb1.w;                              \
       }                                                                                          \
       _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_KSPLIT; ++s_) {                             \
         const bool u_ = s_ < a.n_parts;                                                          \
-        x0.x += u_ ? p0[s_].x : 0.f; x0.y += u_ ? p0[s_].y : 0.f; x0.z += u_ ? p0[s_].z : 0.f; x0.w += u_ ? p0[s_].w : 0.f; \
-        x1.x += u_ ? p1[s_].x : 0.f; x1.y += u_ ? p1[s_].y : 0.f; x1.z += u_ ? p1[s_].z : 0.f; x1.w += u_ ? p1[s_].w : 0.f; \
+        x0.x += u_ ? p0##S[s_].x : 0.f; x0.y += u_ ? p0##S[s_].y : 0.f; x0.z += u_ ? p0##S[s_].z : 0.f; x0.w += u_ ? p0##S[s_].w : 0.f; \
+        x1.x += u_ ? p1##S[s_].x : 0.f; x1.y += u_ ? p1##S[s_].y : 0.f; x1.z += u_ ? p1##S[s_].z : 0.f; x1.w += u_ ? p1##S[s_].w : 0.f; \
       }                                                                                          \
       const float t0_ = on0 ? ((x0.x + x0.y) + (x0.z + x0.w)) : 0.f;                             \
       const float t1_ = on1 ? ((x1.x + x1.y) + (x1.z + x1.w)) : 0.f;                             \
@@ -233,82 +267,130 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
         store4(xr_ + c1, y_);                                                                    \
       }                                                                                          \
     }
-    VC_LOAD_ROW(0);
-    VC_ISSUE_WEIGHTS();
-    VC_FINISH_ROW(0);
-    for (int r = 1; r < n_rows; ++r) {
-      VC_LOAD_ROW(r);
-      VC_FINISH_ROW(r);
+    VC_LOAD_ROW(A, 0, 1);
+    VC_ISSUE_WEIGHTS(0);
+    VC_BURST_OUT();
+    if (n_rows == 1) {
+      VC_FINISH_ROW(A, 0);
+    } else {
+      int r = 0;
+      for (;;) {
+        VC_LOAD_ROW(B, min(r + 1, n_rows - 1), 0);
+        VC_FINISH_ROW(A, r);
+        if (++r >= n_rows) break;
+        VC_LOAD_ROW(A, min(r + 1, n_rows - 1), 0);
+        VC_FINISH_ROW(B, r);
+        if (++r >= n_rows) break;
+      }
     }
 #undef VC_LOAD_ROW
 #undef VC_FINISH_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
-    VC_ISSUE_WEIGHTS();
-    const int upr = kblk * (int)sizeof(WT) / 16;  // 16-byte units per row
-    const char* src = reinterpret_cast<const char*>(a.x_in);
-    for (int idx = tid; idx < n_rows * upr; idx += 256) {
-      const int r = idx / upr, u = idx - r * upr;
-      const long off = ((long)r * a.x_ld + (long)grp * a.x_group_stride + k0) * (long)sizeof(WT) + (long)u * 16;
-      *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) = *reinterpret_cast<const uint4*>(src + off);
-    }
-  } else {  // PRO_ATT: merge the split-S partials of the decode attention (softmax denominators)
-    // item = (row, 4 columns of one head); its 2*VC_MAX_NSPLIT loads are requested before the
-    // weight burst, the exp/scale arithmetic runs behind it.
-    const int q4 = kblk >> 2;
-    const int n_items = n_rows * q4;
-    float2 mls[VC_MAX_NSPLIT];
-    float4 os[VC_MAX_NSPLIT];
-    int r_, c_;
-    bool on_;
-#define VC_LOAD_ITEMS(base)                                                                      \
+    // X rows copied as 16-byte units, flat index = row * upr + unit.  The first XB*256 units are
+    // requested ahead of the weight burst (clamped, unconditional), the rest (many rows) behind it.
+    constexpr int XB = 4;
+    const int upr = kblk * (int)sizeof(WT) / 16;   // 16-byte units per row
+    const int total = n_rows * upr;
+    const char* src = reinterpret_cast<const char*>(a.x_in) + ((long)grp * a.x_group_stride + k0) * (long)sizeof(WT);
+    const long rstride = (long)a.x_ld * (long)sizeof(WT);
+    const int sh = a.x_upr_shift;                  // log2(upr) when upr is a power of two, else -1
+#define VC_X_SPLIT(idx_, r_, u_)                                                                 \
+    const int r_ = (sh >= 0) ? ((idx_) >> sh) : ((idx_) / upr);                                  \
+    const int u_ = (idx_) - r_ * upr;
+    uint4 xv0, xv1, xv2, xv3;
+#define VC_X_LOAD(j, dst)                                                                        \
     {                                                                                            \
-      const int idx_ = (base) + tid;                                                             \
-      on_ = idx_ < n_items;                                                                      \
-      r_ = on_ ? idx_ / q4 : 0;                                                                  \
-      c_ = k0 + (on_ ? (idx_ - r_ * q4) : 0) * 4;                                                \
-      const int h_ = c_ / a.hd, e_ = c_ - h_ * a.hd;                                             \
-      const float2* ml_ = reinterpret_cast<const float2*>(a.att_ml) + (long)(r_ * a.H + h_) * a.nsplit; \
-      const float* op_ = a.att_o + ((long)(r_ * a.H + h_) * a.nsplit) * a.hd + e_;               \
-      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
-        const int se_ = (s_ < a.nsplit) ? s_ : 0;                                                \
-        mls[s_] = ml_[se_];                                                                      \
-        os[s_] = *reinterpret_cast<const float4*>(op_ + (long)se_ * a.hd);                                           \
+      const int i_ = min((j) * 256 + tid, total - 1);                                            \
+      VC_X_SPLIT(i_, rr_, uu_)                                                                   \
+      dst = *reinterpret_cast<const uint4*>(src + (long)rr_ * rstride + (long)uu_ * 16);         \
+    }
+#define VC_X_STORE(j, val)                                                                       \
+    {                                                                                            \
+      const int i_ = (j) * 256 + tid;                                                            \
+      if (i_ < total) {                                                                          \
+        VC_X_SPLIT(i_, rr_, uu_)                                                                 \
+        *reinterpret_cast<uint4*>(xl + (size_t)rr_ * xs + (size_t)uu_ * 16) = val;               \
       }                                                                                          \
     }
-#define VC_FINISH_ITEMS()                                                                        \
+    VC_X_LOAD(0, xv0); VC_X_LOAD(1, xv1); VC_X_LOAD(2, xv2); VC_X_LOAD(3, xv3);
+    VC_ISSUE_WEIGHTS(0);
+    VC_BURST_OUT();
+    VC_X_STORE(0, xv0); VC_X_STORE(1, xv1); VC_X_STORE(2, xv2); VC_X_STORE(3, xv3);
+    for (int i_ = XB * 256 + tid; i_ < total; i_ += 256) {
+      VC_X_SPLIT(i_, rr_, uu_)
+      *reinterpret_cast<uint4*>(xl + (size_t)rr_ * xs + (size_t)uu_ * 16) =
+          *reinterpret_cast<const uint4*>(src + (long)rr_ * rstride + (long)uu_ * 16);
+    }
+#undef VC_X_LOAD
+#undef VC_X_STORE
+#undef VC_X_SPLIT
+  } else {  // PRO_ATT: merge the split-S partials of the decode attention (softmax denominators)
+    // item = (row, 4 columns of one head); its 2*VC_MAX_NSPLIT loads are requested before the
+    // weight burst, the exp/scale arithmetic runs behind it; further items are double-buffered.
+    const int q4 = kblk >> 2;
+    const int n_items = n_rows * q4;
+    float2 mlA[VC_MAX_NSPLIT], mlB[VC_MAX_NSPLIT];
+    float4 osA[VC_MAX_NSPLIT], osB[VC_MAX_NSPLIT];
+    int rA, cA, rB, cB;
+    bool onA, onB;
+#define VC_LOAD_ITEMS(S, base)                                                                   \
+    {                                                                                            \
+      const int idx_ = (base) + tid;                                                             \
+      on##S = idx_ < n_items;                                                                    \
+      r##S = on##S ? idx_ / q4 : 0;                                                              \
+      c##S = k0 + (on##S ? (idx_ - r##S * q4) : 0) * 4;                                          \
+      const int h_ = c##S / a.hd, e_ = c##S - h_ * a.hd;                                         \
+      const float2* ml_ = reinterpret_cast<const float2*>(a.att_ml) + (long)(r##S * a.H + h_) * a.nsplit; \
+      const float* op_ = a.att_o + ((long)(r##S * a.H + h_) * a.nsplit) * a.hd + e_;             \
+      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
+        const int se_ = (s_ < a.nsplit) ? s_ : 0;                                                \
+        ml##S[s_] = ml_[se_];                                                                    \
+        os##S[s_] = *reinterpret_cast<const float4*>(op_ + (long)se_ * a.hd);                    \
+      }                                                                                          \
+    }
+#define VC_FINISH_ITEMS(S)                                                                       \
     {                                                                                            \
       float M_ = -INFINITY;                                                                      \
       _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
-        mls[s_].x = (s_ < a.nsplit) ? mls[s_].x : -INFINITY;                                     \
-        M_ = fmaxf(M_, mls[s_].x);                                                               \
+        ml##S[s_].x = (s_ < a.nsplit) ? ml##S[s_].x : -INFINITY;                                 \
+        M_ = fmaxf(M_, ml##S[s_].x);                                                             \
       }                                                                                          \
       float L_ = 0.f;                                                                            \
       f32x4 o_ = {0.f, 0.f, 0.f, 0.f};                                                           \
       _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
-        const float w_ = (mls[s_].x == -INFINITY) ? 0.f : expf(mls[s_].x - M_);                  \
-        L_ += w_ * mls[s_].y;                                                                    \
-        o_[0] += w_ * os[s_].x; o_[1] += w_ * os[s_].y; o_[2] += w_ * os[s_].z; o_[3] += w_ * os[s_].w; \
+        const float w_ = (ml##S[s_].x == -INFINITY) ? 0.f : expf(ml##S[s_].x - M_);              \
+        L_ += w_ * ml##S[s_].y;                                                                  \
+        o_[0] += w_ * os##S[s_].x; o_[1] += w_ * os##S[s_].y; o_[2] += w_ * os##S[s_].z; o_[3] += w_ * os##S[s_].w; \
       }                                                                                          \
       const float inv_ = (L_ > 0.f) ? 1.0f / L_ : 0.f;                                           \
       o_[0] *= inv_; o_[1] *= inv_; o_[2] *= inv_; o_[3] *= inv_;                                \
-      if (on_) store4(reinterpret_cast<WT*>(xl + (size_t)r_ * xs) + (c_ - k0), o_);              \
+      if (on##S) store4(reinterpret_cast<WT*>(xl + (size_t)r##S * xs) + (c##S - k0), o_);        \
     }
-    VC_LOAD_ITEMS(0);
-    VC_ISSUE_WEIGHTS();
-    VC_FINISH_ITEMS();
-    for (int base = 256; base < n_items; base += 256) {
-      VC_LOAD_ITEMS(base);
-      VC_FINISH_ITEMS();
+    VC_LOAD_ITEMS(A, 0);
+    VC_ISSUE_WEIGHTS(0);
+    VC_BURST_OUT();
+    if (n_items <= 256) {
+      VC_FINISH_ITEMS(A);
+    } else {
+      int base = 0;
+      for (;;) {
+        VC_LOAD_ITEMS(B, base + 256);        // past the end: clamped loads, nothing stored
+        VC_FINISH_ITEMS(A);
+        if ((base += 256) >= n_items) break;
+        VC_LOAD_ITEMS(A, base + 256);
+        VC_FINISH_ITEMS(B);
+        if ((base += 256) >= n_items) break;
+      }
     }
 #undef VC_LOAD_ITEMS
 #undef VC_FINISH_ITEMS
   }
-#undef VC_ISSUE_WEIGHTS
+#undef VC_BURST_OUT
   __syncthreads();
 
-  // (3) main loop: one ds_read_b128 + one MFMA per 1 KiB weight burst
+  // main loop: one ds_read_b128 + one MFMA per 1 KiB weight burst
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  const int mrow = ((lane & 15) < a.r_lds) ? (lane & 15) : 0;
+  const int mrow = (m < a.r_lds) ? m : 0;
   const char* xrow = xl + (size_t)mrow * xs + (size_t)(lane >> 4) * 16;
   for (int c = 0; c < a.nchunk; ++c) {
     const int ktl = (c * 4 + wave) * KTW;
@@ -317,30 +399,19 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)(ktl + i) * 64);
       acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);
     }
-    if (c + 1 < a.nchunk) {   // refill the same registers; co-resident blocks cover the latency
-      const int kt = kt0 + ((c + 1) * 4 + wave) * KTW;
-      if (a.nt) {
-#pragma unroll
-        for (int i = 0; i < KTW; ++i)
-          wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp + (long)(kt + i) * 64)));
-      } else {
-#pragma unroll
-        for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt + i) * 64];
-      }
-    }
+    if (c + 1 < a.nchunk) VC_ISSUE_WEIGHTS(c + 1);   // refill the same registers; co-resident blocks cover the latency
   }
+#undef VC_ISSUE_WEIGHTS
 
-  // (4) 4-way in-block K reduction, then the epilogue on wave 0
+  // 4-way in-block K reduction, then the epilogue on wave 0
   red[wave * 64 + lane] = acc;
   __syncthreads();
-  const int m = lane & 15;
-  const int n = nt * 16 + 4 * (lane >> 4);
   if (wave == 0 && m < n_rows) {
     {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
     }
-    gemm_epilogue<WT, EPI>(a, acc, m, n, ks, grp, (int)gridDim.z);
+    gemm_epilogue<WT, EPI>(a, acc, m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
   }
 }
 
@@ -427,7 +498,10 @@ __global__ __launch_bounds__(256) void rows_gemm_mt_k(const GemmArgs a) {
     if (wave == 0 && m < nr) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
-      gemm_epilogue<WT, EPI>(a, acc, row0 + m, n, ks, grp, (int)gridDim.z);
+      float4 eb;
+      int epos, eseq;
+      epi_preload<WT, EPI>(a, row0 + m, n, grp, eb, epos, eseq);
+      gemm_epilogue<WT, EPI>(a, acc, row0 + m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
     }
     __syncthreads();            // x and red are rewritten by the next tile
   }
@@ -507,7 +581,15 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
       granted = lds;
     }
   }
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles, ksplit, groups), dim3(256), lds, s, a);
+  GemmArgs b = a;
+  {
+    const int esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
+    const int upr = (a.K / ksplit) * esz / 16;
+    b.x_upr_shift = -1;
+    for (int sft = 0; sft < 20; ++sft)
+      if ((1 << sft) == upr) b.x_upr_shift = sft;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles, ksplit, groups), dim3(256), lds, s, b);
   return hipGetLastError();
 }
 
