@@ -38,15 +38,20 @@ def sources() -> list[Path]:
     return [CSRC / s for s in SOURCES if (CSRC / s).exists()]
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile every HIP translation unit and link libvcengine.so. Returns the library path."""
+def build(force: bool = False, verbose: bool = False, variant: str = "", extra_flags=()) -> Path:
+    """Compile every HIP translation unit and link libvcengine.so. Returns the library path.
+
+    variant/extra_flags build a diagnostic twin (libvcengine_<variant>.so, e.g. -DVC_KERNEL_TS for the
+    in-kernel time stamps of tools/kernel_ts.py); select it at run time with VC_ENGINE_LIB=<path>."""
     srcs = sources()
     deps = srcs + list(CSRC.glob("*.h")) + list((HERE.parent / "include").glob("*.h"))
-    stamp = HERE / ".build_stamp"
-    digest = _digest(deps)
+    LIB = HERE / (f"libvcengine_{variant}.so" if variant else "libvcengine.so")
+    FLAGS = [*globals()["FLAGS"], *extra_flags]
+    stamp = HERE / (f".build_stamp_{variant}" if variant else ".build_stamp")
+    digest = _digest(deps) + " ".join(extra_flags)
     if not force and LIB.exists() and stamp.exists() and stamp.read_text() == digest:
         return LIB
-    objdir = HERE / "build"
+    objdir = HERE / (f"build_{variant}" if variant else "build")
     objdir.mkdir(exist_ok=True)
     hipcc = _hipcc()
     procs = []
@@ -74,3 +79,5 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    if "--ts" in sys.argv:
+        print(build(force="--force" in sys.argv, verbose=True, variant="ts", extra_flags=("-DVC_KERNEL_TS",)))

@@ -34,6 +34,8 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
   constexpr int NW = VC_ATT_WAVES;
   __shared__ float s_m[NW], s_l[NW];
   __shared__ float s_o[NW][128];
+  VC_KTS_DECL();
+  VC_KTS(0);
   const int r = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;     // grid.x == n_rows
   // one scalar round trip for everything the addresses depend on (no early exit in between: a
   // branch would let the compiler serialise these three loads)
@@ -54,6 +56,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 
   if (active != 0 && pos >= 0 && seq >= 0) {   // a finished step / an inactive row leaves an empty partial (seq is
                                                // tested only so that its load is not sunk behind the branch)
+    VC_KTS(1);
     const int S = pos + 1;
     const int chunk = (S + a.nsplit - 1) / a.nsplit;
     const int p0 = sp * chunk;
@@ -81,12 +84,14 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     }
     VC_KV_LOADS(p0);
     __builtin_amdgcn_sched_barrier(0);
+    VC_KTS(2);
     float q[EPL];
 #pragma unroll
     for (int j = 0; j < EPL / 4; ++j) {
       q[4 * j] = qv[j].x * a.scale; q[4 * j + 1] = qv[j].y * a.scale;
       q[4 * j + 2] = qv[j].z * a.scale; q[4 * j + 3] = qv[j].w * a.scale;
     }
+    VC_KTS(3);
     for (int pb = p0;;) {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
@@ -113,6 +118,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
       VC_KV_LOADS(pb);
     }
 #undef VC_KV_LOADS
+    VC_KTS(4);
   }
   // merge the PPW position groups of this wave (same li, different sub)
   for (int off = LPR; off < 64; off <<= 1) {
@@ -129,12 +135,14 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     }
     m = mn;
   }
+  VC_KTS(5);
   if (lane < LPR) {
 #pragma unroll
     for (int j = 0; j < EPL; ++j) s_o[wave][lane * EPL + j] = o[j];
     if (lane == 0) { s_m[wave] = m; s_l[wave] = l; }
   }
   __syncthreads();
+  VC_KTS(6);
   if (tid < hd) {
     float M = s_m[0];
 #pragma unroll
@@ -150,6 +158,8 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     a.att_o[pi * hd + tid] = O;
     if (tid == 0) { a.att_ml[pi * 2] = M; a.att_ml[pi * 2 + 1] = L; }
   }
+  VC_KTS(7);
+  VC_KTS_FLUSH();
 }
 
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s) {

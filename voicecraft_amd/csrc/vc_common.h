@@ -123,6 +123,30 @@ __device__ __forceinline__ int wave_min_i(int v) {
              min(__builtin_amdgcn_readlane(v, 32), __builtin_amdgcn_readlane(v, 48)));
 }
 
+// ---------------------------------------------------------------- in-kernel time stamps (diagnostic build)
+// -DVC_KERNEL_TS: the first and the last workgroup of a launch record shader-clock stamps into
+// a.dbg_ts[0..15] / [16..31] (tools/kernel_ts.py).  Compiled out of the product library.
+#ifdef VC_KERNEL_TS
+#define VC_KTS_DECL()                                                                           \
+  long long kts_[16];                                                                           \
+  _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) kts_[i_] = 0;                               \
+  const int kts_lin_ = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);          \
+  const int kts_tot_ = gridDim.x * gridDim.y * gridDim.z;                                       \
+  const int kts_slot_ = (kts_lin_ == 0) ? 0 : ((kts_lin_ == kts_tot_ - 1) ? 16 : -1);
+#define VC_KTS(i)                                                                               \
+  do { __builtin_amdgcn_sched_barrier(0); kts_[i] = clock64(); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define VC_KTS_FLUSH()                                                                          \
+  do {                                                                                          \
+    if (a.dbg_ts && kts_slot_ >= 0 && threadIdx.x == 0) {                                       \
+      _Pragma("unroll") for (int i_ = 0; i_ < 16; ++i_) a.dbg_ts[kts_slot_ + i_] = kts_[i_];    \
+    }                                                                                           \
+  } while (0)
+#else
+#define VC_KTS_DECL()
+#define VC_KTS(i)
+#define VC_KTS_FLUSH()
+#endif
+
 // ---------------------------------------------------------------- per-sequence decode state (device)
 // Mirrors the Python locals of the reference's generation loop (models/voicecraft.py:994-1013,
 // :1037-1067): codebook_eog -> n_eog (always a prefix), cur_num_gen, prev_token,
@@ -201,6 +225,7 @@ struct GemmArgs {
   int S_max;
   float* part_out;          // PART: [ksplit][rows_cap][N]
   void* x_out;              // ln_rows_k: normalised rows, WT [rows][d]
+  long long* dbg_ts;        // shader-clock stamps (diagnostic builds with -DVC_KERNEL_TS only)
 };
 
 struct AttnArgs {
@@ -216,6 +241,7 @@ struct AttnArgs {
   const int* n_active;      // never null
   float* att_o;
   float* att_ml;
+  long long* dbg_ts;        // diagnostic builds only
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence

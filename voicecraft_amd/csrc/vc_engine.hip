@@ -204,6 +204,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.nt = (rs.n_active != nullptr || rs.nt) ? e->nt_decode : 0;   // decode steps (and the kernel microbenchmarks) stream once
   g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+  g.dbg_ts = e->dbg_ts;
   return g;
 }
 
@@ -233,7 +234,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit;
       a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
-      a.n_active = rs.n_active ? rs.n_active : e->one;
+      a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -313,7 +314,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
-      a.n_active = e->one;
+      a.n_active = e->one; a.dbg_ts = e->dbg_ts;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {
@@ -693,8 +694,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->amax, (size_t)VC_ROWS))) return rc;
-  if ((rc = dalloc(e, &e->dbg_ts, (size_t)16))) return rc;
-  HIPCHK(e, hipMemset(e->dbg_ts, 0, 16 * 8));
+  if ((rc = dalloc(e, &e->dbg_ts, (size_t)32))) return rc;
+  HIPCHK(e, hipMemset(e->dbg_ts, 0, 32 * 8));
   e->gen_cap = e->S_max;
   if ((rc = dalloc(e, &e->gen, (size_t)e->B_max * e->gen_cap * K))) return rc;
   HIPCHK(e, hipMemset(e->err_flag, 0, 16));
@@ -981,6 +982,7 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "vcache0") { src = e->layers[0].vc; avail = (int64_t)e->B_max * e->H * e->S_max * e->hd * e->esz; }
   else if (n == "pe") { src = e->pe; avail = (int64_t)e->S_max * e->d * 4; }
   else if (n == "sampler_ts") { src = e->dbg_ts; avail = 16 * 8; }
+  else if (n == "kernel_ts") { src = e->dbg_ts; avail = 32 * 8; }
   else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
   if (nbytes > avail) return fail(e, VC_ECAP, "debug buffer '%s' holds %lld bytes", n.c_str(), (long long)avail);
   HIPCHK(e, hipDeviceSynchronize());
@@ -1053,7 +1055,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
-      a.n_active = e->one;
+      a.n_active = e->one; a.dbg_ts = e->dbg_ts;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);

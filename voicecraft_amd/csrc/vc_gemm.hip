@@ -156,6 +156,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
+  VC_KTS_DECL();
+  VC_KTS(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x, ks = blockIdx.y, grp = blockIdx.z;
@@ -190,7 +192,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   }
 #define VC_BURST_OUT()                                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                             \
-  if (active == 0) return;   /* every sequence finished: the replayed step is a no-op */
+  if (active == 0) return;   /* every sequence finished: the replayed step is a no-op */     \
+  VC_KTS(1);
 
   // prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.  Every load is unconditional and
   // branch-free (out-of-range lanes re-read a valid address, unused split slabs are read and discarded
@@ -386,7 +389,9 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 #undef VC_FINISH_ITEMS
   }
 #undef VC_BURST_OUT
+  VC_KTS(2);
   __syncthreads();
+  VC_KTS(3);
 
   // main loop: one ds_read_b128 + one MFMA per 1 KiB weight burst
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -402,10 +407,12 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     if (c + 1 < a.nchunk) VC_ISSUE_WEIGHTS(c + 1);   // refill the same registers; co-resident blocks cover the latency
   }
 #undef VC_ISSUE_WEIGHTS
+  VC_KTS(4);
 
   // 4-way in-block K reduction, then the epilogue on wave 0
   red[wave * 64 + lane] = acc;
   __syncthreads();
+  VC_KTS(5);
   if (wave == 0 && m < n_rows) {
     {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
@@ -413,6 +420,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     }
     gemm_epilogue<WT, EPI>(a, acc, m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
   }
+  VC_KTS(6);
+  VC_KTS_FLUSH();
 }
 
 // ------------------------------------------------------------------ prefill: up to VC_MAX_ROWS rows per pass
