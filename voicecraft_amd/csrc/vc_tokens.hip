@@ -165,7 +165,16 @@ __device__ __forceinline__ bool is_silence(const SampleArgs& a, int tok) {
 // `sp` is the sequence state (in LDS); results go to xs (LDS in the fused kernel, HBM scratch when the
 // keep decision needs the kernel boundary): xs[0..K) tokens, xs[K] arg-max of codebook 0, xs[K+1] cond.
 #define VC_TS(i) do { if (a.dbg_ts && b == 0 && threadIdx.x == 0) a.dbg_ts[i] = clock64(); } while (0)
-__device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int* xs, float* s_rows) {
+// The logits row of codebook k = wave does not depend on the sequence state: the kernels request it
+// before anything else (v0), so that the state's round trip and the row's overlap.
+__device__ __forceinline__ void preload_row(const SampleArgs& a, int b, float (&v0)[VC_VPL]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const float* row = a.logits + ((long)b * a.K + min(wave, a.K - 1)) * a.V;
+#pragma unroll
+  for (int j = 0; j < VC_VPL; ++j) v0[j] = row[min(lane + 64 * j, a.V - 1)];   // all loads in flight together
+}
+__device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int* xs, float* s_rows,
+                                             const float (&v0)[VC_VPL]) {
   const SeqState st = *sp;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (st.done) return;
@@ -176,8 +185,13 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
     const float* row = a.logits + ((long)b * a.K + k) * V;
     float* sv = s_rows + k * VP;
     float v[VC_VPL];
+    if (k == wave) {
 #pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) v[j] = row[min(lane + 64 * j, V - 1)];   // all loads in flight together
+      for (int j = 0; j < VC_VPL; ++j) v[j] = v0[j];
+    } else {                                                                     // K > 4: later rows of this wave
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) v[j] = row[min(lane + 64 * j, V - 1)];
+    }
     if (a.logits_out && b == 0 && step < a.logit_steps) {
       float* lo = a.logits_out + ((long)step * a.K + k) * V;
 #pragma unroll
@@ -240,7 +254,11 @@ __device__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int
         int c = 0;
 #pragma unroll
         for (int j = 0; j < VC_VPL; ++j) c += (key[j] >= cand) ? 1 : 0;
-        if (wave_sum_i(c) >= kk) t = cand;
+        const int cs = wave_sum_i(c);
+        if (cs >= kk) {
+          t = cand;
+          if (cs == kk) break;        // exactly the kk largest keys are >= t already: the remaining bits cannot change the kept set
+        }
       }
 #pragma unroll
       for (int j = 0; j < VC_VPL; ++j) v[j] = (key[j] < t) ? -INFINITY : v[j];
@@ -454,9 +472,15 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState
   }
 }
 
-__device__ __forceinline__ void load_state(const SampleArgs& a, int b, SeqState* sp) {
+// The state words are requested (fetch_state) together with the "still active" word and the logits
+// row, i.e. in ONE round trip, and only then parked in LDS (park_state).
+__device__ __forceinline__ int fetch_state(const SampleArgs& a, int b) {
   constexpr int W = sizeof(SeqState) / 4;
-  if (threadIdx.x < W) reinterpret_cast<int*>(sp)[threadIdx.x] = reinterpret_cast<const int*>(a.st + b)[threadIdx.x];
+  return reinterpret_cast<const int*>(a.st + b)[min((int)threadIdx.x, W - 1)];
+}
+__device__ __forceinline__ void park_state(SeqState* sp, int word) {
+  constexpr int W = sizeof(SeqState) / 4;
+  if (threadIdx.x < W) reinterpret_cast<int*>(sp)[threadIdx.x] = word;
   __syncthreads();
 }
 __device__ __forceinline__ void store_state(const SampleArgs& a, int b, const SeqState* sp) {
@@ -468,11 +492,16 @@ extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // K rows of 64*
 __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   __shared__ SeqState s_st;
   __shared__ int s_xs[VC_MAX_CODEBOOKS + 2];
-  if (*a.n_active == 0) return;
   const int b = blockIdx.x;
   VC_TS(0);
-  load_state(a, blockIdx.x, &s_st);
-  sample_phase(a, blockIdx.x, &s_st, s_xs, s_dyn);
+  float v0[VC_VPL];
+  preload_row(a, blockIdx.x, v0);
+  const int sw = fetch_state(a, blockIdx.x);
+  const int active = *a.n_active;
+  __builtin_amdgcn_sched_barrier(0);
+  if (active == 0) return;
+  park_state(&s_st, sw);
+  sample_phase(a, blockIdx.x, &s_st, s_xs, s_dyn, v0);
   __syncthreads();
   VC_TS(6);
   advance_phase(a, blockIdx.x, false, &s_st, s_xs);
@@ -482,14 +511,22 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
 }
 __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
-  if (*a.n_active == 0) return;
-  load_state(a, blockIdx.x, &s_st);
-  sample_phase(a, blockIdx.x, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2), s_dyn);
+  float v0[VC_VPL];
+  preload_row(a, blockIdx.x, v0);
+  const int sw = fetch_state(a, blockIdx.x);
+  const int active = *a.n_active;
+  __builtin_amdgcn_sched_barrier(0);
+  if (active == 0) return;
+  park_state(&s_st, sw);
+  sample_phase(a, blockIdx.x, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2), s_dyn, v0);
 }
 __global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
-  if (*a.n_active == 0) return;
-  load_state(a, blockIdx.x, &s_st);
+  const int sw = fetch_state(a, blockIdx.x);
+  const int active = *a.n_active;
+  __builtin_amdgcn_sched_barrier(0);
+  if (active == 0) return;
+  park_state(&s_st, sw);
   advance_phase(a, blockIdx.x, true, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2));
   store_state(a, blockIdx.x, &s_st);
 }
