@@ -15,11 +15,14 @@ from voicecraft_amd.engine import VoiceCraftEngine
 
 GEMM = ["issue(loads+burst out, active known)", "prologue math", "block sync", "weights consumed", "K-reduce sync", "epilogue"]
 ATTN = ["pos known", "loads issued", "q arrived+scaled", "K/V consumed", "wave merge", "block sync", "final+store"]
-a = synth.make_args("giga830M")
+PRESET = sys.argv[1] if len(sys.argv) > 1 else "giga830M"
+ROWS = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+a = synth.make_args(PRESET)
+print(f"# {PRESET}, {ROWS} row(s)")
 sd = synth.make_state_dict(a, seed=0, perturb=False, fast=True)
-eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024)
-for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "ffn1_hot", "ffn2_hot"):
-    ms, _ = eng.bench_kernel(kn, n_rows=1, iters=32)
+eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=max(1, ROWS), max_positions=1024)
+for kn in ("qkv", "qkv_hot", "attn", "oproj", "ffn1", "ffn2", "ffn1_hot", "ffn2_hot"):
+    ms, _ = eng.bench_kernel(kn, n_rows=ROWS, iters=32)
     ts = eng.debug_read("kernel_ts", (32,), dtype=torch.int64).numpy()
     names = ATTN if kn.startswith("attn") else GEMM
     for blk, t in (("first", ts[:16]), ("last", ts[16:])):

@@ -214,6 +214,7 @@ struct GemmArgs {
   const float* att_o;       // [VC_ROWS][H][nsplit][hd]
   const float* att_ml;      // [VC_ROWS][H][nsplit][2]
   int nsplit, H, hd;
+  int att_q4_shift;         // log2 of (K slice / 4) when a power of two, else -1 (set by the launcher)
   // epilogues
   void* out;                // RELU/GELU: WT [r][out_ld]; LOGITS: float [r][group][N]
   int out_ld;

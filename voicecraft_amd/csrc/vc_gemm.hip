@@ -289,9 +289,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 #undef VC_LOAD_ROW
 #undef VC_FINISH_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
-    // X rows copied as 16-byte units, flat index = row * upr + unit.  The first XB*256 units are
-    // requested ahead of the weight burst (clamped, unconditional), the rest (many rows) behind it.
-    constexpr int XB = 4;
+    // X rows copied as 16-byte units, flat index = row * upr + unit.  The first NB*256 units are
+    // requested ahead of the weight burst (clamped, unconditional), the rest behind it.
     const int upr = kblk * (int)sizeof(WT) / 16;   // 16-byte units per row
     const int total = n_rows * upr;
     const char* src = reinterpret_cast<const char*>(a.x_in) + ((long)grp * a.x_group_stride + k0) * (long)sizeof(WT);
@@ -300,7 +299,6 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 #define VC_X_SPLIT(idx_, r_, u_)                                                                 \
     const int r_ = (sh >= 0) ? ((idx_) >> sh) : ((idx_) / upr);                                  \
     const int u_ = (idx_) - r_ * upr;
-    uint4 xv0, xv1, xv2, xv3;
 #define VC_X_LOAD(j, dst)                                                                        \
     {                                                                                            \
       const int i_ = min((j) * 256 + tid, total - 1);                                            \
@@ -315,78 +313,109 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
         *reinterpret_cast<uint4*>(xl + (size_t)rr_ * xs + (size_t)uu_ * 16) = val;               \
       }                                                                                          \
     }
-    VC_X_LOAD(0, xv0); VC_X_LOAD(1, xv1); VC_X_LOAD(2, xv2); VC_X_LOAD(3, xv3);
-    VC_ISSUE_WEIGHTS(0);
-    VC_BURST_OUT();
-    VC_X_STORE(0, xv0); VC_X_STORE(1, xv1); VC_X_STORE(2, xv2); VC_X_STORE(3, xv3);
-    for (int i_ = XB * 256 + tid; i_ < total; i_ += 256) {
-      VC_X_SPLIT(i_, rr_, uu_)
-      *reinterpret_cast<uint4*>(xl + (size_t)rr_ * xs + (size_t)uu_ * 16) =
-          *reinterpret_cast<const uint4*>(src + (long)rr_ * rstride + (long)uu_ * 16);
+    // (explicit scalars: an indexed array here is demoted to scratch memory by the compiler)
+#define VC_X_LATE(NB)                                                                            \
+      for (int i_ = NB * 256 + tid; i_ < total; i_ += 256) {                                     \
+        VC_X_SPLIT(i_, rr_, uu_)                                                                 \
+        *reinterpret_cast<uint4*>(xl + (size_t)rr_ * xs + (size_t)uu_ * 16) =                    \
+            *reinterpret_cast<const uint4*>(src + (long)rr_ * rstride + (long)uu_ * 16);         \
+      }
+    if (total <= 4 * 256) {        // one decode row (up to 4 KB x 4 slices)
+      uint4 x0, x1, x2, x3;
+      VC_X_LOAD(0, x0); VC_X_LOAD(1, x1); VC_X_LOAD(2, x2); VC_X_LOAD(3, x3);
+      VC_ISSUE_WEIGHTS(0);
+      VC_BURST_OUT();
+      VC_X_STORE(0, x0); VC_X_STORE(1, x1); VC_X_STORE(2, x2); VC_X_STORE(3, x3);
+    } else {                       // batched decode / span switch: 16 rows of 4 KB in one round trip
+      uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+      VC_X_LOAD(0, x0); VC_X_LOAD(1, x1); VC_X_LOAD(2, x2); VC_X_LOAD(3, x3);
+      VC_X_LOAD(4, x4); VC_X_LOAD(5, x5); VC_X_LOAD(6, x6); VC_X_LOAD(7, x7);
+      VC_X_LOAD(8, x8); VC_X_LOAD(9, x9); VC_X_LOAD(10, x10); VC_X_LOAD(11, x11);
+      VC_X_LOAD(12, x12); VC_X_LOAD(13, x13); VC_X_LOAD(14, x14); VC_X_LOAD(15, x15);
+      VC_ISSUE_WEIGHTS(0);
+      VC_BURST_OUT();
+      VC_X_STORE(0, x0); VC_X_STORE(1, x1); VC_X_STORE(2, x2); VC_X_STORE(3, x3);
+      VC_X_STORE(4, x4); VC_X_STORE(5, x5); VC_X_STORE(6, x6); VC_X_STORE(7, x7);
+      VC_X_STORE(8, x8); VC_X_STORE(9, x9); VC_X_STORE(10, x10); VC_X_STORE(11, x11);
+      VC_X_STORE(12, x12); VC_X_STORE(13, x13); VC_X_STORE(14, x14); VC_X_STORE(15, x15);
+      VC_X_LATE(16)
     }
+#undef VC_X_LATE
 #undef VC_X_LOAD
 #undef VC_X_STORE
 #undef VC_X_SPLIT
   } else {  // PRO_ATT: merge the split-S partials of the decode attention (softmax denominators)
-    // item = (row, 4 columns of one head); its 2*VC_MAX_NSPLIT loads are requested before the
-    // weight burst, the exp/scale arithmetic runs behind it; further items are double-buffered.
+    // item = (row, 4 columns of one head) with NS partials of (max, sum, acc[4]); a thread carries IB
+    // items at a time, NS * IB = 8 (one decode row: 8 splits x 1 item; batched rows: fewer splits, more
+    // items).  The first batch is requested before the weight burst, the exp/scale arithmetic runs
+    // behind it; further batches are double-buffered.
     const int q4 = kblk >> 2;
     const int n_items = n_rows * q4;
-    float2 mlA[VC_MAX_NSPLIT], mlB[VC_MAX_NSPLIT];
-    float4 osA[VC_MAX_NSPLIT], osB[VC_MAX_NSPLIT];
-    int rA, cA, rB, cB;
-    bool onA, onB;
-#define VC_LOAD_ITEMS(S, base)                                                                   \
-    {                                                                                            \
-      const int idx_ = (base) + tid;                                                             \
-      on##S = idx_ < n_items;                                                                    \
-      r##S = on##S ? idx_ / q4 : 0;                                                              \
-      c##S = k0 + (on##S ? (idx_ - r##S * q4) : 0) * 4;                                          \
-      const int h_ = c##S / a.hd, e_ = c##S - h_ * a.hd;                                         \
-      const float2* ml_ = reinterpret_cast<const float2*>(a.att_ml) + (long)(r##S * a.H + h_) * a.nsplit; \
-      const float* op_ = a.att_o + ((long)(r##S * a.H + h_) * a.nsplit) * a.hd + e_;             \
-      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
+    const int qsh = a.att_q4_shift;                 // log2(q4) when q4 is a power of two, else -1
+#define VC_ATT_LOAD(S, NS, IB, base)                                                             \
+    _Pragma("unroll") for (int ib_ = 0; ib_ < IB; ++ib_) {                                       \
+      const int idx_ = (base) + ib_ * 256 + tid;                                                 \
+      on##S[ib_] = idx_ < n_items;                                                               \
+      const int ic_ = on##S[ib_] ? idx_ : 0;                                                     \
+      r##S[ib_] = (qsh >= 0) ? (ic_ >> qsh) : (ic_ / q4);                                        \
+      c##S[ib_] = k0 + (ic_ - r##S[ib_] * q4) * 4;                                               \
+      const int h_ = c##S[ib_] / a.hd, e_ = c##S[ib_] - h_ * a.hd;                               \
+      const float2* ml_ = reinterpret_cast<const float2*>(a.att_ml) + (long)(r##S[ib_] * a.H + h_) * a.nsplit; \
+      const float* op_ = a.att_o + ((long)(r##S[ib_] * a.H + h_) * a.nsplit) * a.hd + e_;        \
+      _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                        \
         const int se_ = (s_ < a.nsplit) ? s_ : 0;                                                \
-        ml##S[s_] = ml_[se_];                                                                    \
-        os##S[s_] = *reinterpret_cast<const float4*>(op_ + (long)se_ * a.hd);                    \
+        ml##S[ib_][s_] = ml_[se_];                                                               \
+        os##S[ib_][s_] = *reinterpret_cast<const float4*>(op_ + (long)se_ * a.hd);               \
       }                                                                                          \
     }
-#define VC_FINISH_ITEMS(S)                                                                       \
-    {                                                                                            \
+#define VC_ATT_FINISH(S, NS, IB)                                                                 \
+    _Pragma("unroll") for (int ib_ = 0; ib_ < IB; ++ib_) {                                       \
       float M_ = -INFINITY;                                                                      \
-      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
-        ml##S[s_].x = (s_ < a.nsplit) ? ml##S[s_].x : -INFINITY;                                 \
-        M_ = fmaxf(M_, ml##S[s_].x);                                                             \
+      _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                        \
+        ml##S[ib_][s_].x = (s_ < a.nsplit) ? ml##S[ib_][s_].x : -INFINITY;                       \
+        M_ = fmaxf(M_, ml##S[ib_][s_].x);                                                        \
       }                                                                                          \
       float L_ = 0.f;                                                                            \
       f32x4 o_ = {0.f, 0.f, 0.f, 0.f};                                                           \
-      _Pragma("unroll") for (int s_ = 0; s_ < VC_MAX_NSPLIT; ++s_) {                             \
-        const float w_ = (ml##S[s_].x == -INFINITY) ? 0.f : expf(ml##S[s_].x - M_);              \
-        L_ += w_ * ml##S[s_].y;                                                                  \
-        o_[0] += w_ * os##S[s_].x; o_[1] += w_ * os##S[s_].y; o_[2] += w_ * os##S[s_].z; o_[3] += w_ * os##S[s_].w; \
+      _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                        \
+        const float w_ = (ml##S[ib_][s_].x == -INFINITY) ? 0.f : expf(ml##S[ib_][s_].x - M_);    \
+        L_ += w_ * ml##S[ib_][s_].y;                                                             \
+        o_[0] += w_ * os##S[ib_][s_].x; o_[1] += w_ * os##S[ib_][s_].y;                          \
+        o_[2] += w_ * os##S[ib_][s_].z; o_[3] += w_ * os##S[ib_][s_].w;                          \
       }                                                                                          \
       const float inv_ = (L_ > 0.f) ? 1.0f / L_ : 0.f;                                           \
       o_[0] *= inv_; o_[1] *= inv_; o_[2] *= inv_; o_[3] *= inv_;                                \
-      if (on##S) store4(reinterpret_cast<WT*>(xl + (size_t)r##S * xs) + (c##S - k0), o_);        \
+      if (on##S[ib_]) store4(reinterpret_cast<WT*>(xl + (size_t)r##S[ib_] * xs) + (c##S[ib_] - k0), o_); \
     }
-    VC_LOAD_ITEMS(A, 0);
-    VC_ISSUE_WEIGHTS(0);
-    VC_BURST_OUT();
-    if (n_items <= 256) {
-      VC_FINISH_ITEMS(A);
-    } else {
-      int base = 0;
-      for (;;) {
-        VC_LOAD_ITEMS(B, base + 256);        // past the end: clamped loads, nothing stored
-        VC_FINISH_ITEMS(A);
-        if ((base += 256) >= n_items) break;
-        VC_LOAD_ITEMS(A, base + 256);
-        VC_FINISH_ITEMS(B);
-        if ((base += 256) >= n_items) break;
-      }
+#define VC_ATT_PATH(NS, IB)                                                                      \
+    {                                                                                            \
+      float2 mlA[IB][NS], mlB[IB][NS];                                                           \
+      float4 osA[IB][NS], osB[IB][NS];                                                           \
+      int rA[IB], cA[IB], rB[IB], cB[IB];                                                        \
+      bool onA[IB], onB[IB];                                                                     \
+      VC_ATT_LOAD(A, NS, IB, 0);                                                                 \
+      VC_ISSUE_WEIGHTS(0);                                                                       \
+      VC_BURST_OUT();                                                                            \
+      if (n_items <= IB * 256) {                                                                 \
+        VC_ATT_FINISH(A, NS, IB);                                                                \
+      } else {                                                                                   \
+        int base = 0;                                                                            \
+        for (;;) {                                                                               \
+          VC_ATT_LOAD(B, NS, IB, base + IB * 256);   /* past the end: clamped loads, nothing stored */ \
+          VC_ATT_FINISH(A, NS, IB);                                                              \
+          if ((base += IB * 256) >= n_items) break;                                              \
+          VC_ATT_LOAD(A, NS, IB, base + IB * 256);                                               \
+          VC_ATT_FINISH(B, NS, IB);                                                              \
+          if ((base += IB * 256) >= n_items) break;                                              \
+        }                                                                                        \
+      }                                                                                          \
     }
-#undef VC_LOAD_ITEMS
-#undef VC_FINISH_ITEMS
+    if (a.nsplit > 4) VC_ATT_PATH(8, 1)
+    else if (a.nsplit > 2) VC_ATT_PATH(4, 2)
+    else VC_ATT_PATH(2, 4)
+#undef VC_ATT_PATH
+#undef VC_ATT_LOAD
+#undef VC_ATT_FINISH
   }
 #undef VC_BURST_OUT
   VC_KTS(2);
@@ -520,6 +549,7 @@ __global__ __launch_bounds__(256) void rows_gemm_mt_k(const GemmArgs a) {
 template <typename WT>
 __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   __shared__ float s_sum[4], s_sq[4];
+  if (*a.n_active == 0) return;
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = a.d;
   const int nq = d >> 2;
@@ -594,9 +624,13 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   {
     const int esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
     const int upr = (a.K / ksplit) * esz / 16;
+    const int q4 = (a.K / ksplit) / 4;
     b.x_upr_shift = -1;
-    for (int sft = 0; sft < 20; ++sft)
+    b.att_q4_shift = -1;
+    for (int sft = 0; sft < 20; ++sft) {
       if ((1 << sft) == upr) b.x_upr_shift = sft;
+      if ((1 << sft) == q4) b.att_q4_shift = sft;
+    }
   }
   hipLaunchKernelGGL(kern, dim3(a.n_tiles, ksplit, groups), dim3(256), lds, s, b);
   return hipGetLastError();
@@ -641,6 +675,7 @@ static hipError_t launch_ktw(const GemmArgs& a, int dtype, int pro, int epi, int
   if (pro == PRO_PLAIN && epi == EPI_LOGITS) return launch_one<WT, KTW, PRO_PLAIN, EPI_LOGITS>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_QKV) return launch_one<WT, KTW, PRO_PLAIN, EPI_QKV>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_RELU) return launch_one<WT, KTW, PRO_PLAIN, EPI_RELU>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_PLAIN && epi == EPI_GELU) return launch_one<WT, KTW, PRO_PLAIN, EPI_GELU>(a, dtype, ksplit, groups, s);
   return hipErrorInvalidValue;
 }
 
