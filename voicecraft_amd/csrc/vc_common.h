@@ -14,6 +14,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define VC_MAX_NSPLIT 8     // split-S factor cap of the decode attention (the out-projection prologue loads this many partials)
 #define VC_MAX_KSPLIT 4     // cross-block split-K cap of the rows-GEMM (the LN prologue prefetches this many slabs)
 #define VC_MAX_SEG 32       // prompt segments (2*spans+1 pieces + placeholders)
+#define VC_TH_QKV 12       // output channels per weight tile of the QKV projection (every other matrix: 16)
 #define VC_VPL 34           // logits per lane in the sampler: V <= 64*34
 
 // ---------------------------------------------------------------- element types
@@ -322,7 +323,7 @@ struct AssembleArgs {       // writes res [K][res_cap] from y and the generated 
 };
 
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
-hipError_t vc_launch_pack(const float* src, void* dst, int N, int K, int dtype, hipStream_t s);
+hipError_t vc_launch_pack(const float* src, void* dst, int N, int K, int dtype, int th, hipStream_t s);
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s);
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);

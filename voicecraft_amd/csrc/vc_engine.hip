@@ -116,10 +116,10 @@ int dalloc(vc_engine* e, T** p, size_t n) {
   return VC_OK;
 }
 
-Plan make_plan(int N, int Kdim, int dtype, bool allow_split, const char* env_override) {
+Plan make_plan(int N, int Kdim, int dtype, bool allow_split, const char* env_override, int th = 16) {
   Plan p;
   const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16;
-  p.n_tiles = (N + 15) / 16;
+  p.n_tiles = (N + th - 1) / th;
   p.KT = Kdim / KW;
   p.ksplit = 1;
   if (allow_split) {
@@ -161,15 +161,15 @@ int need(vc_engine* e, const std::string& key, std::initializer_list<int64_t> sh
   return VC_OK;
 }
 
-int pack_matrix(vc_engine* e, const std::string& key, int N, int Kdim, uint4** out) {
+int pack_matrix(vc_engine* e, const std::string& key, int N, int Kdim, uint4** out, int th = 16) {
   const RawTensor* t;
   int rc = need(e, key, {N, Kdim}, &t);
   if (rc) return rc;
   const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
-  const long units = (long)((N + 15) / 16) * (Kdim / KW) * 64;
+  const long units = (long)((N + th - 1) / th) * (Kdim / KW) * 4 * th;
   rc = dalloc(e, out, (size_t)units);
   if (rc) return rc;
-  HIPCHK(e, vc_launch_pack(t->dev, *out, N, Kdim, e->dtype, 0));
+  HIPCHK(e, vc_launch_pack(t->dev, *out, N, Kdim, e->dtype, th, 0));
   return VC_OK;
 }
 
@@ -627,7 +627,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (int l = 0; l < L; ++l) {
     const std::string pre = "decoder.layers." + std::to_string(l) + ".";
     Layer& ly = e->layers[l];
-    if ((rc = pack_matrix(e, pre + "self_attn.in_proj_weight", 3 * d, d, &ly.Wqkv))) return rc;
+    if ((rc = pack_matrix(e, pre + "self_attn.in_proj_weight", 3 * d, d, &ly.Wqkv, VC_TH_QKV))) return rc;
     if ((rc = keep_vec(e, pre + "self_attn.in_proj_bias", 3 * d, &ly.bqkv))) return rc;
     if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo))) return rc;
     if ((rc = keep_vec(e, pre + "self_attn.out_proj.bias", d, &ly.bo))) return rc;
@@ -667,7 +667,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
     const long units = (long)(K * P / 16) * (d / KW) * 64;
     if ((rc = dalloc(e, &e->Wh1, (size_t)units))) { hipFree(cat); return rc; }
-    hipError_t pe_ = vc_launch_pack(cat, e->Wh1, K * P, d, e->dtype, 0);
+    hipError_t pe_ = vc_launch_pack(cat, e->Wh1, K * P, d, e->dtype, 16, 0);
     hipDeviceSynchronize();
     hipFree(cat);
     HIPCHK(e, pe_);
@@ -678,7 +678,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     for (int k = 0; k < K; ++k) {
       const std::string pre = "predict_layer." + std::to_string(k) + ".";
       if ((rc = need(e, pre + "2.weight", {V, P}, &t))) return rc;
-      HIPCHK(e, vc_launch_pack(t->dev, e->Wh2 + (size_t)k * gunits, V, P, e->dtype, 0));
+      HIPCHK(e, vc_launch_pack(t->dev, e->Wh2 + (size_t)k * gunits, V, P, e->dtype, 16, 0));
       if ((rc = need(e, pre + "2.bias", {V}, &t))) return rc;
       HIPCHK(e, hipMemcpy(e->bh2 + (size_t)k * V, t->dev, (size_t)V * 4, hipMemcpyDeviceToDevice));
     }
@@ -687,7 +687,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (auto& kv : e->raw) if (kv.second.dev) hipFree(kv.second.dev);
   e->raw.clear();
   // ---- launch plans
-  e->p_qkv = make_plan(3 * d, d, e->dtype, false, nullptr);
+  e->p_qkv = make_plan(3 * d, d, e->dtype, false, nullptr, VC_TH_QKV);
   e->p_o = make_plan(d, d, e->dtype, true, "VC_KSPLIT_O");
   e->p_f1 = make_plan(4 * d, d, e->dtype, false, nullptr);
   e->p_f2 = make_plan(d, 4 * d, e->dtype, true, "VC_KSPLIT_F");

@@ -18,18 +18,21 @@
 #include "vc_common.h"
 
 // ------------------------------------------------------------------ packing
+// th = output channels per tile: 16 (every lane of the A fragment) or 12 (VC_TH_QKV: lanes with
+// (lane & 15) >= 12 carry no weight and nothing is stored for them - a tile is 4 x 12 fragments).
 template <typename WT>
 __global__ void pack_k(const float* __restrict__ src, WT* __restrict__ dst, int N, int K, int KT,
-                       long total) {
+                       long total, int th) {
   constexpr int EPL = WTr<WT>::EPL, KW = WTr<WT>::KW;
-  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (tile, lane)
+  long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (tile, fragment slot)
   if (idx >= total) return;
-  const int lane = (int)(idx & 63);
-  const long tile = idx >> 6;
+  const int spt = 4 * th;                                   // slots per (n_tile, k_tile)
+  const int slot = (int)(idx % spt);
+  const long tile = idx / spt;
   const int kt = (int)(tile % KT);
   const int nt = (int)(tile / KT);
-  const int n = nt * 16 + (lane & 15);
-  const int k = kt * KW + EPL * (lane >> 4);
+  const int n = nt * th + (slot % th);
+  const int k = kt * KW + EPL * (slot / th);
   WT* d = dst + idx * EPL;
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
@@ -38,18 +41,18 @@ __global__ void pack_k(const float* __restrict__ src, WT* __restrict__ dst, int 
   }
 }
 
-hipError_t vc_launch_pack(const float* src, void* dst, int N, int K, int dtype, hipStream_t s) {
-  const int n_tiles = (N + 15) / 16;
+hipError_t vc_launch_pack(const float* src, void* dst, int N, int K, int dtype, int th, hipStream_t s) {
+  const int n_tiles = (N + th - 1) / th;
   if (dtype == VC_DTYPE_BF16) {
     const int KT = K / 32;
-    long total = (long)n_tiles * KT * 64;
+    long total = (long)n_tiles * KT * 4 * th;
     hipLaunchKernelGGL(pack_k<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src,
-                       (bf16_t*)dst, N, K, KT, total);
+                       (bf16_t*)dst, N, K, KT, total, th);
   } else {
     const int KT = K / 16;
-    long total = (long)n_tiles * KT * 64;
+    long total = (long)n_tiles * KT * 4 * th;
     hipLaunchKernelGGL(pack_k<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src,
-                       (float*)dst, N, K, KT, total);
+                       (float*)dst, N, K, KT, total, th);
   }
   return hipGetLastError();
 }
@@ -170,24 +173,33 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   char* xl = smem;
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
 
+  // Tile height: the QKV projection (N = 3d) uses 12-channel tiles, so that its 3d/12 = d/4 tiles are
+  // a multiple of the CU count (512 workgroups of 48 KB at d = 2048 instead of 384 of 64 KB = 1.5 per
+  // CU); lanes 12..15 of each fragment row group re-read slot 11 and are zeroed before the MFMA.
+  constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;
+  constexpr int SPT = 4 * TH;                     // fragment slots per (n_tile, k_tile)
   const int active = *a.n_active;                 // scalar; looked at once the burst is on its way
   const int m = lane & 15;
-  const int n = nt * 16 + 4 * (lane >> 4);
+  const int kg = lane >> 4;
+  const int n = nt * TH + 4 * kg;
+  const bool wvalid = m < TH;                     // this lane's fragment row exists
+  const bool nvalid = 4 * kg < TH;                // this lane's 4 output channels exist
+  const int wslot = kg * TH + min(m, TH - 1);
   float4 eb;
   int epos, eseq;
   epi_preload<WT, EPI>(a, (m < n_rows) ? m : 0, n, grp, eb, epos, eseq);
 
-  const uint4* wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * 64;   // wave-uniform
+  const uint4* wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * SPT;   // wave-uniform
   uint4 wf[KTW];
   // a.nt: non-temporal loads for a weight stream that is read exactly once per launch (decode)
 #define VC_ISSUE_WEIGHTS(c_)                                                                     \
   {                                                                                              \
-    const uint4* wb_ = wbase + (long)(c_) * (4 * KTW * 64);                                       \
+    const uint4* wb_ = wbase + (long)(c_) * (4 * KTW * SPT);                                      \
     if (a.nt) {                                                                                  \
       _Pragma("unroll") for (int i = 0; i < KTW; ++i)                                            \
-        wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb_ + i * 64 + lane))); \
+        wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb_ + i * SPT + wslot))); \
     } else {                                                                                     \
-      _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wb_[i * 64 + lane];                \
+      _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wb_[i * SPT + wslot];              \
     }                                                                                            \
   }
 #define VC_BURST_OUT()                                                                           \
@@ -431,6 +443,9 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 #pragma unroll
     for (int i = 0; i < KTW; ++i) {
       const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)(ktl + i) * 64);
+      if constexpr (TH < 16) {
+        if (!wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
+      }
       acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);
     }
     if (c + 1 < a.nchunk) VC_ISSUE_WEIGHTS(c + 1);   // refill the same registers; co-resident blocks cover the latency
@@ -442,7 +457,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   red[wave * 64 + lane] = acc;
   __syncthreads();
   VC_KTS(5);
-  if (wave == 0 && m < n_rows) {
+  if (wave == 0 && m < n_rows && nvalid) {
     {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
@@ -472,15 +487,22 @@ __global__ __launch_bounds__(256) void rows_gemm_mt_k(const GemmArgs a) {
   const int xs = kblk * (int)sizeof(WT) + 16;
   char* xl = smem;
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)VC_ROWS * xs);
-  const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * 64 + lane;
+  constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;    // see rows_gemm_k
+  constexpr int SPT = 4 * TH;
+  const int m = lane & 15;
+  const int kg = lane >> 4;
+  const bool wvalid = m < TH, nvalid = 4 * kg < TH;
+  const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * SPT + (kg * TH + min(m, TH - 1));
   uint4 wf[KTW];
   {
     const int kt = kt0 + wave * KTW;
 #pragma unroll
-    for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt + i) * 64];
+    for (int i = 0; i < KTW; ++i) {
+      wf[i] = wp[(long)(kt + i) * SPT];
+      if (TH < 16 && !wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
   }
-  const int m = lane & 15;
-  const int n = nt * 16 + 4 * (lane >> 4);
+  const int n = nt * TH + 4 * kg;
   for (int row0 = 0; row0 < n_rows; row0 += VC_ROWS) {
     const int nr = min(VC_ROWS, n_rows - row0);
     if constexpr (PRO == PRO_PLAIN) {
@@ -522,7 +544,10 @@ __global__ __launch_bounds__(256) void rows_gemm_mt_k(const GemmArgs a) {
       if (a.nchunk > 1) {       // several chunks: the registers only ever hold one of them
         const int kt = kt0 + (c * 4 + wave) * KTW;
 #pragma unroll
-        for (int i = 0; i < KTW; ++i) wf[i] = wp[(long)(kt + i) * 64];
+        for (int i = 0; i < KTW; ++i) {
+          wf[i] = wp[(long)(kt + i) * SPT];
+          if (TH < 16 && !wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
       }
       const int ktl = (c * 4 + wave) * KTW;
 #pragma unroll
@@ -533,7 +558,7 @@ __global__ __launch_bounds__(256) void rows_gemm_mt_k(const GemmArgs a) {
     }
     red[wave * 64 + lane] = acc;
     __syncthreads();
-    if (wave == 0 && m < nr) {
+    if (wave == 0 && m < nr && nvalid) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
       float4 eb;
