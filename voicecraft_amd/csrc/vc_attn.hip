@@ -154,9 +154,13 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
       L += c * s_l[w];
       O += c * s_o[w][tid];
     }
-    const long pi = ((long)(r * a.H + h) * a.nsplit + sp);
-    a.att_o[pi * hd + tid] = O;
-    if (tid == 0) { a.att_ml[pi * 2] = M; a.att_ml[pi * 2 + 1] = L; }
+    if (a.x_out) {      // unsplit pass (prefill): the block saw every position, so it normalises itself
+      WTr<WT>::st(reinterpret_cast<WT*>(a.x_out) + (long)r * a.d + h * hd + tid, (L > 0.f) ? O / L : 0.f);
+    } else {
+      const long pi = ((long)(r * a.H + h) * a.nsplit + sp);
+      a.att_o[pi * hd + tid] = O;
+      if (tid == 0) { a.att_ml[pi * 2] = M; a.att_ml[pi * 2 + 1] = L; }
+    }
   }
   VC_KTS(7);
   VC_KTS_FLUSH();

@@ -243,6 +243,7 @@ struct AttnArgs {
   const int* n_active;      // never null
   float* att_o;
   float* att_ml;
+  void* x_out;              // nsplit == 1 only: normalised output rows, WT [rows][d] (the out-projection then takes the plain prologue)
   long long* dbg_ts;        // diagnostic builds only
 };
 

@@ -341,12 +341,19 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts;
+      if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
-      g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts; g.mt = 1;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+      g.Wp = ly.Wo; g.part_out = e->parts; g.mt = 1;
+      if (rs.nsplit == 1) {
+        g.x_in = e->xn; g.x_ld = d;
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_o.ksplit, 1, s));
+      } else {
+        g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+      }
     }
     {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
