@@ -19,6 +19,7 @@ PRESETS = {
     # name: (d_model, nhead, num_decoder_layers)
     "tiny": (256, 4, 2),          # head_dim 64
     "tiny128": (512, 4, 2),       # head_dim 128
+    "tiny_h16": (512, 16, 2),     # 16 heads of 32: batched decode reaches the 4- and 2-split attention merges
     "giga330M": (1024, 16, 24),   # assumed shape: not stated in the reference tree
     "giga830M": (2048, 16, 16),   # z_scripts/e830M.sh:34-37
 }
