@@ -41,6 +41,8 @@ def parse():
     p.add_argument("--lx", type=int, default=80)
     p.add_argument("--prompt-frames", type=int, default=150)
     p.add_argument("--top-k", type=int, default=40)
+    p.add_argument("--mode", default="tts", choices=["tts", "edit"],
+                   help="edit: BASELINE config 4 - one masked span in the middle of a 16 s utterance is re-generated")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--cpu-steps", type=int, default=48, help="decode steps of the bounded CPU sample")
@@ -103,7 +105,12 @@ def main():
     a = synth.make_args(args.preset)
     K = a.n_codebooks
     sd = synth.make_state_dict(a, seed=0, perturb=False, mute_eos=True, fast=True)
-    Tg = 10 * args.lx - args.prompt_frames
+    edit = args.mode == "edit"
+    if edit:       # 16 s utterance (10 frames per phoneme), the middle quarter masked: generation runs to the
+        assert args.batch == 1, "editing is single-utterance (models/voicecraft.py:607)"   # reference's length cap y_len > 10*Lx
+        args.prompt_frames = 10 * args.lx
+        span = (args.prompt_frames * 3 // 8, args.prompt_frames * 5 // 8)
+    Tg = 10 * args.lx - args.prompt_frames if not edit else span[1] - span[0]
     eng = VoiceCraftEngine(a, sd, device=dev, dtype=args.dtype, max_seqs=max(1, args.batch),
                            max_positions=max(1024, args.lx + args.prompt_frames + Tg + 64), use_graph=not args.no_graph)
     # utterance u of this rank = global utterance (u * world + rank); seed = 1 + global index
@@ -115,6 +122,10 @@ def main():
     knobs = dict(top_k=args.top_k, top_p=1.0, temperature=1.0, stop_repetition=3)
 
     def one_step(seed):
+        if edit:
+            mi = torch.tensor([[list(span)]], dtype=torch.int64)
+            res = eng.inference(xs[0], xls[0], ys[0], mi, silence_tokens=[1388, 1898, 131], _seed=seed, **knobs)
+            return (int(res.shape[2]) - (args.prompt_frames - (span[1] - span[0]))) * K
         if B == 1:
             res, gen = eng.inference_tts(xs[0], xls[0], ys[0], kvcache=1, silence_tokens=[1388, 1898, 131], _seed=seed, **knobs)
             gens = [gen]
@@ -177,8 +188,11 @@ def main():
             "metric": "codec_tokens_per_sec", "value": round(value, 1), "unit": "codec-tokens/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.preset} TTS, batch {B}/GPU, Lx={args.lx}, {args.prompt_frames} prompt frames -> "
-                                   f"{Tg} generated frames (16 s total), top_k={args.top_k}, hipGraph={'off' if args.no_graph else 'on'}",
+            "config": {"workload": (f"{args.preset} TTS, batch {B}/GPU, Lx={args.lx}, {args.prompt_frames} prompt frames -> "
+                                    f"{Tg} generated frames (16 s total), top_k={args.top_k}, hipGraph={'off' if args.no_graph else 'on'}")
+                                   if not edit else
+                                   (f"{args.preset} speech editing, Lx={args.lx}, {args.prompt_frames}-frame utterance, span "
+                                    f"{span} re-generated (~{Tg} frames, reference length cap), top_k={args.top_k}"),
                        "utterances_per_step": B * n_gpus, "parallelism": f"dp{n_gpus} (utterance-sharded, one all_gather)"},
             "rtf": round(dt / (frames / 50.0), 4),
             "decode_ms_per_token_step": round(dec_step_ms, 4), "prefill_ms": round(pre_ms / args.steps, 2),
