@@ -148,7 +148,7 @@ def test_wide_batch_decode_equals_per_utterance_oracle(B, dtype):
         else:
             want = eng.inference_tts(xx.cuda(), xl.cuda(), yy.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
             T = yy.shape[1]
-            assert got.shape == want.shape and got.min() >= 0 and got.max() < a.audio_vocab_size
+            assert got.shape == want.shape and got.min() >= 0 and got.max() < a.audio_vocab_size + a.n_special
             assert np.array_equal(got[:, :, :T], want[:, :, :T]) and np.array_equal(got[:, 0, T], want[:, 0, T])
 
 
