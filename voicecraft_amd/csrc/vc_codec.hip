@@ -245,6 +245,93 @@ __global__ __launch_bounds__(256) void lstm_step_k(const LstmArgs a) {
   }
 }
 
+// ---- the same recurrence as a two-layer wavefront: launch k advances layer 0 to step k and layer 1
+// to step k-1 (grid.y = layer), so a T-frame sequence takes T+1 launches instead of 2T, and layer 1's
+// input projection (W_ih h0_t) is folded into its step instead of being a separate GEMM over all T.
+// Every operand of a step is requested up front (one round trip): the 4 gate rows of W_hh (and W_ih),
+// h_{t-1} (and the lower layer's h_t) straight from L2 - no LDS staging, no block barrier.
+struct LstmWaveArgs {
+  const float* Whh[2];   // [4H][H], unit-major rows
+  const float* Wih1;     // layer 1: [4H][H], unit-major rows
+  const float* b1;       // layer 1: b_ih + b_hh, unit-major
+  const float* G0;       // layer 0: [T][4H] input projection + both biases
+  float* hs[2];          // [T][H] hidden sequences
+  float* c[2];           // [H] cell states
+  const float* hzero;    // [H] zeros
+  const float* skip;     // [T][H] block input (EncodecLSTM: lstm(x) + x)
+  float* out_raw;        // optional [T][H]
+  float* out_elu;        // optional [T][H]
+  int H, T, k;
+};
+template <int NQ>   // H = 256 * NQ
+__global__ __launch_bounds__(256) void lstm_wave_k(const LstmWaveArgs a) {
+  const int n = blockIdx.y;
+  const int t = a.k - n;
+  if (t < 0 || t >= a.T) return;
+  const int H = a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + wave;                   // hidden unit (grid.x = H / 4)
+  const int nq = H >> 2;
+  const float4* whh = reinterpret_cast<const float4*>(a.Whh[n] + (long)(4 * u) * H);
+  const float4* hp = reinterpret_cast<const float4*>(t ? a.hs[n] + (long)(t - 1) * H : a.hzero);
+  float4 w[4][NQ], hv[NQ], wi[4][NQ], xv[NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    hv[j] = hp[lane + 64 * j];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w[g][j] = whh[(long)g * nq + lane + 64 * j];
+  }
+  float4 gi;
+  if (n == 0) {
+    gi = *reinterpret_cast<const float4*>(a.G0 + (long)t * 4 * H + 4 * u);
+  } else {
+    const float4* wih = reinterpret_cast<const float4*>(a.Wih1 + (long)(4 * u) * H);
+    const float4* xp = reinterpret_cast<const float4*>(a.hs[0] + (long)t * H);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+      xv[j] = xp[lane + 64 * j];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wi[g][j] = wih[(long)g * nq + lane + 64 * j];
+    }
+    gi = *reinterpret_cast<const float4*>(a.b1 + 4 * u);
+  }
+  const float c_prev = a.c[n][u];
+  const float sk = (n == 1 && a.skip) ? a.skip[(long)t * H + u] : 0.f;
+  float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j)
+      g4[g] += (w[g][j].x * hv[j].x + w[g][j].y * hv[j].y) + (w[g][j].z * hv[j].z + w[g][j].w * hv[j].w);
+  }
+  if (n == 1) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      float acc = 0.f;
+#pragma unroll
+      for (int j = 0; j < NQ; ++j)
+        acc += (wi[g][j].x * xv[j].x + wi[g][j].y * xv[j].y) + (wi[g][j].z * xv[j].z + wi[g][j].w * xv[j].w);
+      g4[g] += acc;
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
+  if (lane != 0) return;
+  const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
+  const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
+  const float gg = tanhf(g4[2] + gi.z);
+  const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
+  const float c = fg * c_prev + ig * gg;
+  const float h = og * tanhf(c);
+  a.c[n][u] = c;
+  a.hs[n][(long)t * H + u] = h;
+  if (n == 1 && a.skip) {
+    const float y = h + sk;
+    if (a.out_raw) a.out_raw[(long)t * H + u] = y;
+    if (a.out_elu) a.out_elu[(long)t * H + u] = elu1(y);
+  }
+}
+
 // ---- residual VQ (EncodecResidualVectorQuantizer.encode/.decode).  One block per frame.
 // dist = -(|r|^2 - 2 r.e + |e|^2), arg-max with the lowest index on ties (torch.max), residual update.
 __global__ __launch_bounds__(256) void rvq_encode_k(const float* __restrict__ z, const float* __restrict__ Et,
@@ -338,6 +425,8 @@ struct Lstm {
   int H = 0, layers = 0;
   std::vector<float*> Whh;   // permuted [4H][H]
   std::vector<Conv> Wih;     // as 1x1 "convs" H -> 4H with the summed, permuted bias
+  std::vector<float*> WihP;  // the same matrices as plain permuted rows (wavefront kernel, layer 1)
+  std::vector<float*> bP;    // permuted b_ih + b_hh
 };
 }  // namespace
 
@@ -460,6 +549,8 @@ int make_lstm(vc_codec* c, const std::string& prefix, int H, int layers, Lstm* L
     hipLaunchKernelGGL(lstm_perm_k, dim3((unsigned)((4 * H + 255) / 256)), dim3(256), 0, 0, bhh, pb2, H, 1);
     hipLaunchKernelGGL(add_vec_k, dim3((unsigned)((4 * H + 255) / 256)), dim3(256), 0, 0, pb, pb2, 4 * H);
     L->Whh.push_back(pwhh);
+    L->WihP.push_back(pwih);
+    L->bP.push_back(pb);
     Conv cv;
     cv.Ci = H; cv.Co = 4 * H; cv.Kw = 1; cv.stride = 1; cv.transposed = 0; cv.w_raw = pwih; cv.bias = pb;
     const long KT = H / 16;
@@ -514,6 +605,28 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
   const int H = L.H;
   const float* in = x;
   float* seq[2] = {c->HS0, c->HS1};
+  if (L.layers == 2 && H % 256 == 0 && H <= 1024 && !getenv("VC_LSTM_SEQUENTIAL")) {
+    // two-layer wavefront: T + 1 launches (lstm_wave_k)
+    int Lo;
+    int rc = run_conv(c, L.Wih[0], x, T, nullptr, c->G, nullptr, &Lo, s);        // layer 0: G = x W_ih^T + b_ih + b_hh
+    if (rc) return rc;
+    CCHK(c, hipMemsetAsync(c->cstate, 0, (size_t)2 * H * 4, s));
+    LstmWaveArgs a;
+    memset(&a, 0, sizeof a);
+    a.Whh[0] = L.Whh[0]; a.Whh[1] = L.Whh[1]; a.Wih1 = L.WihP[1]; a.b1 = L.bP[1]; a.G0 = c->G;
+    a.hs[0] = seq[0]; a.hs[1] = seq[1]; a.c[0] = c->cstate; a.c[1] = c->cstate + H; a.hzero = c->hzero;
+    a.skip = x; a.out_raw = out_raw; a.out_elu = out_elu; a.H = H; a.T = T;
+    const dim3 grid(H / 4, 2);
+    for (int k = 0; k <= T; ++k) {
+      a.k = k;
+      if (H == 256) hipLaunchKernelGGL(lstm_wave_k<1>, grid, dim3(256), 0, s, a);
+      else if (H == 512) hipLaunchKernelGGL(lstm_wave_k<2>, grid, dim3(256), 0, s, a);
+      else if (H == 768) hipLaunchKernelGGL(lstm_wave_k<3>, grid, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(lstm_wave_k<4>, grid, dim3(256), 0, s, a);
+    }
+    CCHK(c, hipGetLastError());
+    return VC_OK;
+  }
   for (int n = 0; n < L.layers; ++n) {
     int Lo;
     int rc = run_conv(c, L.Wih[n], in, T, nullptr, c->G, nullptr, &Lo, s);      // G = in W_ih^T + b_ih + b_hh
@@ -661,7 +774,7 @@ extern "C" int vc_codec_finalize(vc_codec* c) {
   if ((rc = calloc_dev(c, &c->G, (size_t)c->T_max * 4 * top))) return rc;
   if ((rc = calloc_dev(c, &c->HS0, (size_t)c->T_max * top))) return rc;
   if ((rc = calloc_dev(c, &c->HS1, (size_t)c->T_max * top))) return rc;
-  if ((rc = calloc_dev(c, &c->cstate, (size_t)top))) return rc;
+  if ((rc = calloc_dev(c, &c->cstate, (size_t)2 * top))) return rc;
   if ((rc = calloc_dev(c, &c->hzero, (size_t)top))) return rc;
   if ((rc = calloc_dev(c, &c->err_flag, (size_t)4))) return rc;
   CCHK(c, hipMemset(c->hzero, 0, (size_t)top * 4));
