@@ -11,6 +11,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <chrono>
 #include <map>
 #include <string>
 #include <vector>
@@ -82,10 +83,15 @@ struct vc_engine {
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
   float ms[3]{0, 0, 0};
+  double host_ms[8]{};                  // host wall clock of the last call's phases (vc_debug_read "host_ms")
   double bytes_total = 0;               // HBM bytes owned by the engine
 };
 
 namespace {
+
+inline double now_ms() {
+  return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 int fail(vc_engine* e, int code, const char* fmt, ...) {
   char buf[512];
@@ -447,14 +453,18 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   const int poll = sc->poll_every > 0 ? sc->poll_every : 16;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
+  const double t0 = now_ms();
   if (sc->use_graph) {
     HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
     int rc = decode_step(e, sa, B, rps, grouped, s);
     hipError_t ce = hipStreamEndCapture(s, &graph);
     if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
     HIPCHK(e, ce);
+    e->host_ms[1] = now_ms() - t0;
     HIPCHK(e, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
+    e->host_ms[2] = now_ms() - t0 - e->host_ms[1];
   }
+  const double t1 = now_ms();
   int done_steps = 0, rc = VC_OK;
   while (done_steps < max_steps) {
     const int n = std::min(poll, max_steps - done_steps);
@@ -473,8 +483,10 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
     if (me != hipSuccess) { rc = fail(e, VC_EHIP, "poll failed: %s", hipGetErrorString(me)); break; }
     if (*e->h_flag <= 0) break;
   }
+  e->host_ms[3] = now_ms() - t1;
   if (exec) hipGraphExecDestroy(exec);
   if (graph) hipGraphDestroy(graph);
+  e->host_ms[4] = now_ms() - t1 - e->host_ms[3];
   if (steps_run) *steps_run = done_steps;
   return rc;
 }
@@ -1004,6 +1016,7 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   int rc = check_ready(e);
   if (rc) return rc;
   const void* src = nullptr;
+  const void* host_src = nullptr;
   int64_t avail = 0;
   const std::string n = name ? name : "";
   if (n == "logits") { src = e->logits; avail = (int64_t)VC_ROWS * e->K * e->V * 4; }
@@ -1020,8 +1033,10 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "pe") { src = e->pe; avail = (int64_t)e->S_max * e->d * 4; }
   else if (n == "sampler_ts") { src = e->dbg_ts; avail = 16 * 8; }
   else if (n == "kernel_ts") { src = e->dbg_ts; avail = 32 * 8; }
+  else if (n == "host_ms") { host_src = e->host_ms; avail = 8 * 8; }
   else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
   if (nbytes > avail) return fail(e, VC_ECAP, "debug buffer '%s' holds %lld bytes", n.c_str(), (long long)avail);
+  if (host_src) { memcpy(host_dst, host_src, (size_t)nbytes); return VC_OK; }
   HIPCHK(e, hipDeviceSynchronize());
   HIPCHK(e, hipMemcpy(host_dst, src, (size_t)nbytes, hipMemcpyDeviceToHost));
   return VC_OK;
