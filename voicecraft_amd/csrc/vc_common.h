@@ -194,7 +194,8 @@ struct Link {
   const int* done_prev;
   int n_self, n_prev;
   int prev_same_step;      // 1: the predecessor belongs to the same decode step, 0: to the previous one
-  int* err;                // set to 2 when a wait gives up
+  int* err;                // set to 2 when a wait gives up; err[1..4] = slot, target, observed sum, launches of the first one
+  int id;                  // slot index (diagnosis)
 };
 __device__ __forceinline__ int link_sum(const int* p) {
   int s = 0;
@@ -212,7 +213,10 @@ __device__ __forceinline__ void link_wait(const Link& lk) {
     const long long t0 = clock64();
     while (link_sum(lk.done_prev) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (clock64() - t0 > VC_LINK_SPIN_CLOCKS) { *lk.err = 2; break; }
+      if (clock64() - t0 > VC_LINK_SPIN_CLOCKS) {
+        if (atomicCAS(lk.err, 0, 2) == 0) { lk.err[1] = lk.id; lk.err[2] = target; lk.err[3] = link_sum(lk.done_prev); lk.err[4] = launches; }
+        break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }

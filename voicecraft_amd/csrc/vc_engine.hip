@@ -227,6 +227,7 @@ hipStream_t chain_next(vc_engine* e, hipStream_t s, int n_self, Link* lk) {
   }
   lk->n_self = n_self;
   lk->err = e->err_flag;
+  lk->id = j;
   e->ch.n_prev = n_self;
   return e->ch.s[j & 1];
 }
@@ -293,14 +294,17 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml;
-      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
+      hipStream_t st = chain_next(e, s, rs.n_rows * e->H * rs.nsplit, &a.link);
+      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, st));
     }
     {  // out-projection of the merged attention output -> split-K partial slabs
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo;
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
+      g.units = chain_units(e, e->p_o, 1);
+      hipStream_t st = chain_next(e, s, gemm_blocks(e->p_o, 1, g.units), &g.link);
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, st));
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
@@ -820,7 +824,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->logit_row, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->st, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
-  if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
+  if ((rc = dalloc(e, &e->err_flag, (size_t)8))) return rc;
   if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)VC_ROWS))) return rc;
@@ -829,7 +833,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipMemset(e->dbg_ts, 0, 32 * 8));
   e->gen_cap = e->S_max;
   if ((rc = dalloc(e, &e->gen, (size_t)e->B_max * e->gen_cap * K))) return rc;
-  HIPCHK(e, hipMemset(e->err_flag, 0, 16));
+  HIPCHK(e, hipMemset(e->err_flag, 0, 32));
   HIPCHK(e, hipMemset(e->n_active, 0, 16));
   { const int one[4] = {1, 1, 1, 1}; HIPCHK(e, hipMemcpy(e->one, one, 16, hipMemcpyHostToDevice)); }
   HIPCHK(e, hipHostMalloc((void**)&e->h_st, sizeof(SeqState) * VC_ROWS));
@@ -1236,7 +1240,12 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     e->ch.on = false;
     HIPCHK(e, hipStreamSynchronize(e->chain_stream));
     HIPCHK(e, hipMemcpy(e->h_flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (*e->h_flag) { hipMemset(e->err_flag, 0, sizeof(int)); return fail(e, VC_EHIP, "a chained launch gave up waiting for its predecessor"); }
+    if (*e->h_flag) {
+      int info[8] = {0};
+      hipMemcpy(info, e->err_flag, 5 * sizeof(int), hipMemcpyDeviceToHost);
+      hipMemset(e->err_flag, 0, 8 * sizeof(int));
+      return fail(e, VC_EHIP, "a chained launch gave up waiting for its predecessor (slot %d: target %d, saw %d, launches %d)", info[1], info[2], info[3], info[4]);
+    }
   }
   float ms = 0;
   HIPCHK(e, hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
