@@ -196,8 +196,10 @@ struct Link {
   int prev_same_step;      // 1: the predecessor belongs to the same decode step, 0: to the previous one
   int* err;                // set to 2 when a wait gives up; err[1..4] = slot, target, observed sum, launches of the first one
   int id;                  // slot index (diagnosis)
+  int flags;               // experiments (VC_CHAIN_FLAGS): 1 no release fence, 2 no acquire fence, 4 one counter word, 8 long sleep
 };
-__device__ __forceinline__ int link_sum(const int* p) {
+__device__ __forceinline__ int link_sum(const int* p, int flags = 0) {
+  if (flags & 4) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   int s = 0;
 #pragma unroll
   for (int i = 0; i < VC_LINK_SHARDS; ++i)
@@ -208,17 +210,17 @@ __device__ __forceinline__ int link_sum(const int* p) {
 __device__ __forceinline__ void link_wait(const Link& lk) {
   if (!lk.done_self) return;
   if (threadIdx.x == 0) {
-    const int launches = link_sum(lk.done_self) / lk.n_self;       // completed launches of this slot
+    const int launches = link_sum(lk.done_self, lk.flags) / lk.n_self;       // completed launches of this slot
     const int target = (launches + lk.prev_same_step) * lk.n_prev;
     const long long t0 = clock64();
-    while (link_sum(lk.done_prev) < target) {
-      __builtin_amdgcn_s_sleep(1);
+    while (link_sum(lk.done_prev, lk.flags) < target) {
+      if (lk.flags & 8) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(1);
       if (clock64() - t0 > VC_LINK_SPIN_CLOCKS) {
-        if (atomicCAS(lk.err, 0, 2) == 0) { lk.err[1] = lk.id; lk.err[2] = target; lk.err[3] = link_sum(lk.done_prev); lk.err[4] = launches; }
+        if (atomicCAS(lk.err, 0, 2) == 0) { lk.err[1] = lk.id; lk.err[2] = target; lk.err[3] = link_sum(lk.done_prev, lk.flags); lk.err[4] = launches; }
         break;
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    if (!(lk.flags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
@@ -228,11 +230,11 @@ __device__ __forceinline__ void link_arrive(const Link& lk) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    if (!(lk.flags & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    __hip_atomic_fetch_add(lk.done_self + (lin & (VC_LINK_SHARDS - 1)) * VC_LINK_STRIDE, 1, __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
+    const int shard = (lk.flags & 4) ? 0 : (lin & (VC_LINK_SHARDS - 1));
+    __hip_atomic_fetch_add(lk.done_self + shard * VC_LINK_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

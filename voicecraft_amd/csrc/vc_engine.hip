@@ -81,6 +81,7 @@ struct vc_engine {
   hipStream_t chain_stream = nullptr;   // second stream of the chained decode step (vc_common.h "chained launches")
   hipEvent_t chain_ev = nullptr;
   int* chain_done = nullptr;            // [VC_CHAIN_SLOTS][VC_LINK_SHARDS * VC_LINK_STRIDE] completion counters
+  int chain_flags = 0;                  // VC_CHAIN_FLAGS: protocol experiments (vc_common.h Link::flags)
   int chain_mode = 0;                   // VC_CHAIN=1: chain the launches of single-sequence TTS decode steps
   struct { bool on = false; int slot = 0, n_prev = 0, n_last = 0, nslots = 0; bool ring = true; hipStream_t s[2]{}; } ch;
   int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
@@ -228,6 +229,7 @@ hipStream_t chain_next(vc_engine* e, hipStream_t s, int n_self, Link* lk) {
   lk->n_self = n_self;
   lk->err = e->err_flag;
   lk->id = j;
+  lk->flags = e->chain_flags;
   e->ch.n_prev = n_self;
   return e->ch.s[j & 1];
 }
@@ -840,8 +842,17 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipHostMalloc((void**)&e->h_flag, 64));
   for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
   // a blocking stream: implicitly ordered after work the caller queued on the null stream
-  HIPCHK(e, hipStreamCreate(&e->own_stream));
-  HIPCHK(e, hipStreamCreate(&e->chain_stream));
+  {
+    // VC_CHAIN_PRIO (experiment): 1 = second stream at high priority, 2 = both streams
+    const char* pv = getenv("VC_CHAIN_PRIO");
+    const int prio = pv ? atoi(pv) : 0;
+    int lo = 0, hi = 0;
+    hipDeviceGetStreamPriorityRange(&lo, &hi);
+    if (prio >= 2) HIPCHK(e, hipStreamCreateWithPriority(&e->own_stream, hipStreamDefault, hi));
+    else HIPCHK(e, hipStreamCreate(&e->own_stream));
+    if (prio >= 1) HIPCHK(e, hipStreamCreateWithPriority(&e->chain_stream, hipStreamDefault, hi));
+    else HIPCHK(e, hipStreamCreate(&e->chain_stream));
+  }
   HIPCHK(e, hipEventCreateWithFlags(&e->chain_ev, hipEventDisableTiming));
   if ((rc = dalloc(e, &e->chain_done, (size_t)VC_CHAIN_SLOTS * VC_LINK_SHARDS * VC_LINK_STRIDE))) return rc;
   HIPCHK(e, hipMemset(e->chain_done, 0, (size_t)VC_CHAIN_SLOTS * VC_LINK_SHARDS * VC_LINK_STRIDE * 4));
@@ -852,6 +863,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));
     const char* cm = getenv("VC_CHAIN");
     e->chain_mode = cm ? atoi(cm) : 0;
+    const char* cf = getenv("VC_CHAIN_FLAGS");
+    e->chain_flags = cf ? atoi(cf) : 0;
     const char* ls = getenv("VC_LN_SPLIT_ROWS");
     if (ls) e->ln_split_rows = std::max(2, atoi(ls));
   }
