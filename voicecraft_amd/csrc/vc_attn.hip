@@ -39,17 +39,9 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
   const int r = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;     // grid.x == n_rows
   // one scalar round trip for everything the addresses depend on (no early exit in between: a
   // branch would let the compiler serialise these three loads)
-  int active, pos, seq;
-  if (a.link.done_self) {      // chained launch: nothing the predecessors produced is touched before the wait,
-    link_wait(a.link);         // and the per-step words are read past the scalar cache
-    active = __hip_atomic_load(a.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pos = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.row_pos + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    seq = __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.row_seq + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-  } else {
-    active = *a.n_active;
-    pos = a.row_pos[r];
-    seq = a.row_seq[r];
-  }
+  const int active = *a.n_active;
+  const int pos = a.row_pos[r];
+  const int seq = a.row_seq[r];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hd = a.hd;
@@ -171,7 +163,6 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     }
   }
   VC_KTS(7);
-  link_arrive(a.link);
   VC_KTS_FLUSH();
 }
 

@@ -173,71 +173,6 @@ struct SeqState {
   int mask_value[VC_MAX_SPANS];   // mask_embedding row inserted before span i (i >= 1)
 };
 
-// ---------------------------------------------------------------- chained launches (decode step, opt-in)
-// Consecutive kernels of a decode step alternate between two streams, so kernel j+1 is already
-// resident (its first weight burst on its way) while kernel j is still running; the order between
-// them is kept by completion counters instead of the stream barrier.  A Link names the counters of a
-// launch: every workgroup bumps one of VC_LINK_SHARDS words of done_self when it has finished and
-// waits - before it touches anything its predecessor produced - until the predecessor's words sum to
-// "launches so far x workgroups per launch".  Launches of one slot are serialised by their stream, so
-// the number of completed launches is done_self / n_self, read at the top of the kernel.
-// At most two kernels are ever in flight and every chained grid is <= 256 workgroups of <= 4 waves,
-// so both are always co-resident (no workgroup waits for one that cannot be scheduled).
-// Hand-off recipe: cdna_hip_programming.md Guideline 16 (producer: every wave drains its stores,
-// block barrier, one lane release-fences at agent scope, then the counter; consumer: one lane polls
-// with agent-scope loads, acquire fence, block barrier, plain loads).  Every spin is bounded.
-#define VC_LINK_SHARDS 8
-#define VC_LINK_STRIDE 16            // ints between shards (64 B: one word per cache line)
-#define VC_LINK_SPIN_CLOCKS (24LL * 1000 * 1000)   // ~10 ms of shader clock: give up, flag the error
-struct Link {
-  int* done_self;          // null: not chained (plain stream order)
-  const int* done_prev;
-  int n_self, n_prev;
-  int prev_same_step;      // 1: the predecessor belongs to the same decode step, 0: to the previous one
-  int* err;                // set to 2 when a wait gives up; err[1..4] = slot, target, observed sum, launches of the first one
-  int id;                  // slot index (diagnosis)
-  int flags;               // experiments (VC_CHAIN_FLAGS): 1 no release fence, 2 no acquire fence, 4 one counter word, 8 long sleep
-};
-__device__ __forceinline__ int link_sum(const int* p, int flags = 0) {
-  if (flags & 4) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  int s = 0;
-#pragma unroll
-  for (int i = 0; i < VC_LINK_SHARDS; ++i)
-    s += __hip_atomic_load(p + i * VC_LINK_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return s;
-}
-// Whole block.  Returns after the predecessor's results are visible to plain loads of this block.
-__device__ __forceinline__ void link_wait(const Link& lk) {
-  if (!lk.done_self) return;
-  if (threadIdx.x == 0) {
-    const int launches = link_sum(lk.done_self, lk.flags) / lk.n_self;       // completed launches of this slot
-    const int target = (launches + lk.prev_same_step) * lk.n_prev;
-    const long long t0 = clock64();
-    while (link_sum(lk.done_prev, lk.flags) < target) {
-      if (lk.flags & 8) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(1);
-      if (clock64() - t0 > VC_LINK_SPIN_CLOCKS) {
-        if (atomicCAS(lk.err, 0, 2) == 0) { lk.err[1] = lk.id; lk.err[2] = target; lk.err[3] = link_sum(lk.done_prev, lk.flags); lk.err[4] = launches; }
-        break;
-      }
-    }
-    if (!(lk.flags & 2)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-  }
-  __syncthreads();
-}
-// Whole block, after its last store.
-__device__ __forceinline__ void link_arrive(const Link& lk) {
-  if (!lk.done_self) return;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    if (!(lk.flags & 1)) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    const int shard = (lk.flags & 4) ? 0 : (lin & (VC_LINK_SHARDS - 1));
-    __hip_atomic_fetch_add(lk.done_self + shard * VC_LINK_STRIDE, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-}
-
 // ---------------------------------------------------------------- kernel argument blocks
 enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2 };
 enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4 };
@@ -292,8 +227,6 @@ struct GemmArgs {
   int S_max;
   float* part_out;          // PART: [ksplit][rows_cap][N]
   void* x_out;              // ln_rows_k: normalised rows, WT [rows][d]
-  int units;                // weight tiles a workgroup walks (chained decode launches: grid <= 256), >= 1
-  Link link;
   long long* dbg_ts;        // shader-clock stamps (diagnostic builds with -DVC_KERNEL_TS only)
 };
 
@@ -311,7 +244,6 @@ struct AttnArgs {
   float* att_o;
   float* att_ml;
   void* x_out;              // nsplit == 1 only: normalised output rows, WT [rows][d] (the out-projection then takes the plain prologue)
-  Link link;
   long long* dbg_ts;        // diagnostic builds only
 };
 
@@ -377,7 +309,6 @@ struct SampleArgs {
   float alpha_audio;
   int max_positions;
   long long* dbg_ts;        // optional [16] shader-clock stamps of sequence 0 (diagnosis only)
-  Link link;
 };
 
 struct AssembleArgs {       // writes res [K][res_cap] from y and the generated spans

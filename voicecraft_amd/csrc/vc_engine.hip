@@ -78,12 +78,6 @@ struct vc_engine {
   int *h_flag = nullptr;
 
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
-  hipStream_t chain_stream = nullptr;   // second stream of the chained decode step (vc_common.h "chained launches")
-  hipEvent_t chain_ev = nullptr;
-  int* chain_done = nullptr;            // [VC_CHAIN_SLOTS][VC_LINK_SHARDS * VC_LINK_STRIDE] completion counters
-  int chain_flags = 0;                  // VC_CHAIN_FLAGS: protocol experiments (vc_common.h Link::flags)
-  int chain_mode = 0;                   // VC_CHAIN=1: chain the launches of single-sequence TTS decode steps
-  struct { bool on = false; int slot = 0, n_prev = 0, n_last = 0, nslots = 0; bool ring = true; hipStream_t s[2]{}; } ch;
   int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
@@ -94,8 +88,6 @@ struct vc_engine {
 };
 
 namespace {
-
-constexpr int VC_CHAIN_SLOTS = 256;
 
 inline double now_ms() {
   return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
@@ -208,38 +200,6 @@ struct RowSrc {
   int nt;           // force the streaming-load policy (microbenchmarks)
 };
 
-// Next launch of a chained step: its Link and the stream it goes to (alternating).  Unchained: {} and s.
-hipStream_t chain_next(vc_engine* e, hipStream_t s, int n_self, Link* lk) {
-  memset(lk, 0, sizeof *lk);
-  if (!e->ch.on) return s;
-  const int j = e->ch.slot++;
-  const int per = VC_LINK_SHARDS * VC_LINK_STRIDE;
-  lk->done_self = e->chain_done + (size_t)j * per;
-  if (j == 0) {
-    // ring (decode step): the predecessor is the last launch of the previous step; line (microbenchmark):
-    // a slot nobody ever bumps, whose target is 0
-    lk->done_prev = e->chain_done + (size_t)(e->ch.ring ? e->ch.nslots - 1 : VC_CHAIN_SLOTS - 1) * per;
-    lk->n_prev = e->ch.ring ? e->ch.n_last : 1;
-    lk->prev_same_step = 0;
-  } else {
-    lk->done_prev = e->chain_done + (size_t)(j - 1) * per;
-    lk->n_prev = e->ch.n_prev;
-    lk->prev_same_step = 1;
-  }
-  lk->n_self = n_self;
-  lk->err = e->err_flag;
-  lk->id = j;
-  lk->flags = e->chain_flags;
-  e->ch.n_prev = n_self;
-  return e->ch.s[j & 1];
-}
-// weight tiles per workgroup that keep a chained grid <= 256 workgroups
-int chain_units(vc_engine* e, const Plan& p, int groups) {
-  if (!e->ch.on) return 1;
-  return std::max(1, (p.n_tiles * p.ksplit * groups + 255) / 256);
-}
-int gemm_blocks(const Plan& p, int groups, int units) { return ((p.n_tiles + units - 1) / units) * p.ksplit * groups; }
-
 GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdim) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
@@ -281,9 +241,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
       } else {
-        g.units = chain_units(e, e->p_qkv, 1);
-        hipStream_t st = chain_next(e, s, gemm_blocks(e->p_qkv, 1, g.units), &g.link);
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, st));
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
       }
     }
     {  //                                                                 
@@ -296,17 +254,14 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml;
-      hipStream_t st = chain_next(e, s, rs.n_rows * e->H * rs.nsplit, &a.link);
-      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, st));
+      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {  // out-projection of the merged attention output -> split-K partial slabs
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo;
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
-      g.units = chain_units(e, e->p_o, 1);
-      hipStream_t st = chain_next(e, s, gemm_blocks(e->p_o, 1, g.units), &g.link);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, st));
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
@@ -321,9 +276,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
       } else {
-        g.units = chain_units(e, e->p_f1, 1);
-        hipStream_t st = chain_next(e, s, gemm_blocks(e->p_f1, 1, g.units), &g.link);
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, st));
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
       }
     }
     {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
@@ -331,9 +284,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.W2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.part_out = e->parts;
-      g.units = chain_units(e, e->p_f2, 1);
-      hipStream_t st = chain_next(e, s, gemm_blocks(e->p_f2, 1, g.units), &g.link);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, st));
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     }
   }
   return VC_OK;
@@ -358,9 +309,7 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
       g.x_in = e->xn; g.x_ld = e->d;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_GELU, 1, 1, s));
     } else {
-      g.units = chain_units(e, e->p_h1, 1);
-      hipStream_t st = chain_next(e, s, gemm_blocks(e->p_h1, 1, g.units), &g.link);
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, st));
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_GELU, 1, 1, s));
     }
   }
   {  //                                                                          
@@ -369,9 +318,7 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
     g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
     g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits + (size_t)out_row0 * e->K * e->V;
-    g.units = chain_units(e, e->p_h2, e->K);
-    hipStream_t st = chain_next(e, s, gemm_blocks(e->p_h2, e->K, g.units), &g.link);
-    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, st));
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
   }
   return VC_OK;
 }
@@ -495,9 +442,7 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   if ((rc = forward_rows(e, rs, s))) return rc;
   // rps == 1: logit_row[b] == b (vc_tokens.hip advance_phase); the 3-row span switch is single-sequence
   if ((rc = run_heads(e, rps == 1 ? nullptr : e->logit_row, B, 0, e->n_active, s))) return rc;
-  SampleArgs sa2 = sa;
-  hipStream_t st = chain_next(e, s, B, &sa2.link);
-  HIPCHK(e, vc_launch_sample(sa2, grouped, st));
+  HIPCHK(e, vc_launch_sample(sa, grouped, s));
   return VC_OK;
 }
 
@@ -506,41 +451,17 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
 int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, const vc_sample_cfg* sc,
                 int max_steps, int* steps_run, hipStream_t s) {
   const int poll = sc->poll_every > 0 ? sc->poll_every : 16;
-  // chained mode (opt-in): single-row TTS steps only - the batched / span-switch passes keep stream order
-  const bool chain = e->chain_mode && rps == 1 && !grouped && B * rps < e->ln_split_rows && 5 * e->L + 3 < VC_CHAIN_SLOTS;
-  hipStream_t s2 = e->chain_stream;
-  hipGraph_t graph = nullptr, graph2 = nullptr;
-  hipGraphExec_t exec = nullptr, exec2 = nullptr;
-  e->ch.on = false;
-  if (chain) {
-    e->ch.on = true; e->ch.ring = true; e->ch.slot = 0; e->ch.n_prev = 0;
-    e->ch.nslots = 5 * e->L + 3; e->ch.n_last = B;
-    e->ch.s[0] = s; e->ch.s[1] = s2;
-    HIPCHK(e, hipMemsetAsync(e->chain_done, 0, (size_t)VC_CHAIN_SLOTS * VC_LINK_SHARDS * VC_LINK_STRIDE * 4, s));
-    HIPCHK(e, hipEventRecord(e->chain_ev, s));
-    HIPCHK(e, hipStreamWaitEvent(s2, e->chain_ev, 0));      // s2 starts behind the prefill and the counter reset
-  }
-  auto cleanup = [&]() {
-    if (exec) hipGraphExecDestroy(exec);
-    if (exec2) hipGraphExecDestroy(exec2);
-    if (graph) hipGraphDestroy(graph);
-    if (graph2) hipGraphDestroy(graph2);
-    e->ch.on = false;
-  };
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
   const double t0 = now_ms();
   if (sc->use_graph) {
     HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    if (chain) HIPCHK(e, hipStreamBeginCapture(s2, hipStreamCaptureModeThreadLocal));
-    e->ch.slot = 0;
     int rc = decode_step(e, sa, B, rps, grouped, s);
     hipError_t ce = hipStreamEndCapture(s, &graph);
-    hipError_t ce2 = chain ? hipStreamEndCapture(s2, &graph2) : hipSuccess;
-    if (rc) { cleanup(); return rc; }
-    if (ce != hipSuccess || ce2 != hipSuccess) { cleanup(); return fail(e, VC_EHIP, "stream capture failed: %s", hipGetErrorString(ce != hipSuccess ? ce : ce2)); }
+    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+    HIPCHK(e, ce);
     e->host_ms[1] = now_ms() - t0;
-    hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    if (ie == hipSuccess && chain) ie = hipGraphInstantiate(&exec2, graph2, nullptr, nullptr, 0);
-    if (ie != hipSuccess) { cleanup(); return fail(e, VC_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie)); }
+    HIPCHK(e, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
     e->host_ms[2] = now_ms() - t0 - e->host_ms[1];
   }
   const double t1 = now_ms();
@@ -550,30 +471,21 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
     for (int i = 0; i < n && rc == VC_OK; ++i) {
       if (exec) {
         hipError_t le = hipGraphLaunch(exec, s);
-        if (le == hipSuccess && exec2) le = hipGraphLaunch(exec2, s2);
         if (le != hipSuccess) rc = fail(e, VC_EHIP, "hipGraphLaunch failed: %s", hipGetErrorString(le));
       } else {
-        e->ch.slot = 0;
         rc = decode_step(e, sa, B, rps, grouped, s);
       }
     }
     if (rc) break;
     done_steps += n;
-    hipError_t me = chain ? hipStreamSynchronize(s2) : hipSuccess;
-    if (me == hipSuccess) me = hipMemcpyAsync(e->h_flag, e->n_active, sizeof(int), hipMemcpyDeviceToHost, s);
+    hipError_t me = hipMemcpyAsync(e->h_flag, e->n_active, sizeof(int), hipMemcpyDeviceToHost, s);
     if (me == hipSuccess) me = hipStreamSynchronize(s);
     if (me != hipSuccess) { rc = fail(e, VC_EHIP, "poll failed: %s", hipGetErrorString(me)); break; }
     if (*e->h_flag <= 0) break;
   }
-  if (chain) {
-    hipStreamSynchronize(s2);
-    if (rc == VC_OK && hipMemcpy(e->h_flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost) == hipSuccess && *e->h_flag == 2) {
-      hipMemset(e->err_flag, 0, sizeof(int));
-      rc = fail(e, VC_EHIP, "a chained launch gave up waiting for its predecessor");
-    }
-  }
   e->host_ms[3] = now_ms() - t1;
-  cleanup();
+  if (exec) hipGraphExecDestroy(exec);
+  if (graph) hipGraphDestroy(graph);
   e->host_ms[4] = now_ms() - t1 - e->host_ms[3];
   if (steps_run) *steps_run = done_steps;
   return rc;
@@ -663,8 +575,6 @@ extern "C" void vc_destroy(vc_engine* e) {
   if (e->h_flag) hipHostFree(e->h_flag);
   for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
-  if (e->chain_stream) hipStreamDestroy(e->chain_stream);
-  if (e->chain_ev) hipEventDestroy(e->chain_ev);
   delete e;
 }
 
@@ -826,7 +736,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->logit_row, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->st, (size_t)VC_ROWS))) return rc;
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
-  if ((rc = dalloc(e, &e->err_flag, (size_t)8))) return rc;
+  if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)VC_ROWS))) return rc;
@@ -835,36 +745,19 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipMemset(e->dbg_ts, 0, 32 * 8));
   e->gen_cap = e->S_max;
   if ((rc = dalloc(e, &e->gen, (size_t)e->B_max * e->gen_cap * K))) return rc;
-  HIPCHK(e, hipMemset(e->err_flag, 0, 32));
+  HIPCHK(e, hipMemset(e->err_flag, 0, 16));
   HIPCHK(e, hipMemset(e->n_active, 0, 16));
   { const int one[4] = {1, 1, 1, 1}; HIPCHK(e, hipMemcpy(e->one, one, 16, hipMemcpyHostToDevice)); }
   HIPCHK(e, hipHostMalloc((void**)&e->h_st, sizeof(SeqState) * VC_ROWS));
   HIPCHK(e, hipHostMalloc((void**)&e->h_flag, 64));
   for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
   // a blocking stream: implicitly ordered after work the caller queued on the null stream
-  {
-    // VC_CHAIN_PRIO (experiment): 1 = second stream at high priority, 2 = both streams
-    const char* pv = getenv("VC_CHAIN_PRIO");
-    const int prio = pv ? atoi(pv) : 0;
-    int lo = 0, hi = 0;
-    hipDeviceGetStreamPriorityRange(&lo, &hi);
-    if (prio >= 2) HIPCHK(e, hipStreamCreateWithPriority(&e->own_stream, hipStreamDefault, hi));
-    else HIPCHK(e, hipStreamCreate(&e->own_stream));
-    if (prio >= 1) HIPCHK(e, hipStreamCreateWithPriority(&e->chain_stream, hipStreamDefault, hi));
-    else HIPCHK(e, hipStreamCreate(&e->chain_stream));
-  }
-  HIPCHK(e, hipEventCreateWithFlags(&e->chain_ev, hipEventDisableTiming));
-  if ((rc = dalloc(e, &e->chain_done, (size_t)VC_CHAIN_SLOTS * VC_LINK_SHARDS * VC_LINK_STRIDE))) return rc;
-  HIPCHK(e, hipMemset(e->chain_done, 0, (size_t)VC_CHAIN_SLOTS * VC_LINK_SHARDS * VC_LINK_STRIDE * 4));
+  HIPCHK(e, hipStreamCreate(&e->own_stream));
   {
     const char* nv = getenv("VC_NT");
     e->nt_decode = nv ? atoi(nv) : 1;
     const char* pr = getenv("VC_PREFILL_ROWS");
     if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));
-    const char* cm = getenv("VC_CHAIN");
-    e->chain_mode = cm ? atoi(cm) : 0;
-    const char* cf = getenv("VC_CHAIN_FLAGS");
-    e->chain_flags = cf ? atoi(cf) : 0;
     const char* ls = getenv("VC_LN_SPLIT_ROWS");
     if (ls) e->ln_split_rows = std::max(2, atoi(ls));
   }
@@ -1187,19 +1080,6 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   bool hot = false;
   std::string w2 = w;
   if (w.size() > 4 && w.substr(w.size() - 4) == "_hot") { hot = true; w2 = w.substr(0, w.size() - 4); }
-  // "step_chain": the same 5L+2 launches as "step", chained over two streams (vc_common.h "chained launches")
-  const bool chain = (w == "step_chain");
-  if (chain) {
-    if (n_rows >= e->ln_split_rows || 5 * e->L + 2 >= VC_CHAIN_SLOTS) return fail(e, VC_EINVAL, "step_chain: single-row passes only");
-    w2 = "step";
-    e->ch.on = true; e->ch.ring = true; e->ch.slot = 0; e->ch.n_prev = 0;
-    e->ch.nslots = 5 * e->L + 2;
-    e->ch.n_last = gemm_blocks(e->p_h2, e->K, chain_units(e, e->p_h2, e->K));
-    e->ch.s[0] = s; e->ch.s[1] = e->chain_stream;
-    HIPCHK(e, hipMemsetAsync(e->chain_done, 0, (size_t)VC_CHAIN_SLOTS * VC_LINK_SHARDS * VC_LINK_STRIDE * 4, s));
-    HIPCHK(e, hipEventRecord(e->chain_ev, s));
-    HIPCHK(e, hipStreamWaitEvent(e->chain_stream, e->chain_ev, 0));
-  }
   auto one = [&](int i) -> int {
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
@@ -1230,7 +1110,6 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.n_active = e->one; a.dbg_ts = e->dbg_ts;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "step") {
-      e->ch.slot = 0;
       int r = forward_rows(e, rs, s);
       if (r) return r;
       return run_heads(e, nullptr, n_rows, 0, nullptr, s);
@@ -1239,27 +1118,11 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     }
     return VC_OK;
   };
-  for (int i = 0; i < 3; ++i) { rc = one(i); if (rc) { e->ch.on = false; return rc; } }
-  if (chain) { HIPCHK(e, hipStreamSynchronize(e->chain_stream)); HIPCHK(e, hipStreamSynchronize(s)); }
+  for (int i = 0; i < 3; ++i) { rc = one(i); if (rc) return rc; }
   HIPCHK(e, hipEventRecord(e->ev[0], s));
-  for (int i = 0; i < iters; ++i) { rc = one(i); if (rc) { e->ch.on = false; return rc; } }
-  if (chain) {            // the timed region ends when both streams are through
-    HIPCHK(e, hipEventRecord(e->chain_ev, e->chain_stream));
-    HIPCHK(e, hipStreamWaitEvent(s, e->chain_ev, 0));
-  }
+  for (int i = 0; i < iters; ++i) { rc = one(i); if (rc) return rc; }
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   HIPCHK(e, hipStreamSynchronize(s));
-  if (chain) {
-    e->ch.on = false;
-    HIPCHK(e, hipStreamSynchronize(e->chain_stream));
-    HIPCHK(e, hipMemcpy(e->h_flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost));
-    if (*e->h_flag) {
-      int info[8] = {0};
-      hipMemcpy(info, e->err_flag, 5 * sizeof(int), hipMemcpyDeviceToHost);
-      hipMemset(e->err_flag, 0, 8 * sizeof(int));
-      return fail(e, VC_EHIP, "a chained launch gave up waiting for its predecessor (slot %d: target %d, saw %d, launches %d)", info[1], info[2], info[3], info[4]);
-    }
-  }
   float ms = 0;
   HIPCHK(e, hipEventElapsedTime(&ms, e->ev[0], e->ev[1]));
   *avg_ms = ms / (float)iters;

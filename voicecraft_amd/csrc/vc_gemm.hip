@@ -15,7 +15,6 @@
 // Block = 4 waves sharing one 16-row output tile; the waves split the block's K range 4 ways and
 // reduce through LDS.  Cross-block split-K (EPI_PART) leaves fp32 partial slabs that the NEXT
 // kernel's LayerNorm prologue sums (launch-boundary reduce: no atomics, deterministic).
-#include <algorithm>
 #include "vc_common.h"
 
 // ------------------------------------------------------------------ packing
@@ -88,11 +87,15 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) {
 // lane at the very top of the kernel - a dependent load at the END of a 10 us kernel is a full
 // round trip on the critical path.  mg < n_rows (host contract), n is clamped here.
 template <typename WT, int EPI>
-__device__ __forceinline__ float4 epi_bias(const GemmArgs& a, int n, int grp) {     // static operand (weights)
-  float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+__device__ __forceinline__ void epi_preload(const GemmArgs& a, int mg, int n, int grp, float4& b, int& pos, int& seq) {
+  b = make_float4(0.f, 0.f, 0.f, 0.f);
+  pos = -1;
+  seq = 0;
   const int nc = (n < a.N) ? n : 0;
   if constexpr (EPI == EPI_QKV) {
     b = *reinterpret_cast<const float4*>(a.bias + nc);
+    pos = a.row_pos[mg];
+    seq = a.row_seq[mg];
   } else if constexpr (EPI == EPI_RELU || EPI == EPI_GELU) {
     b = *reinterpret_cast<const float4*>(a.bias + (long)grp * a.bias_group_stride + nc);
   } else if constexpr (EPI == EPI_LOGITS) {   // N need not be a multiple of 4
@@ -100,21 +103,6 @@ __device__ __forceinline__ float4 epi_bias(const GemmArgs& a, int n, int grp) { 
     const int last = a.N - 1;
     b.x = bp[min(n, last)]; b.y = bp[min(n + 1, last)]; b.z = bp[min(n + 2, last)]; b.w = bp[min(n + 3, last)];
   }
-  return b;
-}
-template <int EPI>
-__device__ __forceinline__ void epi_slot(const GemmArgs& a, int mg, int& pos, int& seq) {   // per-step operand
-  pos = -1;
-  seq = 0;
-  if constexpr (EPI == EPI_QKV) {
-    pos = a.row_pos[mg];
-    seq = a.row_seq[mg];
-  }
-}
-template <typename WT, int EPI>
-__device__ __forceinline__ void epi_preload(const GemmArgs& a, int mg, int n, int grp, float4& b, int& pos, int& seq) {
-  b = epi_bias<WT, EPI>(a, n, grp);
-  epi_slot<EPI>(a, mg, pos, seq);
 }
 
 // fused epilogue of one lane: output channels n..n+3 of row mg (mg = global row index of the pass)
@@ -166,10 +154,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int 
 // behind from a wave-uniform base (SGPR addressing: no per-load VALU address arithmetic, no register
 // reuse that would make the compiler wait mid-burst); (3) a scheduling barrier keeps the prologue
 // arithmetic from being hoisted into the burst; (4) only then is anything waited for.
-// CH = 1: chained launch (vc_common.h "chained launches"): the first weight burst is requested before the
-// wait for the predecessor, everything step-dependent after it, and the workgroup walks a.units weight
-// tiles so that the grid stays <= 256 workgroups.
-template <typename WT, int KTW, int PRO, int EPI, int CH>
+template <typename WT, int KTW, int PRO, int EPI>
 __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -178,10 +163,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   VC_KTS(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int U = CH ? a.units : 1;                 // weight tiles of this workgroup
-  const int nt0 = blockIdx.x * U;
-  int nt = min(nt0, a.n_tiles - 1);
-  const int ks = blockIdx.y, grp = blockIdx.z;
+  const int nt = blockIdx.x, ks = blockIdx.y, grp = blockIdx.z;
   const int n_rows = a.n_rows;                    // >= 1 (host contract)
   const int kt_blk = a.nchunk * 4 * KTW;          // k-tiles this block covers
   const int kt0 = ks * kt_blk;                    // first of them
@@ -196,17 +178,16 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   // CU); lanes 12..15 of each fragment row group re-read slot 11 and are zeroed before the MFMA.
   constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;
   constexpr int SPT = 4 * TH;                     // fragment slots per (n_tile, k_tile)
-  int active = 1;
-  if constexpr (!CH) active = *a.n_active;        // scalar; looked at once the burst is on its way
+  const int active = *a.n_active;                 // scalar; looked at once the burst is on its way
   const int m = lane & 15;
   const int kg = lane >> 4;
-  int n = nt * TH + 4 * kg;
+  const int n = nt * TH + 4 * kg;
   const bool wvalid = m < TH;                     // this lane's fragment row exists
   const bool nvalid = 4 * kg < TH;                // this lane's 4 output channels exist
   const int wslot = kg * TH + min(m, TH - 1);
-  float4 eb = epi_bias<WT, EPI>(a, n, grp);
-  int epos = -1, eseq = 0;
-  if constexpr (!CH) epi_slot<EPI>(a, (m < n_rows) ? m : 0, epos, eseq);
+  float4 eb;
+  int epos, eseq;
+  epi_preload<WT, EPI>(a, (m < n_rows) ? m : 0, n, grp, eb, epos, eseq);
 
   const uint4* wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * SPT;   // wave-uniform
   uint4 wf[KTW];
@@ -221,21 +202,10 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       _Pragma("unroll") for (int i = 0; i < KTW; ++i) wf[i] = wb_[i * SPT + wslot];              \
     }                                                                                            \
   }
-#define VC_ISSUE_FIRST() if constexpr (!CH) { VC_ISSUE_WEIGHTS(0); }
 #define VC_BURST_OUT()                                                                           \
   __builtin_amdgcn_sched_barrier(0);                                                             \
-  if (active == 0) {         /* every sequence finished: the replayed step is a no-op */         \
-    if constexpr (CH) link_arrive(a.link);                                                       \
-    return;                                                                                      \
-  }                                                                                              \
+  if (active == 0) return;   /* every sequence finished: the replayed step is a no-op */     \
   VC_KTS(1);
-  if constexpr (CH) {        // burst first, then the predecessor, then everything it produced
-    VC_ISSUE_WEIGHTS(0);
-    __builtin_amdgcn_sched_barrier(0);
-    link_wait(a.link);
-    active = __hip_atomic_load(a.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    epi_slot<EPI>(a, (m < n_rows) ? m : 0, epos, eseq);
-  }
 
   // prologue: build the rows' X slice [n_rows][kblk] as WT in LDS.  Every load is unconditional and
   // branch-free (out-of-range lanes re-read a valid address, unused split slabs are read and discarded
@@ -313,7 +283,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       }                                                                                          \
     }
     VC_LOAD_ROW(A, 0, 1);
-    VC_ISSUE_FIRST();
+    VC_ISSUE_WEIGHTS(0);
     VC_BURST_OUT();
     if (n_rows == 1) {
       VC_FINISH_ROW(A, 0);
@@ -365,7 +335,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     if (total <= 4 * 256) {        // one decode row (up to 4 KB x 4 slices)
       uint4 x0, x1, x2, x3;
       VC_X_LOAD(0, x0); VC_X_LOAD(1, x1); VC_X_LOAD(2, x2); VC_X_LOAD(3, x3);
-      VC_ISSUE_FIRST();
+      VC_ISSUE_WEIGHTS(0);
       VC_BURST_OUT();
       VC_X_STORE(0, x0); VC_X_STORE(1, x1); VC_X_STORE(2, x2); VC_X_STORE(3, x3);
     } else {                       // batched decode / span switch: 16 rows of 4 KB in one round trip
@@ -374,7 +344,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       VC_X_LOAD(4, x4); VC_X_LOAD(5, x5); VC_X_LOAD(6, x6); VC_X_LOAD(7, x7);
       VC_X_LOAD(8, x8); VC_X_LOAD(9, x9); VC_X_LOAD(10, x10); VC_X_LOAD(11, x11);
       VC_X_LOAD(12, x12); VC_X_LOAD(13, x13); VC_X_LOAD(14, x14); VC_X_LOAD(15, x15);
-      VC_ISSUE_FIRST();
+      VC_ISSUE_WEIGHTS(0);
       VC_BURST_OUT();
       VC_X_STORE(0, x0); VC_X_STORE(1, x1); VC_X_STORE(2, x2); VC_X_STORE(3, x3);
       VC_X_STORE(4, x4); VC_X_STORE(5, x5); VC_X_STORE(6, x6); VC_X_STORE(7, x7);
@@ -436,7 +406,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       int rA[IB], cA[IB], rB[IB], cB[IB];                                                        \
       bool onA[IB], onB[IB];                                                                     \
       VC_ATT_LOAD(A, NS, IB, 0);                                                                 \
-      VC_ISSUE_FIRST();                                                                       \
+      VC_ISSUE_WEIGHTS(0);                                                                       \
       VC_BURST_OUT();                                                                            \
       if (n_items <= IB * 256) {                                                                 \
         VC_ATT_FINISH(A, NS, IB);                                                                \
@@ -460,56 +430,41 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 #undef VC_ATT_FINISH
   }
 #undef VC_BURST_OUT
-#undef VC_ISSUE_FIRST
   VC_KTS(2);
   __syncthreads();
   VC_KTS(3);
 
-  // main loop: one ds_read_b128 + one MFMA per 1 KiB weight burst; chained launches walk U tiles
+  // main loop: one ds_read_b128 + one MFMA per 1 KiB weight burst
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   const int mrow = (m < a.r_lds) ? m : 0;
   const char* xrow = xl + (size_t)mrow * xs + (size_t)(lane >> 4) * 16;
-  for (int u = 0; u < U; ++u) {
-    const bool tile_ok = nt0 + u < a.n_tiles;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    for (int c = 0; c < a.nchunk; ++c) {
-      const int ktl = (c * 4 + wave) * KTW;
+  for (int c = 0; c < a.nchunk; ++c) {
+    const int ktl = (c * 4 + wave) * KTW;
 #pragma unroll
-      for (int i = 0; i < KTW; ++i) {
-        const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)(ktl + i) * 64);
-        if constexpr (TH < 16) {
-          if (!wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-        acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);
+    for (int i = 0; i < KTW; ++i) {
+      const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)(ktl + i) * 64);
+      if constexpr (TH < 16) {
+        if (!wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
       }
-      if (c + 1 < a.nchunk) VC_ISSUE_WEIGHTS(c + 1);   // refill the same registers; co-resident blocks cover the latency
+      acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);
     }
-    const int n_cur = n;
-    const float4 eb_cur = eb;
-    if (u + 1 < U) {          // next tile's burst (and bias) before this tile's reduce and epilogue
-      nt = min(nt0 + u + 1, a.n_tiles - 1);
-      n = nt * TH + 4 * kg;
-      wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * SPT;
-      eb = epi_bias<WT, EPI>(a, n, grp);
-      VC_ISSUE_WEIGHTS(0);
-    }
-    if (u == 0) VC_KTS(4);
-
-    // 4-way in-block K reduction, then the epilogue on wave 0
-    red[wave * 64 + lane] = acc;
-    __syncthreads();
-    if (u == 0) VC_KTS(5);
-    if (wave == 0 && m < n_rows && nvalid && tile_ok) {
-      {
-        const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
-        acc = (acc + a1) + (a2 + a3);
-      }
-      gemm_epilogue<WT, EPI>(a, acc, m, n_cur, ks, grp, (int)gridDim.z, eb_cur, epos, eseq);
-    }
-    if (u + 1 < U) __syncthreads();      // the reduce area is rewritten by the next tile
+    if (c + 1 < a.nchunk) VC_ISSUE_WEIGHTS(c + 1);   // refill the same registers; co-resident blocks cover the latency
   }
 #undef VC_ISSUE_WEIGHTS
+  VC_KTS(4);
+
+  // 4-way in-block K reduction, then the epilogue on wave 0
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  VC_KTS(5);
+  if (wave == 0 && m < n_rows && nvalid) {
+    {
+      const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
+      acc = (acc + a1) + (a2 + a3);
+    }
+    gemm_epilogue<WT, EPI>(a, acc, m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
+  }
   VC_KTS(6);
-  if constexpr (CH) link_arrive(a.link);
   VC_KTS_FLUSH();
 }
 
@@ -729,9 +684,9 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4);
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int CH>
-static hipError_t launch_dec_ch(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, CH>;
+template <typename WT, int KTW, int PRO, int EPI>
+static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit);
   if (lds > 64 * 1024) {
     static size_t granted = 0;   // per instantiation
@@ -754,15 +709,8 @@ static hipError_t launch_dec_ch(const GemmArgs& a, int dtype, int ksplit, int gr
       if ((1 << sft) == q4) b.att_q4_shift = sft;
     }
   }
-  const int U = CH ? std::max(1, a.units) : 1;
-  b.units = U;
-  hipLaunchKernelGGL(kern, dim3((a.n_tiles + U - 1) / U, ksplit, groups), dim3(256), lds, s, b);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles, ksplit, groups), dim3(256), lds, s, b);
   return hipGetLastError();
-}
-template <typename WT, int KTW, int PRO, int EPI>
-static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  if (a.link.done_self) return launch_dec_ch<WT, KTW, PRO, EPI, 1>(a, dtype, ksplit, groups, s);
-  return launch_dec_ch<WT, KTW, PRO, EPI, 0>(a, dtype, ksplit, groups, s);
 }
 
 template <typename WT, int KTW, int PRO, int EPI, int NTW>

@@ -494,13 +494,12 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   __shared__ int s_xs[VC_MAX_CODEBOOKS + 2];
   const int b = blockIdx.x;
   VC_TS(0);
-  link_wait(a.link);           // chained launch: the heads' logits are the predecessor's product
   float v0[VC_VPL];
   preload_row(a, blockIdx.x, v0);
   const int sw = fetch_state(a, blockIdx.x);
-  const int active = a.link.done_self ? __hip_atomic_load(a.n_active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *a.n_active;
+  const int active = *a.n_active;
   __builtin_amdgcn_sched_barrier(0);
-  if (active == 0) { link_arrive(a.link); return; }
+  if (active == 0) return;
   park_state(&s_st, sw);
   sample_phase(a, blockIdx.x, &s_st, s_xs, s_dyn, v0);
   __syncthreads();
@@ -509,7 +508,6 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   VC_TS(8);
   store_state(a, blockIdx.x, &s_st);
   VC_TS(9);
-  link_arrive(a.link);
 }
 __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
