@@ -45,7 +45,7 @@ def parse():
                    help="edit: BASELINE config 4 - one masked span in the middle of a 16 s utterance is re-generated")
     p.add_argument("--no-graph", action="store_true")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--cpu-steps", type=int, default=48, help="decode steps of the bounded CPU sample")
+    p.add_argument("--cpu-steps", type=int, default=96, help="decode steps of the bounded CPU sample")
     p.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads for the CPU baseline (capped at the core count)")
     return p.parse_args()
 
