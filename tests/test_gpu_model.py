@@ -152,6 +152,37 @@ def test_wide_batch_decode_equals_per_utterance_oracle(B, dtype):
             assert np.array_equal(got[:, :, :T], want[:, :, :T]) and np.array_equal(got[:, 0, T], want[:, 0, T])
 
 
+def test_full_size_giga830M_logits_against_oracle():
+    """BASELINE-size parity (d=2048, 16 layers, 16 heads of 128): the kernel variants only this shape
+    reaches - 16 k-tiles per wave, 12-channel QKV tiles on a 512-workgroup grid, split-K 2 and 4 slabs,
+    8 attention splits, a 2-pass prefill of 191 rows - against the CPU oracle on the first decode steps.
+    fp32 mode: head logits within 1e-3 absolute and the same arg-max; bf16 mode: relative L2 <= 2e-2."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("giga830M")
+    sd = synth.make_state_dict(a, seed=0, fast=True)
+    x, xl, y = synth.random_prompt(a, 40, 150, seed=5)
+    n = 6
+    trace = []
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
+    VoiceCraftOracle(a, sd).inference_tts(x, xl, y, top_k=1, stop_repetition=3, trace=trace, max_steps=n)
+    want = torch.stack([t["logits"][0] for t in trace]).numpy()
+    forced = torch.stack([t["tokens"] for t in trace]).numpy()
+    for dtype in ("fp32", "bf16"):
+        eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype=dtype, max_seqs=1, max_positions=512)
+        out = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3, _forced=forced, _logit_steps=len(trace))
+        got = out[2].cpu().numpy()
+        if dtype == "fp32":
+            live = np.abs(want) < 1e3
+            assert np.abs((got - want) * live).max() <= 1e-3
+            assert np.array_equal((got * live).argmax(-1), (want * live).argmax(-1))
+        else:
+            assert rel_l2(got, want).max() <= 2e-2
+        del eng
+        torch.cuda.empty_cache()
+
+
 def test_input_validation_mirrors_reference_asserts():
     eng, spec, x, x_lens, y = make_engine("tts_greedy", "bf16")
     with pytest.raises(AssertionError):
