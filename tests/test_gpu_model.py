@@ -185,6 +185,22 @@ def test_full_size_giga830M_logits_against_oracle():
         torch.cuda.empty_cache()
 
 
+def test_full_size_giga830M_batch8_equals_single_fp32():
+    """BASELINE-size batched decode (8 utterances, d=2048): per-row LayerNorm launch + 16-slot plain prologue,
+    4-split attention and its (4 x 2) merge prologue, two weight chunks per workgroup (fp32: K/16 = 128
+    k-tiles) - every utterance must reproduce its own single-utterance run token for token (fp32)."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("giga830M")
+    sd = synth.make_state_dict(a, seed=0, fast=True)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=8, max_positions=256)
+    prompts = [synth.random_prompt(a, 4 + (u % 3), 10 + 4 * (u % 5), seed=700 + u) for u in range(8)]
+    outs = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3)
+    for (xx, xl, yy), (res, gen) in zip(prompts, outs):
+        single = eng.inference_tts(xx.cuda(), xl.cuda(), yy.cuda(), top_k=1, stop_repetition=3)[0]
+        assert res.shape == single.shape and np.array_equal(res.cpu().numpy(), single.cpu().numpy())
+
+
 def test_input_validation_mirrors_reference_asserts():
     eng, spec, x, x_lens, y = make_engine("tts_greedy", "bf16")
     with pytest.raises(AssertionError):
