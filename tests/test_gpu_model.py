@@ -201,6 +201,25 @@ def test_full_size_giga830M_batch8_equals_single_fp32():
         assert res.shape == single.shape and np.array_equal(res.cpu().numpy(), single.cpu().numpy())
 
 
+def test_full_size_giga830M_two_span_edit_equals_oracle_fp32():
+    """BASELINE-size editing: rearranged prompt with two masked spans, the 3-row span switch (per-row
+    LayerNorm launch + 3-row plain prologue, 8-split attention over 3 rows) - greedy tokens equal the
+    CPU oracle's, fp32 mode."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("giga830M")
+    sd = synth.make_state_dict(a, seed=0, fast=True)
+    x, xl, y = synth.random_prompt(a, 5, 30, seed=41)
+    mi = torch.tensor([[[5, 10], [18, 24]]], dtype=torch.int64)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
+    want = VoiceCraftOracle(a, sd).inference(x, xl, y, mi, top_k=1, stop_repetition=3)
+    want = (want[0] if isinstance(want, tuple) else want).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=1, max_positions=256)
+    got = eng.inference(x.cuda(), xl.cuda(), y.cuda(), mi, top_k=1, stop_repetition=3).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 def test_input_validation_mirrors_reference_asserts():
     eng, spec, x, x_lens, y = make_engine("tts_greedy", "bf16")
     with pytest.raises(AssertionError):
