@@ -14,7 +14,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 #define VC_MAX_NSPLIT 8     // split-S factor cap of the decode attention (the out-projection prologue loads this many partials)
 #define VC_MAX_KSPLIT 4     // cross-block split-K cap of the rows-GEMM (the LN prologue prefetches this many slabs)
 #define VC_MAX_SEG 32       // prompt segments (2*spans+1 pieces + placeholders)
+#ifndef VC_TH_QKV
 #define VC_TH_QKV 12       // output channels per weight tile of the QKV projection (every other matrix: 16)
+#endif
 #define VC_VPL 34           // logits per lane in the sampler: V <= 64*34
 
 // ---------------------------------------------------------------- element types
