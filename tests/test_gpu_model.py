@@ -101,6 +101,43 @@ def test_sampling_is_seeded_and_in_range():
     assert a.shape[2] == 10 * x.shape[1] - y.shape[1]
 
 
+@pytest.mark.parametrize("top_k,top_p,temperature", [(3, 1.0, 1.0), (0, 0.35, 1.0), (8, 0.6, 0.7)])
+def test_sampled_tokens_stay_inside_the_filter_support(top_k, top_p, temperature):
+    """The device sampler (top-k threshold search, top-p mass search, inverse-CDF draw) against the
+    reference's filter semantics (models/voicecraft.py:26-68) applied to the engine's OWN logits of the
+    same step: every free-running codebook-0 token must lie in the set top_k_top_p_filtering keeps."""
+    eng, spec, x, x_lens, y = make_engine("tts_sampled", "fp32", use_graph=True)
+    n = 40
+    res, gen, lg = eng.inference_tts(x, x_lens, y, top_k=top_k, top_p=top_p, temperature=temperature,
+                                     stop_repetition=-1, _seed=123, _logit_steps=n)
+    lg = lg.cpu()
+    T = y.shape[1]
+    toks = res[0, 0, T:].cpu().numpy()                  # codebook 0 is not delayed: frame T+s comes from step s
+    steps = min(n, len(toks) - 1)
+    assert steps >= 20
+    args = eng.args
+    eos = int(args.eos)
+    term = eos if eos > 0 else int(args.eog)            # eog_inference (voicecraft.py:1016)
+    for s_ in range(steps):
+        logits = lg[s_, 0].clone()
+        if eos > 0:
+            logits[int(args.eog)] = -10000.0            # :1091-1093 (eog is never generated when eos ends the utterance)
+        if s_ <= int(args.encodec_sr) // 5:
+            logits[term] = -10000.0                     # :1024 (cur_num_gen == step while codebook 0 runs free)
+        logits = logits / temperature
+        if top_k > 0:
+            kth = torch.topk(logits, min(max(top_k, 1), logits.numel()))[0][-1]
+            logits[logits < kth] = -float("inf")
+        if top_p < 1.0:
+            sl, si = torch.sort(logits, descending=True)
+            cum = torch.cumsum(torch.softmax(sl, dim=-1), dim=-1)
+            rm = cum > top_p
+            rm[1:] = rm[:-1].clone(); rm[0] = False
+            logits[si[rm]] = -float("inf")
+        keep = set(torch.nonzero(torch.isfinite(logits)).flatten().tolist())
+        assert int(toks[s_]) in keep, (s_, int(toks[s_]), len(keep))
+
+
 def test_graph_equals_eager_bf16():
     eng, spec, x, x_lens, y = make_engine("tts_sampled", "bf16", use_graph=True)
     kn = dict(spec["knobs"])
