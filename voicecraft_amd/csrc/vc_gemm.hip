@@ -626,24 +626,37 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
 template <typename WT>
 __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   __shared__ float s_sum[4], s_sq[4];
-  if (*a.n_active == 0) return;
+  const int active = *a.n_active;
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = a.d;
   const int nq = d >> 2;
   const bool on0 = tid < nq, on1 = tid + 256 < nq;
   const int c0 = on0 ? tid * 4 : 0, c1 = on1 ? (tid + 256) * 4 : 0;
+  // every operand is requested before anything is waited for (one round trip): the row, the bias,
+  // all VC_MAX_KSPLIT slabs (unused ones are read and discarded by a select) and the LayerNorm parameters
   const float* hp = a.h_in + (long)r * d;
   float4 x0 = *reinterpret_cast<const float4*>(hp + c0), x1 = *reinterpret_cast<const float4*>(hp + c1);
-  if (a.has_prev_bias) {
-    const float4 b0 = *reinterpret_cast<const float4*>(a.prev_bias + c0), b1 = *reinterpret_cast<const float4*>(a.prev_bias + c1);
-    x0.x += b0.x; x0.y += b0.y; x0.z += b0.z; x0.w += b0.w;
-    x1.x += b1.x; x1.y += b1.y; x1.z += b1.z; x1.w += b1.w;
-  }
-  for (int s = 0; s < a.n_parts; ++s) {
+  const float4 pb0 = *reinterpret_cast<const float4*>(a.prev_bias + c0), pb1 = *reinterpret_cast<const float4*>(a.prev_bias + c1);
+  float4 p0[VC_MAX_KSPLIT], p1[VC_MAX_KSPLIT];
+#pragma unroll
+  for (int s = 0; s < VC_MAX_KSPLIT; ++s) {
     const float* pp = a.parts + ((long)(s * a.rows_cap + r)) * d;
-    const float4 p0 = *reinterpret_cast<const float4*>(pp + c0), p1 = *reinterpret_cast<const float4*>(pp + c1);
-    x0.x += p0.x; x0.y += p0.y; x0.z += p0.z; x0.w += p0.w;
-    x1.x += p1.x; x1.y += p1.y; x1.z += p1.z; x1.w += p1.w;
+    p0[s] = *reinterpret_cast<const float4*>(pp + c0);
+    p1[s] = *reinterpret_cast<const float4*>(pp + c1);
+  }
+  const float4 g0 = *reinterpret_cast<const float4*>(a.ln_w + c0), g1 = *reinterpret_cast<const float4*>(a.ln_w + c1);
+  const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + c0), b1 = *reinterpret_cast<const float4*>(a.ln_b + c1);
+  __builtin_amdgcn_sched_barrier(0);
+  if (active == 0) return;
+  if (a.has_prev_bias) {
+    x0.x += pb0.x; x0.y += pb0.y; x0.z += pb0.z; x0.w += pb0.w;
+    x1.x += pb1.x; x1.y += pb1.y; x1.z += pb1.z; x1.w += pb1.w;
+  }
+#pragma unroll
+  for (int s = 0; s < VC_MAX_KSPLIT; ++s) {
+    const bool u = s < a.n_parts;
+    x0.x += u ? p0[s].x : 0.f; x0.y += u ? p0[s].y : 0.f; x0.z += u ? p0[s].z : 0.f; x0.w += u ? p0[s].w : 0.f;
+    x1.x += u ? p1[s].x : 0.f; x1.y += u ? p1[s].y : 0.f; x1.z += u ? p1[s].z : 0.f; x1.w += u ? p1[s].w : 0.f;
   }
   const float t0 = on0 ? ((x0.x + x0.y) + (x0.z + x0.w)) : 0.f, t1 = on1 ? ((x1.x + x1.y) + (x1.z + x1.w)) : 0.f;
   const float ws = wave_sum(t0 + t1);
@@ -660,14 +673,12 @@ __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   WT* xo = reinterpret_cast<WT*>(a.x_out) + (long)r * d;
   if (on0) {
     if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (long)r * d + c0) = x0;
-    const float4 g = *reinterpret_cast<const float4*>(a.ln_w + c0), b = *reinterpret_cast<const float4*>(a.ln_b + c0);
-    f32x4 y = {dx * rstd * g.x + b.x, dy * rstd * g.y + b.y, dz * rstd * g.z + b.z, dw * rstd * g.w + b.w};
+    f32x4 y = {dx * rstd * g0.x + b0.x, dy * rstd * g0.y + b0.y, dz * rstd * g0.z + b0.z, dw * rstd * g0.w + b0.w};
     store4(xo + c0, y);
   }
   if (on1) {
     if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (long)r * d + c1) = x1;
-    const float4 g = *reinterpret_cast<const float4*>(a.ln_w + c1), b = *reinterpret_cast<const float4*>(a.ln_b + c1);
-    f32x4 y = {ex * rstd * g.x + b.x, ey * rstd * g.y + b.y, ez * rstd * g.z + b.z, ew * rstd * g.w + b.w};
+    f32x4 y = {ex * rstd * g1.x + b1.x, ey * rstd * g1.y + b1.y, ez * rstd * g1.z + b1.z, ew * rstd * g1.w + b1.w};
     store4(xo + c1, y);
   }
 }
