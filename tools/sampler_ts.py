@@ -8,10 +8,15 @@ from voicecraft_amd import synth
 from voicecraft_amd.engine import VoiceCraftEngine
 a = synth.make_args("giga830M")
 sd = synth.make_state_dict(a, seed=0, perturb=False, fast=True)
-eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=1024)
 x, xl, y = synth.random_prompt(a, 20, 150, seed=1)
+prompts = [synth.random_prompt(a, 20, 150, seed=1 + u) for u in range(B)]
 for rep in range(2):
-    eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, _seed=1)
+    if B == 1:
+        eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, _seed=1)
+    else:
+        eng.inference_tts_multi([p[0][0].cuda() for p in prompts], [p[2][0].cuda() for p in prompts], top_k=40, _seed=1)
     ts = eng.debug_read("sampler_ts", (16,), dtype=torch.int64).numpy()
     d = np.diff(ts[:10])
     names = ["load_state+rows->LDS", "logits_out/edits/argmax", "temperature+top-k", "exp/softmax(+top-p)", "draw", "cond+sync", "advance(thread0)", "embedding", "store_state"]

@@ -532,21 +532,7 @@ __global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
   store_state(a, blockIdx.x, &s_st);
 }
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
-  size_t lds = (size_t)a.K * (((a.V + 63) >> 6) << 6) * sizeof(float);
-  // Several sequences: the dispatcher packs up to four of these blocks onto one CU, where their
-  // threshold searches (pure VALU) share the SIMDs - measured 43 us at 8 sequences against 19 us at one.
-  // Asking for more than half of a CU's LDS gives every block a CU of its own.
-  if (a.B > 1) {
-    lds = std::max(lds, (size_t)96 * 1024);
-    static bool granted = false;
-    if (!granted) {
-      hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_fused_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(sample_only_k), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e1 != hipSuccess) return e1;
-      if (e2 != hipSuccess) return e2;
-      granted = true;
-    }
-  }
+  const size_t lds = (size_t)a.K * (((a.V + 63) >> 6) << 6) * sizeof(float);
   if (!grouped) {
     hipLaunchKernelGGL(sample_fused_k, dim3(a.B), dim3(256), lds, s, a);
   } else {
