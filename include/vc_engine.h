@@ -79,6 +79,9 @@ typedef struct vc_sample_cfg {
   uint64_t seed;            /* Philox key; stream = (seed, sequence, step, codebook) */
   int32_t use_graph;        /* 1: replay the decode step as a captured hipGraph */
   int32_t poll_every;       /* host polls the done flag every N steps (0 = default 16) */
+  int32_t forced_mode;      /* parity hook, meaning of forced_dev: 0 = the step's FINAL tokens (teacher forcing
+                             * for logits parity); 1 = the raw draws of topk_sampling (models/voicecraft.py:1033):
+                             * the state machine - overrides, termination, best-of-N keep - runs on them */
 } vc_sample_cfg;
 
 /* ---- lifecycle ---------------------------------------------------------- */
@@ -103,11 +106,11 @@ int vc_finalize_weights(vc_engine* e, int compute_dtype);
  * whose first codebook terminates first is kept).
  *   x_dev      int64 [Lx]            phoneme ids
  *   y_dev      int64 [T][K]          prompt codes, time-major exactly as the caller's y[0]
- *   forced_dev int64 [n_forced][K]   optional teacher-forcing trajectory (parity hook): the
- *                                    step's final tokens are replaced by these; NULL = sample
+ *   forced_dev int64 [n_forced][B][K] optional teacher-forcing trajectory (parity hook, see
+ *                                    vc_sample_cfg.forced_mode; B = n_samples); NULL = sample
  *   res_dev    int64 [K][res_cap]    out: prompt followed by generated frames (row stride res_cap)
  *   gen_len    out (host): number of generated frames Tg; res holds T+Tg columns
- *   logits_dev float [logit_steps][K][V] optional: raw head outputs of the first steps
+ *   logits_dev float [logit_steps][B][K][V] optional: raw head outputs of the first steps
  *   n_steps    out (host, optional): decode steps taken (Tg + K)                       */
 int vc_tts(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, int T,
            const vc_sample_cfg* sc, int n_samples, const int64_t* forced_dev, int n_forced,
@@ -117,10 +120,12 @@ int vc_tts(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, int
 /* ---- multi-utterance TTS (SURVEY.md §8f-1 / BASELINE config 5): B independent
  * (x, y) pairs decoded as one batch; each row follows inference_tts exactly.
  *   x_dev int64 [sum Lx], y_dev int64 [sum T][K] concatenated; *_off host arrays [B+1].
- *   res_dev int64 [B][K][res_cap]; gen_len host [B]. */
+ *   res_dev int64 [B][K][res_cap]; gen_len host [B].
+ *   forced_dev / logits_dev: as in vc_tts, indexed by each sequence's own step count. */
 int vc_tts_multi(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_off,
                  const int64_t* y_dev, const int32_t* y_off, const vc_sample_cfg* sc,
-                 int64_t* res_dev, int res_cap, int* gen_len, int* n_steps, void* stream);
+                 const int64_t* forced_dev, int n_forced, int64_t* res_dev, int res_cap, int* gen_len,
+                 float* logits_dev, int logit_steps, int* n_steps, void* stream);
 
 /* ---- speech editing: VoiceCraft.inference (models/voicecraft.py:561-906).
  *   mask_intervals host int32 [M][2] (codec-frame units, as mask_interval[0])
@@ -144,6 +149,11 @@ int vc_pattern_revert(const int64_t* s_dev, int B, int K, int S, int T, int64_t 
 int vc_pattern_unshift(const int64_t* span_dev, int N, int K, int64_t* out_dev, void* stream);
 
 /* ---- parity/debug hooks (tests only) ------------------------------------ */
+/* n_draws independent draws from one logits row [V] through the product sampler (temperature, top-k,
+ * top-p, inverse-CDF on a Philox stream; models/voicecraft.py:26-86): out_dev int32 [n_draws].
+ * Only top_k / top_p / temperature / seed of `sc` are read.  No engine needed. */
+int vc_debug_sample(const float* logits_dev, int V, const vc_sample_cfg* sc, int n_draws,
+                    int32_t* out_dev, void* stream);
 /* Copies a named internal device buffer to host memory. */
 int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int64_t nbytes);
 /* Timing of the last vc_tts/vc_edit call, measured with HIP events on `stream`:

@@ -58,15 +58,73 @@ MODEL_CASES = {
                                knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
     "edit_sampled": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(8, 60, 16), mode="edit", spans=[(20, 31)], tseed=99,
                          knobs=dict(top_k=30, top_p=0.8, temperature=1.0, stop_repetition=2, kvcache=1)),
+    # ---- round 2: the terminator is NOT muted (sd_kw), so the end-of-generation branches fire
+    # (voicecraft.py:1024 min-length guard, :1041-1045 sampled / arg-max terminator, :1027-1031 silence penalty,
+    #  :1296-1302 best-of-N keep).  `boost` = (codebook, token, delta) added to the head bias.
+    "tts_eos_guard": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(8, 21, 31), mode="tts",          # terminator wins at once:
+                          sd_kw=dict(mute_eos=False, boost=[(0, 2051, 8.0)]),                        # ends when the guard releases
+                          knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1)),
+    "tts_eos_greedy": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(8, 21, 31), mode="tts",
+                           sd_kw=dict(mute_eos=False, boost=[(0, 2051, 0.4)]),                       # ends somewhere in the middle
+                           knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1)),
+    "tts_oldscheme_eog": dict(preset="tiny", arg_kw=dict(eos=-1, n_special=3, reduced_eog=0), wseed=4, prompt=(7, 19, 32),
+                              mode="tts", sd_kw=dict(mute_eos=False, boost=[(0, 2049, 0.62)]),
+                              knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
+    "tts_silence_sr1": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(6, 15, 33), mode="tts",
+                            sd_kw=dict(mute_eos=True, boost=[(0, 131, 1.2)]),
+                            knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=1, kvcache=1)),
+    "tts_silence_sr2": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(6, 15, 33), mode="tts",
+                            sd_kw=dict(mute_eos=True, boost=[(0, 131, 1.2)]),
+                            knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1)),
+    "tts_silence_sr3": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(6, 15, 33), mode="tts",
+                            sd_kw=dict(mute_eos=False, boost=[(0, 1388, 1.2), (0, 2051, 0.5)]),
+                            knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1,
+                                       silence_tokens=[1388, 1898, 131])),
+    "edit_eog_greedy": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(9, 64, 34), mode="edit", spans=[(10, 18), (40, 47)],
+                            sd_kw=dict(mute_eos=False, boost=[(0, 2049, 0.55)]),
+                            knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=2, kvcache=1)),
+    "edit_eog_oldscheme": dict(preset="tiny", arg_kw=dict(eos=-1, n_special=3, reduced_eog=0), wseed=4, prompt=(8, 55, 35),
+                               mode="edit", spans=[(15, 25)], sd_kw=dict(mute_eos=False, boost=[(0, 2049, 0.45)]),
+                               knobs=dict(top_k=1, top_p=1.0, temperature=1.0, stop_repetition=-1, kvcache=1)),
+    # sampled runs: the reference's own draws are recorded (`draws`) and replayed through the device
+    # state machine (vc_sample_cfg.forced_mode = draws), so everything but the RNG stream is compared
+    "tts_sampled_eos": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(9, 30, 36), mode="tts", tseed=4321,
+                            sd_kw=dict(mute_eos=False, boost=[(0, 2051, 1.5), (0, 131, 4.0)]),
+                            knobs=dict(top_k=40, top_p=0.9, temperature=0.8, stop_repetition=1, kvcache=1)),
+    "tts_batch4_sampled": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(9, 30, 37), mode="tts_batch", tseed=777,
+                               sd_kw=dict(mute_eos=False, boost=[(0, 2051, 3.0), (0, 131, 4.0)]),
+                               knobs=dict(top_k=0, top_p=0.95, temperature=1.0, stop_repetition=2, kvcache=1, batch_size=4)),
+    "tts_batch3_sampled_b": dict(preset="tiny", arg_kw={}, wseed=5, prompt=(8, 25, 38), mode="tts_batch", tseed=778,
+                                 sd_kw=dict(mute_eos=False, boost=[(0, 700, 4.0), (0, 2051, 2.2)]),
+                                 knobs=dict(top_k=20, top_p=1.0, temperature=1.3, stop_repetition=3, kvcache=1, batch_size=3)),
+    "edit_sampled_eog": dict(preset="tiny", arg_kw={}, wseed=3, prompt=(8, 60, 39), mode="edit", spans=[(12, 20), (30, 41)], tseed=98,
+                             sd_kw=dict(mute_eos=False, boost=[(0, 500, 3.0), (0, 2049, 2.0)]),
+                             knobs=dict(top_k=30, top_p=0.8, temperature=1.0, stop_repetition=2, kvcache=1)),
 }
+
+
+def case_state_dict(spec, args):
+    """The synthetic checkpoint of a golden case (shared with tests/_util.py)."""
+    kw = dict(mute_eos=True)
+    kw.update(spec.get("sd_kw", {}))
+    return synth.make_state_dict(args, seed=spec["wseed"], perturb=True, **kw)
 
 
 def run_reference_case(spec):
     args = synth.make_args(spec["preset"], **spec["arg_kw"])
-    # un-muted terminator for the early-stop / editing cases would end generation at random places;
-    # keep it muted everywhere so lengths are set by the reference's own cap
-    sd = synth.make_state_dict(args, seed=spec["wseed"], perturb=True, mute_eos=True)
+    # round-1 cases mute the terminator (lengths set by the reference's own cap, BASELINE.md §4.2);
+    # the round-2 cases un-mute it through spec["sd_kw"]
+    sd = case_state_dict(spec, args)
     model = ref_loader.build_reference_model(args, sd)
+    vc_mod, _ = ref_loader.import_reference()
+    draws = []
+    orig_sampling = vc_mod.topk_sampling
+
+    def recording_sampling(*a, **k):          # the reference's raw draws, before the state machine's overrides
+        o = orig_sampling(*a, **k)
+        draws.append(o.detach().clone().reshape(-1))
+        return o
+    vc_mod.topk_sampling = recording_sampling
     Lx, T, pseed = spec["prompt"]
     x, x_lens, y = synth.random_prompt(args, Lx, T, seed=pseed)
     captured = []
@@ -90,7 +148,9 @@ def run_reference_case(spec):
             out["mask_interval"] = mi.numpy()
     for h in hooks:
         h.remove()
+    vc_mod.topk_sampling = orig_sampling
     K = args.n_codebooks
+    out["draws"] = torch.stack(draws).reshape(len(draws), -1, K).numpy().astype(np.int64)      # [steps,B,K]
     steps = len(captured) // K
     lg = torch.stack([torch.stack([captured[s * K + k] for k in range(K)], dim=0) for s in range(steps)], dim=0)
     lg = lg.reshape(steps, K, -1, lg.shape[-1])          # [steps,K,B,V]

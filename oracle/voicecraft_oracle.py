@@ -156,8 +156,11 @@ class VoiceCraftOracle:
 
     # ---- the shared generation loop
     def _run(self, x, cols0, mask_cols, *, mode, more_mask, n_spans, B, top_k, top_p, temperature,
-             stop_repetition, kvcache, silence_tokens, trace, forced=None, max_steps=None):
+             stop_repetition, kvcache, silence_tokens, trace, forced=None, max_steps=None, forced_draws=None):
         """x [1,Lx]; cols0 [K,S0] prompt columns; mask_cols {col: mask_embedding row}.
+        forced [steps][K]: the step's FINAL tokens are replaced (teacher forcing for logits parity);
+        forced_draws [steps][B][K]: the raw draws of topk_sampling are replaced and the state machine
+        (overrides, termination, keep) runs on them - the replay of a recorded reference run.
         Returns (spans: list of [N,K] int arrays per finished span, kept sample index)."""
         K, V = self.K, self.V
         tts = mode == "tts"
@@ -220,6 +223,8 @@ class VoiceCraftOracle:
                             logits[b, 0, prev[b]] = logits[b, 0, prev[b]] / f
             flat = logits.reshape(B * K, V) if grouped else logits[0]
             samples = draw(flat, top_k, top_p, temperature).reshape(B, K)
+            if forced_draws is not None:
+                samples = torch.as_tensor(np.asarray(forced_draws[step]), dtype=samples.dtype).reshape(B, K).clone()
             if n_eog == 0:
                 for b in range(B):
                     for jj in range(1, K - cur_num_gen):
@@ -279,7 +284,7 @@ class VoiceCraftOracle:
     @torch.no_grad()
     def inference_tts(self, x, x_lens, y, top_k=-100, top_p=1.0, temperature=1.0, stop_repetition=3,
                       kvcache=1, silence_tokens=(1388, 1898, 131), batch_size=1, trace=None, forced=None,
-                      max_steps=None):
+                      max_steps=None, forced_draws=None):
         assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3
         if self.special_first:
             y = y + self.n_special
@@ -292,7 +297,7 @@ class VoiceCraftOracle:
         spans, _ = self._run(x, cols, {}, mode="tts", more_mask=[], n_spans=1, B=batch_size, top_k=top_k,
                              top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
                              kvcache=kvcache, silence_tokens=list(silence_tokens), trace=trace, forced=forced,
-                             max_steps=max_steps)
+                             max_steps=max_steps, forced_draws=forced_draws)
         if spans is None:
             return None, None
         gen = torch.from_numpy(unshift_span(spans[0]))                       # [K,Tg]
@@ -301,10 +306,35 @@ class VoiceCraftOracle:
             res, gen = res - self.n_special, gen - self.n_special
         return res, gen.unsqueeze(0)
 
+    @torch.no_grad()
+    def tts_logits_for_trajectory(self, x, y, tokens, steps=None):
+        """Raw head logits [len(steps),K,V] that inference_tts sees at the given decode steps when the
+        emitted tokens are forced to `tokens` [N,K] - computed in ONE full causal pass over
+        [x ; prompt columns ; tokens] (the no-cache form of dec_forward, voicecraft.py:449-453; equal
+        to the cached path by SURVEY.md §8c-2 and tests/test_oracle_golden.py).  Step s reads the hidden
+        state of audio position T + s (the last prompt column for s = 0).  This is how long contexts at
+        full model size are checked in seconds instead of minutes."""
+        if self.special_first:
+            y = y + self.n_special
+        yk = y.transpose(2, 1)
+        T = yk.shape[2]
+        cols = delayed_shift(yk.numpy(), self.empty)[0][:, :T + 1]
+        cols = torch.from_numpy(np.ascontiguousarray(cols))
+        tok = torch.as_tensor(np.asarray(tokens), dtype=torch.long).reshape(-1, self.K)
+        steps = list(range(tok.shape[0] + 1)) if steps is None else list(steps)
+        n_tok = max(steps)                                   # step s needs tokens 0..s-1
+        allc = torch.cat([cols, tok[:n_tok].t().contiguous()], dim=1)            # [K, T+1+n_tok]
+        x_in = self._pos(F.embedding(x, self.sd["text_embedding.word_embeddings.weight"]), "text")
+        y_in = self._pos(self._embed_cols(allc.unsqueeze(-1)), "audio")
+        Lx, S = x.size(1), x.size(1) + y_in.size(1)
+        out, _ = self._stack(torch.cat([x_in, y_in], dim=1), self._causal_rows(1, S, S), None)
+        rows = out[:, [Lx + T + s for s in steps]]                                # [1,n,d]
+        return torch.stack([self._heads(rows[:, i:i + 1])[0] for i in range(rows.size(1))], dim=0)
+
     def inference_tts_batch(self, x, x_lens, y, top_k=-100, top_p=1.0, temperature=1.0, stop_repetition=3,
-                            kvcache=1, batch_size=5, silence_tokens=(1388, 1898, 131), trace=None):
+                            kvcache=1, batch_size=5, silence_tokens=(1388, 1898, 131), trace=None, forced_draws=None):
         return self.inference_tts(x, x_lens, y, top_k, top_p, temperature, stop_repetition, kvcache,
-                                  silence_tokens, batch_size=batch_size, trace=trace)
+                                  silence_tokens, batch_size=batch_size, trace=trace, forced_draws=forced_draws)
 
     def edit_layout(self, T: int, intervals: list[tuple[int, int]], mask_value: list[int]):
         """Pieces of the rearranged sequence (voicecraft.py:618-679).  Returns
@@ -330,7 +360,7 @@ class VoiceCraftOracle:
     @torch.no_grad()
     def inference(self, x, x_lens, y, mask_interval, top_k=-100, top_p=1.0, temperature=1.0,
                   stop_repetition=-1, kvcache=1, silence_tokens=(1388, 1898, 131), trace=None,
-                  mask_value=None, forced=None):
+                  mask_value=None, forced=None, forced_draws=None):
         assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3
         if self.special_first:
             y = y + self.n_special
@@ -363,7 +393,8 @@ class VoiceCraftOracle:
         assert not (cols == self.pad).any()
         spans, _ = self._run(x, cols, mask_cols, mode="edit", more_mask=mask_value[M + 1:], n_spans=M, B=1,
                              top_k=top_k, top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
-                             kvcache=kvcache, silence_tokens=list(silence_tokens), trace=trace, forced=forced)
+                             kvcache=kvcache, silence_tokens=list(silence_tokens), trace=trace, forced=forced,
+                             forced_draws=forced_draws)
         out = []
         for (s, e), sp in zip(non_mask, spans):
             out.append(yk[0, :, s:e])

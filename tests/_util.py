@@ -6,7 +6,7 @@ import os
 import numpy as np
 import torch
 
-from oracle.gen_golden import MODEL_CASES  # specs only; importing this module does not touch /root/reference
+from oracle.gen_golden import MODEL_CASES, case_state_dict  # specs only; importing this module does not touch /root/reference
 from oracle.voicecraft_oracle import VoiceCraftOracle
 from voicecraft_amd import synth
 
@@ -21,7 +21,7 @@ def build_case(name: str):
     """(spec, args, state_dict, x, x_lens, y) of a golden model case, regenerated from seeds."""
     spec = MODEL_CASES[name]
     args = synth.make_args(spec["preset"], **spec["arg_kw"])
-    sd = synth.make_state_dict(args, seed=spec["wseed"], perturb=True, mute_eos=True)
+    sd = case_state_dict(spec, args)
     Lx, T, pseed = spec["prompt"]
     x, x_lens, y = synth.random_prompt(args, Lx, T, seed=pseed)
     return spec, args, sd, x, x_lens, y

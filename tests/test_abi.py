@@ -45,8 +45,10 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 def test_struct_layout_matches_header():
     from voicecraft_amd._lib import ModelCfg, SampleCfg
     assert C.sizeof(ModelCfg) == 17 * 4
-    # int32 top_k, float top_p, float temperature, int32 stop_repetition, int32 n_silence, int32[8], (pad) u64 seed, 2x int32
-    assert SampleCfg.seed.offset % 8 == 0 and C.sizeof(SampleCfg) == SampleCfg.seed.offset + 8 + 8
+    # int32 top_k, float top_p, float temperature, int32 stop_repetition, int32 n_silence, int32[8], (pad) u64 seed,
+    # 3x int32 (use_graph, poll_every, forced_mode) + tail padding to the 8-byte alignment of the struct
+    assert SampleCfg.seed.offset % 8 == 0 and C.sizeof(SampleCfg) == SampleCfg.seed.offset + 8 + 16
+    assert SampleCfg.forced_mode.offset == SampleCfg.seed.offset + 16
 
 
 def test_no_device_fails_loudly(lib):

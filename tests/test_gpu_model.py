@@ -34,17 +34,56 @@ def make_engine(name, dtype, **kw):
     return eng, spec, x.cuda(), x_lens.cuda(), y.cuda()
 
 
-def engine_run(eng, spec, x, x_lens, y, forced=None, logit_steps=0, seed=1):
+def engine_run(eng, spec, x, x_lens, y, forced=None, logit_steps=0, seed=1, forced_mode="tokens"):
     kn = dict(spec["knobs"])
     if spec["mode"] == "tts":
-        out = eng.inference_tts(x, x_lens, y, **kn, _forced=forced, _logit_steps=logit_steps, _seed=seed)
+        out = eng.inference_tts(x, x_lens, y, **kn, _forced=forced, _logit_steps=logit_steps, _seed=seed, _forced_mode=forced_mode)
         return (out[0], out[2]) if logit_steps else (out[0], None)
     if spec["mode"] == "tts_batch":
-        out = eng.inference_tts_batch(x, x_lens, y, **kn, _seed=seed)
+        out = eng.inference_tts_batch(x, x_lens, y, **kn, _seed=seed, _forced=forced, _forced_mode=forced_mode)
         return out[0], None
     mi = torch.tensor([spec["spans"]], dtype=torch.int64)
-    out = eng.inference(x, x_lens, y, mi, **kn, _forced=forced, _logit_steps=logit_steps, _seed=seed)
+    out = eng.inference(x, x_lens, y, mi, **kn, _forced=forced, _logit_steps=logit_steps, _seed=seed, _forced_mode=forced_mode)
     return (out[0], out[1]) if logit_steps else (out, None)
+
+
+SAMPLED = sorted(n for n, s_ in MODEL_CASES.items() if "tseed" in s_)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("name", SAMPLED)
+def test_fp32_replay_of_reference_draws_equals_reference(name, graph):
+    """Sampled reference runs (top-k / top-p / temperature, UN-muted terminator, best-of-N with four
+    different samples): the reference's recorded raw draws are fed to the device state machine
+    (forced_mode = draws), which must turn them into exactly the reference's result - the K-1 `empty`
+    overrides, the sampled / arg-max / length-cap terminator, the min-length guard, the silence
+    bookkeeping, the staggered EOG tail, the keep-LAST rule of inference_tts_batch and the drop of the
+    other samples (models/voicecraft.py:1018-1067, :1269-1325, :718-787)."""
+    g = load_golden(name)
+    eng, spec, x, x_lens, y = make_engine(name, "fp32", use_graph=graph)
+    res, _ = engine_run(eng, spec, x, x_lens, y, forced=g["draws"], forced_mode="draws", seed=99)
+    assert list(res.shape) == list(g["res"].shape), (res.shape, g["res"].shape)
+    assert np.array_equal(res.cpu().numpy(), g["res"])
+
+
+def test_best_of_n_keeps_the_last_terminating_sample():
+    """Hand-made draws for inference_tts_batch(batch_size=4): samples 1 and 2 both emit the terminator at
+    step 12 (sample 0 and 3 do not): the reference keeps the LAST of them (`keep = b` overwritten in order,
+    models/voicecraft.py:1296-1302).  Checked against the oracle replaying the same draws, fp32."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    name = "tts_batch4_sampled"
+    eng, spec, x, x_lens, y = make_engine(name, "fp32", use_graph=True)
+    _, args, sd, xc, xlc, yc = build_case(name)
+    K, B, n = 4, 4, 24
+    rs = np.random.RandomState(5)
+    draws = rs.randint(0, 2048, size=(n, B, K)).astype(np.int64)
+    draws[12, 1, 0] = draws[12, 2, 0] = int(args.eos)
+    kn = dict(spec["knobs"])
+    want = VoiceCraftOracle(args, sd).inference_tts_batch(xc, xlc, yc, forced_draws=draws, **kn)[0].numpy()
+    got = eng.inference_tts_batch(x, x_lens, y, **kn, _forced=draws, _forced_mode="draws", _seed=1)[0].cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+    T = yc.shape[1]
+    assert got.shape[2] == T + 12 and np.array_equal(got[0, 0, T:], draws[:12, 2, 0])     # sample 2's trajectory
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -306,3 +345,92 @@ def test_bf16_long_edit_prefill_teacher_forced():
     assert np.array_equal(res.cpu().numpy(), want_res.numpy())
     rel = rel_l2(lg.cpu().numpy(), want)
     assert rel.max() <= 2e-2, rel.max()
+
+
+def test_bf16_long_context_at_the_benchmark_shape_tiny128():
+    """The benchmarked sequence geometry (Lx 80, 150 prompt frames -> 650 generated, 654 graph-replayed
+    steps, final context 884 positions) on the 2-layer hd-128 model: bf16 logits of EVERY step, teacher-forced
+    on the oracle's own trajectory, within 2e-2 relative L2 - named check points 0 / 100 / 300 / 500 / 653."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("tiny128")
+    sd = synth.make_state_dict(a, seed=12)
+    x, xl, y = synth.random_prompt(a, 80, 150, seed=2)
+    trace = []
+    res_o, gen_o = VoiceCraftOracle(a, sd).inference_tts(x, xl, y, top_k=1, stop_repetition=3, trace=trace)
+    assert gen_o.shape[2] == 650 and len(trace) == 654
+    want = torch.stack([t["logits"][0] for t in trace]).numpy()
+    forced = torch.stack([t["tokens"] for t in trace]).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024, use_graph=True)
+    res, gen, lg = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3, _forced=forced, _logit_steps=654)
+    assert np.array_equal(res.cpu().numpy(), res_o.numpy())
+    rel = rel_l2(lg.cpu().numpy(), want)
+    assert rel.max() <= 2e-2, {s_: float(rel[s_]) for s_ in (0, 100, 300, 500, 653)}
+    # free-running, sampled, as bench.py runs it: exactly 650 frames of plain codes
+    gen = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, stop_repetition=3, _seed=5)[1].cpu().numpy()
+    assert gen.shape == (1, 4, 650) and gen.min() >= 0 and gen.max() < 2048
+
+
+def test_full_size_giga830M_long_context_bench_shape():
+    """BASELINE config 3 itself: giga830M, bf16, Lx 80, 150 -> 650 frames, hipGraph replay, 654 steps to a
+    context of 884 positions (16 heads x 128, 8 attention splits over up to 111 positions each).  A random
+    token trajectory is forced; the oracle evaluates it in ONE causal pass (tts_logits_for_trajectory) and the
+    engine's logits at steps 0 / 100 / 300 / 500 / 653 must agree within 2e-2 relative L2.  Then the
+    free-running top-k 40 run of bench.py: exactly 650 frames, every id a plain code."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("giga830M")
+    sd = synth.make_state_dict(a, seed=0, fast=True)
+    x, xl, y = synth.random_prompt(a, 80, 150, seed=1)
+    K, n = 4, 654
+    rs = np.random.RandomState(3)
+    toks = rs.randint(0, 2048, size=(n, K)).astype(np.int64)
+    for j in range(K):                                   # the staggered end of the span (steps 650..653)
+        toks[650 + j, :j] = a.empty_token
+        toks[650 + j, j] = a.eos
+    steps = [0, 100, 300, 500, 653]
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
+    want = VoiceCraftOracle(a, sd).tts_logits_for_trajectory(x, y, toks, steps=steps).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024, use_graph=True)
+    res, gen, lg = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, stop_repetition=3, _forced=toks, _logit_steps=n)
+    assert gen.shape[2] == 650 and eng.last_steps >= 654
+    got = lg.cpu().numpy()[steps]
+    rel = rel_l2(got, want)
+    assert rel.max() <= 2e-2, dict(zip(steps, rel.tolist()))
+    gen = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, stop_repetition=3, _seed=11)[1].cpu().numpy()
+    assert gen.shape == (1, 4, 650) and gen.min() >= 0 and gen.max() < 2048
+
+
+@pytest.mark.parametrize("B", [8, 12])
+def test_bf16_batched_decode_logits_per_sequence(B):
+    """bf16 batched decode (per-row LayerNorm launch, 16-slot plain prologue, 4- and 2-split attention merges):
+    every sequence of a ragged batch is teacher-forced on ITS OWN oracle trajectory and its per-step head
+    logits must stay within 2e-2 relative L2 of the fp32 oracle."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("tiny_h16")
+    sd = synth.make_state_dict(a, seed=4)
+    prompts = [synth.random_prompt(a, 4 + (u % 5), 9 + 3 * (u % 7), seed=300 + u) for u in range(B)]
+    orc = VoiceCraftOracle(a, sd)
+    traces, want_res = [], []
+    for (xx, xl, yy) in prompts:
+        tr = []
+        want_res.append(orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3, trace=tr)[0].numpy())
+        traces.append(tr)
+    n = max(len(t) for t in traces)
+    forced = np.zeros((n, B, 4), dtype=np.int64)
+    for b, tr in enumerate(traces):
+        forced[: len(tr), b] = torch.stack([t["tokens"] for t in tr]).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256)
+    outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3,
+                                       _forced=forced, _logit_steps=n)
+    lg = lg.cpu().numpy()
+    worst = 0.0
+    for b, tr in enumerate(traces):
+        assert np.array_equal(outs[b][0].cpu().numpy(), want_res[b])
+        want = torch.stack([t["logits"][0] for t in tr]).numpy()
+        worst = max(worst, float(rel_l2(lg[: len(tr), b], want).max()))
+    assert worst <= 2e-2, worst

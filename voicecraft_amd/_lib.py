@@ -25,7 +25,7 @@ class SampleCfg(C.Structure):
         ("top_k", C.c_int32), ("top_p", C.c_float), ("temperature", C.c_float),
         ("stop_repetition", C.c_int32), ("n_silence", C.c_int32),
         ("silence_tokens", C.c_int32 * VC_MAX_SILENCE), ("seed", C.c_uint64),
-        ("use_graph", C.c_int32), ("poll_every", C.c_int32),
+        ("use_graph", C.c_int32), ("poll_every", C.c_int32), ("forced_mode", C.c_int32),
     ]
 
 
@@ -41,7 +41,9 @@ PROTOTYPES = {
                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int,
                          C.POINTER(C.c_int), C.c_void_p]),
     "vc_tts_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32),
-                               C.POINTER(SampleCfg), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_void_p]),
+                               C.POINTER(SampleCfg), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                               C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
+    "vc_debug_sample": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SampleCfg), C.c_int, C.c_void_p, C.c_void_p]),
     "vc_edit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int,
                           C.POINTER(C.c_int32), C.POINTER(SampleCfg), C.c_void_p, C.c_int, C.c_void_p, C.c_int,
                           C.POINTER(C.c_int), C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),

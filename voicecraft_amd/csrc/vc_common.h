@@ -295,9 +295,10 @@ struct SampleArgs {
   int* amax;                // scratch [B]
   int* gen;                 // [B][max_steps][K]
   int max_steps;
-  const int64_t* forced;    // [n_forced][K] or null
+  const int64_t* forced;    // [n_forced][B][K] or null
   int n_forced;
-  float* logits_out;        // [logit_steps][K][V] or null (sequence 0 only)
+  int forced_mode;          // 0: the step's final tokens are replaced; 1: the raw draws are replaced (vc_sample_cfg.forced_mode)
+  float* logits_out;        // [logit_steps][B][K][V] or null
   int logit_steps;
   // next-step rows
   int rps;                  // rows per sequence slot (1, or 3 for editing)

@@ -1,6 +1,7 @@
 // vc_tokens.hip — the integer side of the path: delayed-codebook pattern kernels, prompt
 // construction (+ embedding gather), the device-side sampler / end-of-generation state machine
 // and the output assembly.  Everything here that produces token ids is bit-exact by contract.
+#include <string.h>
 #include <algorithm>
 #include "vc_common.h"
 
@@ -174,6 +175,98 @@ __device__ __forceinline__ void preload_row(const SampleArgs& a, int b, float (&
 #pragma unroll
   for (int j = 0; j < VC_VPL; ++j) v0[j] = row[min(lane + 64 * j, a.V - 1)];   // all loads in flight together
 }
+// temperature -> top-k -> softmax -> top-p -> inverse-CDF draw for the row a wave holds in registers
+// (v: edited logits, padding -inf; bv: their maximum; u: the uniform of this draw).  Wave-uniform result.
+__device__ __forceinline__ int filter_draw(const SampleArgs& a, int b, float (&v)[VC_VPL], float bv, int V, float u) {
+  const int lane = threadIdx.x & 63;
+  // ---- temperature
+  float mx = bv;
+  if (a.temperature != 1.0f) {
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) v[j] = v[j] / a.temperature;
+    mx = bv / a.temperature;                      // filters never remove the maximum
+  }
+  // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive).
+  // Bitwise binary search for the k-th largest order-preserving key, on registers.
+  if (a.top_k > 0) {
+    const int kk = min(max(a.top_k, 1), V);
+    uint32_t key[VC_VPL];
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) key[j] = fkey(v[j]);       // padding: key(-inf) = 0x007fffff, below every finite key
+    uint32_t t = 0;
+#pragma unroll 1
+    for (int bit = 31; bit >= 0; --bit) {
+      const uint32_t cand = t | (1u << bit);
+      int c = 0;
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) c += (key[j] >= cand) ? 1 : 0;
+      const int cs = wave_sum_i(c);
+      if (cs >= kk) {
+        t = cand;
+        if (cs == kk) break;        // exactly the kk largest keys are >= t already: the remaining bits cannot change the kept set
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) v[j] = (key[j] < t) ? -INFINITY : v[j];
+  }
+  VC_TS(3);
+  // ---- softmax numerators (v now holds p >= 0; 0 = filtered out)
+  float ps = 0.f;
+#pragma unroll
+  for (int j = 0; j < VC_VPL; ++j) { v[j] = __expf(v[j] - mx); ps += v[j]; }        // exp(-inf) = 0
+  float tot = wave_sum(ps);
+  // ---- top-p: drop a token when the mass of the strictly larger ones already exceeds top_p.
+  // p is monotone in the logit, and the bits of a non-negative float order like the float.
+  if (a.top_p < 1.0f) {
+    const float lim = a.top_p * tot;
+    // t = the largest key whose strictly-larger mass still exceeds lim (key 0 always qualifies:
+    // the whole row weighs tot > lim); exactly the keys <= t are dropped.
+    uint32_t t = 0;
+#pragma unroll 1
+    for (int bit = 30; bit >= 0; --bit) {
+      const uint32_t cand = t | (1u << bit);
+      float mm = 0.f;
+#pragma unroll
+      for (int j = 0; j < VC_VPL; ++j) mm += (__float_as_uint(v[j]) > cand) ? v[j] : 0.f;
+      if (wave_sum(mm) > lim) t = cand;
+    }
+    ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) { v[j] = (__float_as_uint(v[j]) <= t) ? 0.f : v[j]; ps += v[j]; }
+    tot = wave_sum(ps);
+  }
+  VC_TS(4);
+  // ---- categorical draw by inverse CDF, order = (lane, j)
+  const float target = u * tot;
+  float incl = ps;
+  for (int off = 1; off < 64; off <<= 1) {
+    const float o = __shfl_up(incl, off, 64);
+    if (lane >= off) incl += o;
+  }
+  const float excl = incl - ps;
+  const bool mine = (ps > 0.f) && (target >= excl) && (target < incl);
+  const uint64_t ball = __ballot(mine);
+  int src_lane;
+  if (ball) src_lane = __ffsll((long long)ball) - 1;
+  else {     // rounding put target at/after the end: take the last lane with mass
+    const uint64_t nz = __ballot(ps > 0.f);
+    src_lane = nz ? 63 - __clzll((long long)nz) : 0;
+  }
+  // every lane walks its own elements (cheap, branch-free); the owner's result is broadcast
+  float acc = excl;
+  int pick = -1, last = -1;
+#pragma unroll
+  for (int j = 0; j < VC_VPL; ++j) {
+    const bool nz = v[j] > 0.f;
+    acc += v[j];
+    last = nz ? lane + 64 * j : last;
+    pick = (pick < 0 && nz && target < acc) ? lane + 64 * j : pick;
+  }
+  int tok = (pick >= 0) ? pick : last;
+  tok = __shfl(tok, src_lane, 64);
+  return tok;
+}
+
 __device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int* xs, float* s_rows,
                                              const float (&v0)[VC_VPL]) {
   const SeqState st = *sp;
@@ -193,8 +286,8 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const S
 #pragma unroll
       for (int j = 0; j < VC_VPL; ++j) v[j] = row[min(lane + 64 * j, V - 1)];
     }
-    if (a.logits_out && b == 0 && step < a.logit_steps) {
-      float* lo = a.logits_out + ((long)step * a.K + k) * V;
+    if (a.logits_out && step < a.logit_steps) {
+      float* lo = a.logits_out + (((long)step * a.B + b) * a.K + k) * V;
 #pragma unroll
       for (int j = 0; j < VC_VPL; ++j) if (lane + 64 * j < V) lo[lane + 64 * j] = v[j];
     }
@@ -234,92 +327,10 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const S
     for (int j = VC_VPL - 1; j >= 0; --j) bi = (v[j] == bv) ? lane + 64 * j : bi;     // padding is -inf, never equal
     bi = wave_min_i(bi);
     VC_TS(2);
-    // ---- temperature
-    float mx = bv;
-    if (a.temperature != 1.0f) {
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) v[j] = v[j] / a.temperature;
-      mx = bv / a.temperature;                      // filters never remove the maximum
-    }
-    // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive).
-    // Bitwise binary search for the k-th largest order-preserving key, on registers.
-    if (a.top_k > 0) {
-      const int kk = min(max(a.top_k, 1), V);
-      uint32_t key[VC_VPL];
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) key[j] = fkey(v[j]);       // padding: key(-inf) = 0x007fffff, below every finite key
-      uint32_t t = 0;
-#pragma unroll 1
-      for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = t | (1u << bit);
-        int c = 0;
-#pragma unroll
-        for (int j = 0; j < VC_VPL; ++j) c += (key[j] >= cand) ? 1 : 0;
-        const int cs = wave_sum_i(c);
-        if (cs >= kk) {
-          t = cand;
-          if (cs == kk) break;        // exactly the kk largest keys are >= t already: the remaining bits cannot change the kept set
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) v[j] = (key[j] < t) ? -INFINITY : v[j];
-    }
-    VC_TS(3);
-    // ---- softmax numerators (v now holds p >= 0; 0 = filtered out)
-    float ps = 0.f;
-#pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) { v[j] = __expf(v[j] - mx); ps += v[j]; }        // exp(-inf) = 0
-    float tot = wave_sum(ps);
-    // ---- top-p: drop a token when the mass of the strictly larger ones already exceeds top_p.
-    // p is monotone in the logit, and the bits of a non-negative float order like the float.
-    if (a.top_p < 1.0f) {
-      const float lim = a.top_p * tot;
-      // t = the largest key whose strictly-larger mass still exceeds lim (key 0 always qualifies:
-      // the whole row weighs tot > lim); exactly the keys <= t are dropped.
-      uint32_t t = 0;
-#pragma unroll 1
-      for (int bit = 30; bit >= 0; --bit) {
-        const uint32_t cand = t | (1u << bit);
-        float mm = 0.f;
-#pragma unroll
-        for (int j = 0; j < VC_VPL; ++j) mm += (__float_as_uint(v[j]) > cand) ? v[j] : 0.f;
-        if (wave_sum(mm) > lim) t = cand;
-      }
-      ps = 0.f;
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) { v[j] = (__float_as_uint(v[j]) <= t) ? 0.f : v[j]; ps += v[j]; }
-      tot = wave_sum(ps);
-    }
-    VC_TS(4);
-    // ---- categorical draw by inverse CDF, order = (lane, j)
     const float u = philox_uniform(a.seed, (uint32_t)b, (uint32_t)step, (uint32_t)k);
-    const float target = u * tot;
-    float incl = ps;
-    for (int off = 1; off < 64; off <<= 1) {
-      const float o = __shfl_up(incl, off, 64);
-      if (lane >= off) incl += o;
-    }
-    const float excl = incl - ps;
-    const bool mine = (ps > 0.f) && (target >= excl) && (target < incl);
-    const uint64_t ball = __ballot(mine);
-    int src_lane;
-    if (ball) src_lane = __ffsll((long long)ball) - 1;
-    else {     // rounding put target at/after the end: take the last lane with mass
-      const uint64_t nz = __ballot(ps > 0.f);
-      src_lane = nz ? 63 - __clzll((long long)nz) : 0;
-    }
-    // every lane walks its own elements (cheap, branch-free); the owner's result is broadcast
-    float acc = excl;
-    int pick = -1, last = -1;
-#pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) {
-      const bool nz = v[j] > 0.f;
-      acc += v[j];
-      last = nz ? lane + 64 * j : last;
-      pick = (pick < 0 && nz && target < acc) ? lane + 64 * j : pick;
-    }
-    int tok = (pick >= 0) ? pick : last;
-    tok = __shfl(tok, src_lane, 64);
+    int tok = filter_draw(a, b, v, bv, V, u);
+    if (a.forced && a.forced_mode == 1 && step < a.n_forced)      // replay of recorded reference draws (parity tests)
+      tok = (int)a.forced[((long)step * a.B + b) * a.K + k];
     if (lane == 0) {
       xs[k] = tok;
       if (k == 0) xs[a.K] = bi;
@@ -360,12 +371,12 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState
         if (keep >= 0 && keep != b) drop = true;
       }
       const int step = st.total_steps;
-      const bool forced = a.forced && step < a.n_forced;
+      const bool forced = a.forced && a.forced_mode == 0 && step < a.n_forced;
       if (st.n_eog == 0) {
         if (st.cur_num_gen < K - 1)
           for (int jj = 1; jj < K - st.cur_num_gen; ++jj) tok[K - jj] = a.empty_token;
         if (forced) {
-          for (int k = 0; k < K; ++k) tok[k] = (int)a.forced[(long)step * K + k];
+          for (int k = 0; k < K; ++k) tok[k] = (int)a.forced[((long)step * a.B + b) * K + k];
           cond = (tok[0] == st.term_token);
         }
         if (cond) { tok[0] = st.term_token; st.n_eog = 1; }
@@ -376,7 +387,7 @@ __device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState
         for (int k = 0; k < st.n_eog; ++k) tok[k] = a.empty_token;
         tok[st.n_eog] = st.term_token;
         if (forced)
-          for (int k = 0; k < K; ++k) tok[k] = (int)a.forced[(long)step * K + k];
+          for (int k = 0; k < K; ++k) tok[k] = (int)a.forced[((long)step * a.B + b) * K + k];
         st.n_eog += 1;
       }
       st.cur_num_gen += 1;
@@ -541,6 +552,39 @@ hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
     hipLaunchKernelGGL(advance_only_k, dim3(a.B), dim3(256), 0, s, a);
   }
   return hipGetLastError();
+}
+
+// =============================================================== sampler test hook
+// n_draws independent draws from ONE logits row through the product filter_draw (the distribution test
+// of tests/test_gpu_sampler.py): draw i uses the Philox counter (seed, sequence i, step 0, codebook 0).
+__global__ __launch_bounds__(256) void sample_test_k(const SampleArgs a, int n_draws, int* __restrict__ out) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x * 4 + wave;
+  if (i >= n_draws) return;
+  float v[VC_VPL];
+#pragma unroll
+  for (int j = 0; j < VC_VPL; ++j) {
+    const int c = lane + 64 * j;
+    const float t = a.logits[min(c, a.V - 1)];
+    v[j] = (c < a.V) ? t : -INFINITY;
+  }
+  float bv = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < VC_VPL; ++j) bv = fmaxf(bv, v[j]);
+  bv = wave_max(bv);
+  const float u = philox_uniform(a.seed, (uint32_t)i, 0u, 0u);
+  const int tok = filter_draw(a, 0, v, bv, a.V, u);
+  if (lane == 0) out[i] = tok;
+}
+extern "C" int vc_debug_sample(const float* logits_dev, int V, const vc_sample_cfg* sc, int n_draws,
+                               int32_t* out_dev, void* stream) {
+  if (!logits_dev || !sc || !out_dev || V < 1 || V > 64 * VC_VPL || n_draws < 1) return VC_EINVAL;
+  SampleArgs a;
+  memset(&a, 0, sizeof a);
+  a.logits = logits_dev; a.B = 1; a.K = 1; a.V = V;
+  a.top_k = sc->top_k; a.top_p = sc->top_p; a.temperature = sc->temperature; a.seed = sc->seed;
+  hipLaunchKernelGGL(sample_test_k, dim3((n_draws + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, n_draws, out_dev);
+  return hipGetLastError() == hipSuccess ? VC_OK : VC_EHIP;
 }
 
 // =============================================================== output assembly

@@ -10,6 +10,7 @@ There is no CPU or eager fallback: without the library every constructor raises.
 """
 from __future__ import annotations
 
+import ast
 import ctypes as C
 import logging
 import math
@@ -37,10 +38,19 @@ def _sine_table(n: int, d: int) -> torch.Tensor:
 
 
 class VoiceCraftEngine:
-    """Drop-in for `VoiceCraft(args)` + `load_state_dict` + `.to(device).eval()` on the inference path."""
+    """Drop-in for `VoiceCraft(args)` + `load_state_dict` + `.to(device).eval()` on the inference path.
+
+    Capacities (the reference grows its tensors as it goes; the engine preallocates):
+      max_seqs       concurrent sequences (best-of-N samples / utterances of inference_tts_multi)
+      max_positions  cached positions per sequence = Lx + prompt columns + generated steps.  A call whose
+                     PROMPT does not fit raises EngineError(VC_ECAP) at once; a call whose worst case (the
+                     reference's length cap, 10 frames per phoneme) does not fit still runs and raises only
+                     if generation really reaches the end of the cache before the terminator.  The default
+                     covers Lx <= 370 phonemes in the worst case (11*Lx + 6 positions).
+    """
 
     def __init__(self, args: Namespace | dict, state_dict: dict[str, torch.Tensor], device="cuda:0",
-                 dtype="bf16", max_seqs: int = 8, max_positions: int = 2048, use_graph: bool = True):
+                 dtype="bf16", max_seqs: int = 8, max_positions: int = 4096, use_graph: bool = True):
         self.lib = _lib.load()
         a = Namespace(**args) if isinstance(args, dict) else Namespace(**vars(args))
         # the same normalisation VoiceCraft.__init__ applies (models/voicecraft.py:117-127)
@@ -50,7 +60,7 @@ class VoiceCraftEngine:
             a.n_special = 3
         a.eos = getattr(a, "eos", -1)
         if isinstance(a.audio_vocab_size, str):
-            a.audio_vocab_size = eval(a.audio_vocab_size)
+            a.audio_vocab_size = int(ast.literal_eval(a.audio_vocab_size))   # the reference eval()s it (voicecraft.py:126-127)
         assert a.text_pad_token == a.text_vocab_size, (a.text_vocab_size, a.text_pad_token)
         assert a.audio_vocab_size == a.empty_token, a.empty_token
         assert a.eog == a.audio_vocab_size + 1, a.eog
@@ -116,13 +126,16 @@ class VoiceCraftEngine:
     def _stream(self) -> C.c_void_p:
         return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
 
-    def _sample_cfg(self, top_k, top_p, temperature, stop_repetition, silence_tokens, seed=None) -> SampleCfg:
+    def _sample_cfg(self, top_k, top_p, temperature, stop_repetition, silence_tokens, seed=None,
+                    forced_mode="tokens") -> SampleCfg:
         sc = SampleCfg()
+        sc.forced_mode = {"tokens": 0, "draws": 1}[forced_mode]
         sc.top_k = int(top_k)
         sc.top_p = float(top_p)
         sc.temperature = float(temperature)
         sc.stop_repetition = int(stop_repetition)
-        sil = list(silence_tokens)[: _lib.VC_MAX_SILENCE]
+        sil = list(silence_tokens)
+        assert len(sil) <= _lib.VC_MAX_SILENCE, f"at most {_lib.VC_MAX_SILENCE} silence tokens are supported, got {len(sil)}"
         sc.n_silence = len(sil)
         for i, v in enumerate(sil):
             sc.silence_tokens[i] = int(v)
@@ -146,6 +159,14 @@ class VoiceCraftEngine:
         yd = y[0].to(self.device, torch.int64).contiguous()          # [T,K], time-major as given
         return xd, Lx, yd, int(yd.shape[0])
 
+    def _forced_arg(self, forced, B: int):
+        """[steps,K] or [steps,B,K] int64 -> (device tensor kept alive by the caller, pointer, n_steps)."""
+        if forced is None:
+            return None, None, 0
+        K = self.args.n_codebooks
+        fd = torch.as_tensor(forced, dtype=torch.int64).reshape(-1, B, K).to(self.device).contiguous()
+        return fd, C.c_void_p(fd.data_ptr()), int(fd.shape[0])
+
     def _gen_budget(self, Lx: int, n_cols: int, mult: int, spans: int = 1) -> int:
         K = self.args.n_codebooks
         return max(0, Lx * mult - n_cols + 1) + spans * (K + 4) + 8
@@ -154,23 +175,22 @@ class VoiceCraftEngine:
     @torch.no_grad()
     def inference_tts(self, x, x_lens, y, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
                       stop_repetition: int = 3, kvcache: int = 1, silence_tokens: Iterable[int] = (1388, 1898, 131),
-                      *kargs, _n_samples: int = 1, _forced=None, _logit_steps: int = 0, _seed=None):
+                      *kargs, _n_samples: int = 1, _forced=None, _logit_steps: int = 0, _seed=None,
+                      _forced_mode: str = "tokens"):
         """models/voicecraft.py:908.  `kvcache` is accepted and ignored: the cache is always on
         (kvcache=0 and kvcache=1 give identical tokens in the reference)."""
         xd, Lx, yd, T = self._prep(x, x_lens, y)
         logging.info(f"silence tokens: {list(silence_tokens)}, note that if you are not using the pretrained encodec 6f79c6a8, make sure you specified it yourself, rather than using the default")
         K = self.args.n_codebooks
-        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed)
+        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed, _forced_mode)
         cap = T + self._gen_budget(Lx, T + 1, self.args.encodec_sr // 5)
         res = torch.empty((K, cap), dtype=torch.int64, device=self.device)
-        forced_ptr, n_forced = None, 0
-        if _forced is not None:
-            fd = torch.as_tensor(_forced, dtype=torch.int64).to(self.device).contiguous()
-            forced_ptr, n_forced = C.c_void_p(fd.data_ptr()), int(fd.shape[0])
+        nb = int(_n_samples)
+        fd, forced_ptr, n_forced = self._forced_arg(_forced, nb)
         logits = None
         if _logit_steps > 0:
             V = self.args.audio_vocab_size + int(self.args.n_special)
-            logits = torch.zeros((_logit_steps, K, V), dtype=torch.float32, device=self.device)
+            logits = torch.zeros((_logit_steps, nb, K, V), dtype=torch.float32, device=self.device)
         gen_len, n_steps = C.c_int(0), C.c_int(0)
         rc = self.lib.vc_tts(self._h, C.c_void_p(xd.data_ptr()), Lx, C.c_void_p(yd.data_ptr()), T, C.byref(sc),
                              int(_n_samples), forced_ptr, n_forced, C.c_void_p(res.data_ptr()), cap, C.byref(gen_len),
@@ -186,22 +206,26 @@ class VoiceCraftEngine:
         if self.args.special_first:
             out, gen = out - int(self.args.n_special), gen - int(self.args.n_special)
         if logits is not None:
-            return out, gen, logits
+            return out, gen, (logits[:, 0] if nb == 1 else logits)
         return out, gen
 
     @torch.no_grad()
     def inference_tts_batch(self, x, x_lens, y, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
                             stop_repetition: int = 3, kvcache: int = 1, batch_size: int = 5,
-                            silence_tokens: Iterable[int] = (1388, 1898, 131), *kargs, _seed=None):
+                            silence_tokens: Iterable[int] = (1388, 1898, 131), *kargs, _seed=None, _forced=None,
+                            _forced_mode: str = "tokens", _logit_steps: int = 0):
         """models/voicecraft.py:1156 — best-of-N sampling of ONE utterance; returns the kept sample."""
         return self.inference_tts(x, x_lens, y, top_k, top_p, temperature, stop_repetition, kvcache,
-                                  silence_tokens, _n_samples=int(batch_size), _seed=_seed)
+                                  silence_tokens, _n_samples=int(batch_size), _seed=_seed, _forced=_forced,
+                                  _forced_mode=_forced_mode, _logit_steps=_logit_steps)
 
     @torch.no_grad()
     def inference_tts_multi(self, xs, ys, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
-                            stop_repetition: int = 3, silence_tokens: Iterable[int] = (1388, 1898, 131), _seed=None):
+                            stop_repetition: int = 3, silence_tokens: Iterable[int] = (1388, 1898, 131), _seed=None,
+                            _forced=None, _forced_mode: str = "tokens", _logit_steps: int = 0):
         """B different utterances as one batch (not in the reference: SURVEY.md §8f-1).
-        xs: list of int64 [Lx_i]; ys: list of int64 [T_i,K].  Returns list of (res [1,K,T_i+Tg_i], gen)."""
+        xs: list of int64 [Lx_i]; ys: list of int64 [T_i,K].  Returns list of (res [1,K,T_i+Tg_i], gen)
+        (+ the raw head logits [steps,B,K,V] as a third value when _logit_steps > 0)."""
         B = len(xs)
         assert B == len(ys) and 1 <= B <= self.max_seqs, (B, self.max_seqs)
         K = self.args.n_codebooks
@@ -218,12 +242,19 @@ class VoiceCraftEngine:
             cap = max(cap, T + self._gen_budget(Lx, T + 1, self.args.encodec_sr // 5))
         x_off = (C.c_int32 * (B + 1))(*xo)
         y_off = (C.c_int32 * (B + 1))(*yo)
-        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed)
+        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed, _forced_mode)
         res = torch.empty((B, K, cap), dtype=torch.int64, device=self.device)
         gen_len = (C.c_int * B)()
         n_steps = C.c_int(0)
+        fd, forced_ptr, n_forced = self._forced_arg(_forced, B)
+        logits = None
+        if _logit_steps > 0:
+            V = self.args.audio_vocab_size + int(self.args.n_special)
+            logits = torch.zeros((_logit_steps, B, K, V), dtype=torch.float32, device=self.device)
         rc = self.lib.vc_tts_multi(self._h, B, C.c_void_p(xcat.data_ptr()), x_off, C.c_void_p(ycat.data_ptr()), y_off,
-                                   C.byref(sc), C.c_void_p(res.data_ptr()), cap, gen_len, C.byref(n_steps), self._stream())
+                                   C.byref(sc), forced_ptr, n_forced, C.c_void_p(res.data_ptr()), cap, gen_len,
+                                   C.c_void_p(logits.data_ptr()) if logits is not None else None, int(_logit_steps),
+                                   C.byref(n_steps), self._stream())
         check(rc, self._h, "vc_tts_multi")
         self.last_steps = n_steps.value
         outs = []
@@ -233,13 +264,15 @@ class VoiceCraftEngine:
             if self.args.special_first:
                 r, g = r - int(self.args.n_special), g - int(self.args.n_special)
             outs.append((r, g))
+        if logits is not None:
+            return outs, logits
         return outs
 
     # ------------------------------------------------------------------ editing
     @torch.no_grad()
     def inference(self, x, x_lens, y, mask_interval, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
                   stop_repetition: int = -1, kvcache: int = 1, silence_tokens: Iterable[int] = (1388, 1898, 131),
-                  _forced=None, _logit_steps: int = 0, _seed=None):
+                  _forced=None, _logit_steps: int = 0, _seed=None, _forced_mode: str = "tokens"):
         """models/voicecraft.py:561."""
         xd, Lx, yd, T = self._prep(x, x_lens, y)
         assert mask_interval.shape == torch.Size((1, mask_interval.shape[1], 2)), mask_interval
@@ -262,17 +295,14 @@ class VoiceCraftEngine:
             has_term = (i == M) if (eos > 0 or reduced) else True
             if e - s + int(has_term) <= 0:
                 raise IndexError("index is out of bounds for dimension with size 0 (zero-length non-masked piece)")
-        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed)
+        sc = self._sample_cfg(top_k, top_p, temperature, stop_repetition, silence_tokens, _seed, _forced_mode)
         flat = [v for iv in ivs for v in iv]
         iv_arr = (C.c_int32 * (2 * M))(*flat)
         mv_arr = (C.c_int32 * (2 * M))(*mask_value)
         n_cols = T + 2 * (M + 1) + (M + 1) * K + 1
         cap = T + self._gen_budget(Lx, n_cols, 10, spans=M)
         res = torch.empty((K, cap), dtype=torch.int64, device=self.device)
-        forced_ptr, n_forced = None, 0
-        if _forced is not None:
-            fd = torch.as_tensor(_forced, dtype=torch.int64).to(self.device).contiguous()
-            forced_ptr, n_forced = C.c_void_p(fd.data_ptr()), int(fd.shape[0])
+        fd, forced_ptr, n_forced = self._forced_arg(_forced, 1)
         logits = None
         if _logit_steps > 0:
             V = self.args.audio_vocab_size + int(self.args.n_special)
@@ -308,6 +338,23 @@ class VoiceCraftEngine:
         check(self.lib.vc_debug_read(self._h, name.encode(), C.c_void_p(out.data_ptr()), out.numel() * out.element_size()),
               self._h, "vc_debug_read")
         return out
+
+
+def debug_sample(logits: torch.Tensor, n_draws: int, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
+                 seed: int = 0) -> torch.Tensor:
+    """n_draws independent tokens from ONE fp32 logits row [V] on the GPU through the product sampler
+    (vc_debug_sample; tests only): int32 [n_draws]."""
+    lib = _lib.load()
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.ndim == 1
+    logits = logits.contiguous()
+    sc = SampleCfg()
+    sc.top_k, sc.top_p, sc.temperature, sc.seed = int(top_k), float(top_p), float(temperature), int(seed)
+    out = torch.empty((n_draws,), dtype=torch.int32, device=logits.device)
+    rc = lib.vc_debug_sample(C.c_void_p(logits.data_ptr()), int(logits.numel()), C.byref(sc), int(n_draws),
+                             C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream))
+    if rc != 0:
+        raise AssertionError(f"vc_debug_sample rejected its arguments (code {rc})")
+    return out
 
 
 # ---------------------------------------------------------------------- pattern ops (no engine needed)
