@@ -23,12 +23,14 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 struct bf16_t { uint16_t u; };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t u) { return __uint_as_float(((uint32_t)u) << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f) {   // round-to-nearest-even (torch .to(bfloat16))
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN stays NaN
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (uint16_t)(u >> 16);
+// round-to-nearest-even (torch .to(bfloat16)): gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32)
+typedef __attribute__((ext_vector_type(2))) float vc_f32x2;
+typedef __attribute__((ext_vector_type(2))) __bf16 vc_bf16x2;
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+  const vc_f32x2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vc_bf16x2));
 }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) { return (uint16_t)(pack_bf16x2(f, 0.f) & 0xffffu); }
 
 template <typename WT> struct WTr;
 template <> struct WTr<float> {      // exact mode: v_mfma_f32_16x16x4_f32, 4 per 16-byte fragment
@@ -197,15 +199,15 @@ struct GemmArgs {
   const int* row_pos;
   int n_rows;
   const int* n_active;      // never null: the launch is a no-op when *n_active == 0
-  // prologue LN:   hn = h_in[src] + prev_bias + sum_s parts[s][r]; X = LN(hn) ; h_out[r] = hn
+  // prologue LN:   hn = h_in[src] + prev_bias + sum_s parts[s][r]; X = hn (un-normalised); h_out[r] = hn;
+  //                the LayerNorm itself is folded into the weights and the epilogue (vc_gemm.hip, "LayerNorm fold")
   const float* h_in;
   float* h_out;
   const float* parts;       // [VC_MAX_KSPLIT][rows_cap][d], always readable; the first n_parts slabs are summed
   int n_parts;
   const float* prev_bias;   // always a readable [d] vector; added only when has_prev_bias
   int has_prev_bias;
-  const float* ln_w;
-  const float* ln_b;
+  const float* wg;          // LN prologue: [group][N] row sums of the folded weights (W . gamma), see vc_gemm.hip
   const int* gather_rows;   // optional indirection on h_in/parts rows (logit rows for the heads)
   int d;                    // row width of h / parts
   // prologue PLAIN: X = x_in[r][grp*x_group_stride + k]
@@ -327,7 +329,9 @@ struct AssembleArgs {       // writes res [K][res_cap] from y and the generated 
 };
 
 // ---------------------------------------------------------------- launchers (defined in the .hip files)
-hipError_t vc_launch_pack(const float* src, void* dst, int N, int K, int dtype, int th, hipStream_t s);
+hipError_t vc_launch_pack(const float* src, const float* colscale, void* dst, int N, int K, int dtype, int th, hipStream_t s);
+hipError_t vc_launch_fold_vecs(const float* W, const float* gamma, const float* beta, const float* bias, float* wg,
+                               float* cb, int N, int K, int dtype, hipStream_t s);
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s);
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);

@@ -30,8 +30,8 @@ struct RawTensor {
 
 struct Layer {
   uint4 *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;
-  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
-  float *ln1w = nullptr, *ln1b = nullptr, *ln2w = nullptr, *ln2b = nullptr;
+  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;   // bqkv / b1 hold the FOLDED biases (W beta + b)
+  float *wg_qkv = nullptr, *wg_1 = nullptr;                             // row sums of the folded weights W . gamma
   void *kc = nullptr, *vc = nullptr;   // KV cache of this layer: WT [max_seqs][H][S_max][hd]
 };
 
@@ -52,9 +52,8 @@ struct vc_engine {
   int esz = 2;
 
   std::vector<Layer> layers;
-  float *lnf_w = nullptr, *lnf_b = nullptr;
   uint4 *Wh1 = nullptr, *Wh2 = nullptr;
-  float *bh1 = nullptr, *bh2 = nullptr;
+  float *bh1 = nullptr, *bh2 = nullptr, *wg_h1 = nullptr;               // bh1: folded with the final LayerNorm
   long wh2_group_stride = 0;
   float *text_emb = nullptr, *audio_emb = nullptr, *mask_emb = nullptr, *pe = nullptr;
   float alpha_text = 1.f, alpha_audio = 1.f;
@@ -167,7 +166,8 @@ int need(vc_engine* e, const std::string& key, std::initializer_list<int64_t> sh
   return VC_OK;
 }
 
-int pack_matrix(vc_engine* e, const std::string& key, int N, int Kdim, uint4** out, int th = 16) {
+int pack_matrix(vc_engine* e, const std::string& key, int N, int Kdim, uint4** out, int th = 16,
+                const float* colscale = nullptr) {
   const RawTensor* t;
   int rc = need(e, key, {N, Kdim}, &t);
   if (rc) return rc;
@@ -175,7 +175,24 @@ int pack_matrix(vc_engine* e, const std::string& key, int N, int Kdim, uint4** o
   const long units = (long)((N + th - 1) / th) * (Kdim / KW) * 4 * th;
   rc = dalloc(e, out, (size_t)units);
   if (rc) return rc;
-  HIPCHK(e, vc_launch_pack(t->dev, *out, N, Kdim, e->dtype, th, 0));
+  HIPCHK(e, vc_launch_pack(t->dev, colscale, *out, N, Kdim, e->dtype, th, 0));
+  return VC_OK;
+}
+
+// A linear layer behind a LayerNorm (vc_gemm.hip, "LayerNorm fold"): packs W . gamma, and produces
+// wg = rowsum(W . gamma) and the folded bias cb = W beta + bias.
+int pack_folded(vc_engine* e, const std::string& wkey, const std::string& bkey, const std::string& ln_prefix,
+                int N, int Kdim, uint4** Wout, float** wg, float** cb, int th = 16) {
+  const RawTensor *tw, *tb, *tg, *tbe;
+  int rc;
+  if ((rc = need(e, wkey, {N, Kdim}, &tw))) return rc;
+  if ((rc = need(e, bkey, {N}, &tb))) return rc;
+  if ((rc = need(e, ln_prefix + "weight", {Kdim}, &tg))) return rc;
+  if ((rc = need(e, ln_prefix + "bias", {Kdim}, &tbe))) return rc;
+  if ((rc = pack_matrix(e, wkey, N, Kdim, Wout, th, tg->dev))) return rc;
+  if ((rc = dalloc(e, wg, (size_t)N))) return rc;
+  if ((rc = dalloc(e, cb, (size_t)N))) return rc;
+  HIPCHK(e, vc_launch_fold_vecs(tw->dev, tg->dev, tbe->dev, tb->dev, *wg, *cb, N, Kdim, e->dtype, 0));
   return VC_OK;
 }
 
@@ -231,9 +248,9 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.h_out = e->hA;
       g.parts = e->parts;
       g.n_parts = (l == 0) ? 0 : e->p_f2.ksplit;
-      g.prev_bias = (l == 0) ? ly.ln1b : e->layers[l - 1].b2;
+      g.prev_bias = (l == 0) ? ly.bo : e->layers[l - 1].b2;    // (any readable [d] vector when unused)
       g.has_prev_bias = (l == 0) ? 0 : 1;
-      g.ln_w = ly.ln1w; g.ln_b = ly.ln1b;
+      g.wg = ly.wg_qkv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
@@ -268,7 +285,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.W1; g.bias = ly.b1;
       g.h_in = e->hA; g.h_out = e->hB;
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
-      g.ln_w = ly.ln2w; g.ln_b = ly.ln2b;
+      g.wg = ly.wg_1;
       g.out = e->act; g.out_ld = 4 * d;
       if (split_ln) {
         g.x_out = e->xn;
@@ -301,7 +318,7 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
     g.Wp = e->Wh1; g.bias = e->bh1;
     g.h_in = e->hB; g.h_out = nullptr;
     g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
-    g.ln_w = e->lnf_w; g.ln_b = e->lnf_b; g.gather_rows = gather;
+    g.wg = e->wg_h1; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
     if (!gather && n >= e->ln_split_rows) {
       g.x_out = e->xn;
@@ -333,8 +350,8 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.h_in = (l == 0) ? rs.h_in : e->hB; g.h_out = e->hA; g.parts = e->parts;
       g.n_parts = (l == 0) ? 0 : e->p_f2.ksplit;
-      g.prev_bias = (l == 0) ? ly.ln1b : e->layers[l - 1].b2; g.has_prev_bias = (l == 0) ? 0 : 1;
-      g.ln_w = ly.ln1w; g.ln_b = ly.ln1b; g.x_out = e->xn;
+      g.prev_bias = (l == 0) ? ly.bo : e->layers[l - 1].b2; g.has_prev_bias = (l == 0) ? 0 : 1;
+      g.x_out = e->xn;
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
       g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = 1;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
@@ -364,7 +381,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
-      g.ln_w = ly.ln2w; g.ln_b = ly.ln2b; g.x_out = e->xn;
+      g.x_out = e->xn;
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
       g.Wp = ly.W1; g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = 1;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
@@ -647,18 +664,14 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (int l = 0; l < L; ++l) {
     const std::string pre = "decoder.layers." + std::to_string(l) + ".";
     Layer& ly = e->layers[l];
-    if ((rc = pack_matrix(e, pre + "self_attn.in_proj_weight", 3 * d, d, &ly.Wqkv, VC_TH_QKV))) return rc;
-    if ((rc = keep_vec(e, pre + "self_attn.in_proj_bias", 3 * d, &ly.bqkv))) return rc;
+    if ((rc = pack_folded(e, pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias", pre + "norm1.", 3 * d, d,
+                          &ly.Wqkv, &ly.wg_qkv, &ly.bqkv, VC_TH_QKV))) return rc;
     if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo))) return rc;
     if ((rc = keep_vec(e, pre + "self_attn.out_proj.bias", d, &ly.bo))) return rc;
-    if ((rc = pack_matrix(e, pre + "linear1.weight", 4 * d, d, &ly.W1))) return rc;
-    if ((rc = keep_vec(e, pre + "linear1.bias", 4 * d, &ly.b1))) return rc;
+    if ((rc = pack_folded(e, pre + "linear1.weight", pre + "linear1.bias", pre + "norm2.", 4 * d, d,
+                          &ly.W1, &ly.wg_1, &ly.b1))) return rc;
     if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W2))) return rc;
     if ((rc = keep_vec(e, pre + "linear2.bias", d, &ly.b2))) return rc;
-    if ((rc = keep_vec(e, pre + "norm1.weight", d, &ly.ln1w))) return rc;
-    if ((rc = keep_vec(e, pre + "norm1.bias", d, &ly.ln1b))) return rc;
-    if ((rc = keep_vec(e, pre + "norm2.weight", d, &ly.ln2w))) return rc;
-    if ((rc = keep_vec(e, pre + "norm2.bias", d, &ly.ln2b))) return rc;
     const size_t cache_bytes = (size_t)e->B_max * e->H * e->S_max * e->hd * e->esz;
     char* kc; char* vc;
     if ((rc = dalloc(e, &kc, cache_bytes))) return rc;
@@ -670,26 +683,31 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
       if (it != e->raw.end()) { hipDeviceSynchronize(); hipFree(it->second.dev); e->raw.erase(it); }
     }
   }
-  if ((rc = keep_vec(e, "decoder.norm.weight", d, &e->lnf_w))) return rc;
-  if ((rc = keep_vec(e, "decoder.norm.bias", d, &e->lnf_b))) return rc;
   // ---- heads: first linears concatenated to one [K*P][d] matrix, second ones one group each
   {
-    float* cat;
+    // (folded with the final LayerNorm decoder.norm, transformer.py:484-485)
+    float *cat, *bcat;
+    const RawTensor *tg, *tbe;
+    if ((rc = need(e, "decoder.norm.weight", {d}, &tg))) return rc;
+    if ((rc = need(e, "decoder.norm.bias", {d}, &tbe))) return rc;
     HIPCHK(e, hipMalloc((void**)&cat, (size_t)K * P * d * 4));
-    if ((rc = dalloc(e, &e->bh1, (size_t)K * P))) { hipFree(cat); return rc; }
+    if (hipMalloc((void**)&bcat, (size_t)K * P * 4) != hipSuccess) { hipFree(cat); return fail(e, VC_EHIP, "hipMalloc failed"); }
+    auto drop = [&]() { hipDeviceSynchronize(); hipFree(cat); hipFree(bcat); };
+    if ((rc = dalloc(e, &e->bh1, (size_t)K * P))) { drop(); return rc; }
+    if ((rc = dalloc(e, &e->wg_h1, (size_t)K * P))) { drop(); return rc; }
     for (int k = 0; k < K; ++k) {
       const std::string pre = "predict_layer." + std::to_string(k) + ".";
-      if ((rc = need(e, pre + "0.weight", {P, d}, &t))) { hipFree(cat); return rc; }
+      if ((rc = need(e, pre + "0.weight", {P, d}, &t))) { drop(); return rc; }
       hipMemcpy(cat + (size_t)k * P * d, t->dev, (size_t)P * d * 4, hipMemcpyDeviceToDevice);
-      if ((rc = need(e, pre + "0.bias", {P}, &t))) { hipFree(cat); return rc; }
-      hipMemcpy(e->bh1 + (size_t)k * P, t->dev, (size_t)P * 4, hipMemcpyDeviceToDevice);
+      if ((rc = need(e, pre + "0.bias", {P}, &t))) { drop(); return rc; }
+      hipMemcpy(bcat + (size_t)k * P, t->dev, (size_t)P * 4, hipMemcpyDeviceToDevice);
     }
     const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
     const long units = (long)(K * P / 16) * (d / KW) * 64;
-    if ((rc = dalloc(e, &e->Wh1, (size_t)units))) { hipFree(cat); return rc; }
-    hipError_t pe_ = vc_launch_pack(cat, e->Wh1, K * P, d, e->dtype, 16, 0);
-    hipDeviceSynchronize();
-    hipFree(cat);
+    if ((rc = dalloc(e, &e->Wh1, (size_t)units))) { drop(); return rc; }
+    hipError_t pe_ = vc_launch_pack(cat, tg->dev, e->Wh1, K * P, d, e->dtype, 16, 0);
+    if (pe_ == hipSuccess) pe_ = vc_launch_fold_vecs(cat, tg->dev, tbe->dev, bcat, e->wg_h1, e->bh1, K * P, d, e->dtype, 0);
+    drop();
     HIPCHK(e, pe_);
     const long gunits = (long)((V + 15) / 16) * (P / KW) * 64;
     e->wh2_group_stride = gunits;
@@ -698,7 +716,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     for (int k = 0; k < K; ++k) {
       const std::string pre = "predict_layer." + std::to_string(k) + ".";
       if ((rc = need(e, pre + "2.weight", {V, P}, &t))) return rc;
-      HIPCHK(e, vc_launch_pack(t->dev, e->Wh2 + (size_t)k * gunits, V, P, e->dtype, 16, 0));
+      HIPCHK(e, vc_launch_pack(t->dev, nullptr, e->Wh2 + (size_t)k * gunits, V, P, e->dtype, 16, 0));
       if ((rc = need(e, pre + "2.bias", {V}, &t))) return rc;
       HIPCHK(e, hipMemcpy(e->bh2 + (size_t)k * V, t->dev, (size_t)V * 4, hipMemcpyDeviceToDevice));
     }
@@ -1099,7 +1117,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
-      g.prev_bias = ly.bo; g.has_prev_bias = 1; g.ln_w = ly.ln2w; g.ln_b = ly.ln2b; g.out = e->act; g.out_ld = 4 * d;
+      g.prev_bias = ly.bo; g.has_prev_bias = 1; g.wg = ly.wg_1; g.out = e->act; g.out_ld = 4 * d;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
     } else if (w == "ffn2") {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
@@ -1108,7 +1126,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     } else if (w == "qkv") {
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.h_in = e->hB; g.h_out = e->hA; g.parts = e->parts; g.n_parts = e->p_f2.ksplit;
-      g.prev_bias = ly.b2; g.has_prev_bias = 1; g.ln_w = ly.ln1w; g.ln_b = ly.ln1b; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      g.prev_bias = ly.b2; g.has_prev_bias = 1; g.wg = ly.wg_qkv; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
     } else if (w == "oproj") {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);

@@ -12,6 +12,16 @@
 // pure HBM stream (1 FLOP/byte); the MFMA is only the cheapest way to consume 1 KiB per instruction
 // and makes rows 2..16 (batched decode, prefill groups, the 3-row span switch of editing) free.
 //
+// LayerNorm fold.  Every LayerNorm on the path feeds a linear layer (transformer.py:328-329, voicecraft.py
+// :1084-1086), and LN(x) = (x - mean) * rstd * gamma + beta is affine in x up to two per-row scalars:
+//   W LN(x) + c = rstd * ( (W . gamma) x  -  mean * rowsum(W . gamma) )  +  (W beta + c)
+// so the engine stores W' = W . gamma (column-scaled at load time, pack_k), wg = rowsum(W') over the
+// ROUNDED elements and cb = W beta + c (fold_vecs_k).  A decode GEMM then multiplies the UN-normalised row
+// and applies mean / rstd in its epilogue: the row's statistics are two wave sums computed in the shadow of
+// the weight stream instead of a two-pass LayerNorm (2 block barriers, ~3000 clocks, measured) on the
+// critical path of every launch.  Multi-row passes normalise once per row in ln_rows_k (x_hat = (x - mean)
+// * rstd, no affine) and use the same W' / cb through the plain prologue.
+//
 // Block = 4 waves sharing one 16-row output tile; the waves split the block's K range 4 ways and
 // reduce through LDS.  Cross-block split-K (EPI_PART) leaves fp32 partial slabs that the NEXT
 // kernel's LayerNorm prologue sums (launch-boundary reduce: no atomics, deterministic).
@@ -21,8 +31,8 @@
 // th = output channels per tile: 16 (every lane of the A fragment) or 12 (VC_TH_QKV: lanes with
 // (lane & 15) >= 12 carry no weight and nothing is stored for them - a tile is 4 x 12 fragments).
 template <typename WT>
-__global__ void pack_k(const float* __restrict__ src, WT* __restrict__ dst, int N, int K, int KT,
-                       long total, int th) {
+__global__ void pack_k(const float* __restrict__ src, const float* __restrict__ colscale, WT* __restrict__ dst,
+                       int N, int K, int KT, long total, int th) {
   constexpr int EPL = WTr<WT>::EPL, KW = WTr<WT>::KW;
   long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;   // one thread per (tile, fragment slot)
   if (idx >= total) return;
@@ -37,23 +47,54 @@ __global__ void pack_k(const float* __restrict__ src, WT* __restrict__ dst, int 
 #pragma unroll
   for (int j = 0; j < EPL; ++j) {
     float v = (n < N) ? src[(long)n * K + k + j] : 0.0f;
+    if (colscale) v *= colscale[k + j];
     WTr<WT>::st(d + j, v);
   }
 }
 
-hipError_t vc_launch_pack(const float* src, void* dst, int N, int K, int dtype, int th, hipStream_t s) {
+hipError_t vc_launch_pack(const float* src, const float* colscale, void* dst, int N, int K, int dtype, int th,
+                          hipStream_t s) {
   const int n_tiles = (N + th - 1) / th;
   if (dtype == VC_DTYPE_BF16) {
     const int KT = K / 32;
     long total = (long)n_tiles * KT * 4 * th;
-    hipLaunchKernelGGL(pack_k<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src,
+    hipLaunchKernelGGL(pack_k<bf16_t>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, colscale,
                        (bf16_t*)dst, N, K, KT, total, th);
   } else {
     const int KT = K / 16;
     long total = (long)n_tiles * KT * 4 * th;
-    hipLaunchKernelGGL(pack_k<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src,
+    hipLaunchKernelGGL(pack_k<float>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, colscale,
                        (float*)dst, N, K, KT, total, th);
   }
+  return hipGetLastError();
+}
+
+// wg[n] = sum_k WT(W[n][k] * gamma[k]) (the rounded elements the MFMA will see), cb[n] = bias[n] + sum_k W[n][k] * beta[k].
+// One wave per output channel.
+template <typename WT>
+__global__ __launch_bounds__(256) void fold_vecs_k(const float* __restrict__ W, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, const float* __restrict__ bias,
+                                                   float* __restrict__ wg, float* __restrict__ cb, int N, int K) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float sg = 0.f, sb = 0.f;
+  for (int k = lane; k < K; k += 64) {
+    const float w = W[(long)n * K + k];
+    WT r;
+    WTr<WT>::st(&r, w * gamma[k]);
+    sg += WTr<WT>::ld(&r);
+    sb += w * beta[k];
+  }
+  sg = wave_sum(sg);
+  sb = wave_sum(sb);
+  if (lane == 0) { wg[n] = sg; cb[n] = bias[n] + sb; }
+}
+hipError_t vc_launch_fold_vecs(const float* W, const float* gamma, const float* beta, const float* bias, float* wg,
+                               float* cb, int N, int K, int dtype, hipStream_t s) {
+  if (dtype == VC_DTYPE_BF16)
+    hipLaunchKernelGGL(fold_vecs_k<bf16_t>, dim3((N + 3) / 4), dim3(256), 0, s, W, gamma, beta, bias, wg, cb, N, K);
+  else
+    hipLaunchKernelGGL(fold_vecs_k<float>, dim3((N + 3) / 4), dim3(256), 0, s, W, gamma, beta, bias, wg, cb, N, K);
   return hipGetLastError();
 }
 
@@ -78,14 +119,35 @@ __device__ __forceinline__ void store4(float* p, const f32x4& v) {
 }
 __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) {
   uint2 u;
-  u.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-  u.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+  u.x = pack_bf16x2(v[0], v[1]);
+  u.y = pack_bf16x2(v[2], v[3]);
   *reinterpret_cast<uint2*>(p) = u;
+}
+
+// store and return the values as the MFMA will read them back (identity in fp32 mode)
+__device__ __forceinline__ f32x4 store4r(float* p, const f32x4& v) { store4(p, v); return v; }
+__device__ __forceinline__ f32x4 store4r(bf16_t* p, const f32x4& v) {
+  uint2 u;
+  u.x = pack_bf16x2(v[0], v[1]);
+  u.y = pack_bf16x2(v[2], v[3]);
+  *reinterpret_cast<uint2*>(p) = u;
+  const f32x4 r = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u),
+                   __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
+  return r;
 }
 
 // Operands of the fused epilogue that live in HBM (bias, the row's cache slot).  Requested by every
 // lane at the very top of the kernel - a dependent load at the END of a 10 us kernel is a full
 // round trip on the critical path.  mg < n_rows (host contract), n is clamped here.
+template <typename WT, int EPI>
+__device__ __forceinline__ void epi_preload(const GemmArgs& a, int mg, int n, int grp, float4& b, int& pos, int& seq);
+// LN prologue: the row sums of the folded weights, same indexing as the bias
+template <typename WT, int EPI>
+__device__ __forceinline__ float4 wg_preload(const GemmArgs& a, int n, int grp) {
+  const int nc = (n < a.N) ? n : 0;
+  if constexpr (EPI == EPI_QKV) return *reinterpret_cast<const float4*>(a.wg + nc);
+  else return *reinterpret_cast<const float4*>(a.wg + (long)grp * a.bias_group_stride + nc);
+}
 template <typename WT, int EPI>
 __device__ __forceinline__ void epi_preload(const GemmArgs& a, int mg, int n, int grp, float4& b, int& pos, int& seq) {
   b = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -172,6 +234,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   const int xs = kblk * (int)sizeof(WT) + 16;     // LDS row stride in bytes (+16: rotate bank slots)
   char* xl = smem;
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
+  float* stat = reinterpret_cast<float*>(red + 256);      // LN prologue: [row][wave][sum, sum of squares]
 
   // Tile height: the QKV projection (N = 3d) uses 12-channel tiles, so that its 3d/12 = d/4 tiles are
   // a multiple of the CU count (512 workgroups of 48 KB at d = 2048 instead of 384 of 64 KB = 1.5 per
@@ -188,6 +251,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   float4 eb;
   int epos, eseq;
   epi_preload<WT, EPI>(a, (m < n_rows) ? m : 0, n, grp, eb, epos, eseq);
+  float4 ewg = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (PRO == PRO_LN) ewg = wg_preload<WT, EPI>(a, n, grp);
 
   const uint4* wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * SPT;   // wave-uniform
   uint4 wf[KTW];
@@ -211,17 +276,15 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   // branch-free (out-of-range lanes re-read a valid address, unused split slabs are read and discarded
   // by a select): a load inside a branch makes the compiler drain the whole queue (vmcnt(0)).
   if constexpr (PRO == PRO_LN) {
-    // LayerNorm of hn = h + prev_bias + sum(parts) (eps 1e-5, transformer.py:30), two-pass, the whole
-    // block on one row at a time: thread t owns float4 columns t and t+256.  Rows beyond the first are
-    // software-pipelined through two register sets (the next row's loads fly during this row's math).
-    float* s_sum = reinterpret_cast<float*>(red);        // [4] wave partials (the reduce area is free until step 4)
-    float* s_sq = s_sum + 4;
+    // LayerNorm fold (see the top of this file): X = hn = h + prev_bias + sum(parts), un-normalised; the row's
+    // sum and sum of squares (of the ROUNDED values the MFMA multiplies) are reduced per wave here, in the
+    // shadow of the weight stream, and combined in the epilogue.  The whole block works on one row at a time:
+    // thread t owns float4 columns t and t+256.  Rows beyond the first are software-pipelined through two
+    // register sets (the next row's loads fly during this row's arithmetic).
     const int d = a.d;
     const int nq = d >> 2;                               // float4 per row (<= 512)
     const bool on0 = tid < nq, on1 = tid + 256 < nq;
     const int c0 = on0 ? tid * 4 : 0, c1 = on1 ? (tid + 256) * 4 : 0;
-    const float4 g0 = *reinterpret_cast<const float4*>(a.ln_w + c0), g1 = *reinterpret_cast<const float4*>(a.ln_w + c1);
-    const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + c0), b1 = *reinterpret_cast<const float4*>(a.ln_b + c1);
     const float4 pb0 = *reinterpret_cast<const float4*>(a.prev_bias + c0), pb1 = *reinterpret_cast<const float4*>(a.prev_bias + c1);
     const bool use_pb = a.has_prev_bias != 0;
     float4 x0A, x1A, p0A[VC_MAX_KSPLIT], p1A[VC_MAX_KSPLIT];
@@ -251,36 +314,26 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
         x0.x += u_ ? p0##S[s_].x : 0.f; x0.y += u_ ? p0##S[s_].y : 0.f; x0.z += u_ ? p0##S[s_].z : 0.f; x0.w += u_ ? p0##S[s_].w : 0.f; \
         x1.x += u_ ? p1##S[s_].x : 0.f; x1.y += u_ ? p1##S[s_].y : 0.f; x1.z += u_ ? p1##S[s_].z : 0.f; x1.w += u_ ? p1##S[s_].w : 0.f; \
       }                                                                                          \
-      const float t0_ = on0 ? ((x0.x + x0.y) + (x0.z + x0.w)) : 0.f;                             \
-      const float t1_ = on1 ? ((x1.x + x1.y) + (x1.z + x1.w)) : 0.f;                             \
-      const float ws_ = wave_sum(t0_ + t1_);                                                     \
-      if (lane == 0) s_sum[wave] = ws_;                                                          \
-      __syncthreads();                                                                           \
-      const float mean_ = ((s_sum[0] + s_sum[1]) + (s_sum[2] + s_sum[3])) / (float)d;            \
-      const float dx_ = x0.x - mean_, dy_ = x0.y - mean_, dz_ = x0.z - mean_, dw_ = x0.w - mean_; \
-      const float ex_ = x1.x - mean_, ey_ = x1.y - mean_, ez_ = x1.z - mean_, ew_ = x1.w - mean_; \
-      const float q0_ = on0 ? ((dx_ * dx_ + dy_ * dy_) + (dz_ * dz_ + dw_ * dw_)) : 0.f;         \
-      const float q1_ = on1 ? ((ex_ * ex_ + ey_ * ey_) + (ez_ * ez_ + ew_ * ew_)) : 0.f;         \
-      const float wq_ = wave_sum(q0_ + q1_);                                                     \
-      if (lane == 0) s_sq[wave] = wq_;                                                           \
-      __syncthreads();                                                                           \
-      const float rstd_ = 1.0f / sqrtf(((s_sq[0] + s_sq[1]) + (s_sq[2] + s_sq[3])) / (float)d + 1e-5f); \
       const bool writer_ = a.h_out && grp == 0 && (((r) % (int)gridDim.x) == (int)blockIdx.x);   \
       WT* xr_ = reinterpret_cast<WT*>(xl + (size_t)(r) * xs);                                    \
+      float s1_ = 0.f, s2_ = 0.f;                                                                \
       if (on0) {                                                                                 \
         if (writer_) *reinterpret_cast<float4*>(a.h_out + (long)(r) * d + c0) = x0;              \
-        f32x4 y_;                                                                                \
-        y_[0] = dx_ * rstd_ * g0.x + b0.x; y_[1] = dy_ * rstd_ * g0.y + b0.y;                    \
-        y_[2] = dz_ * rstd_ * g0.z + b0.z; y_[3] = dw_ * rstd_ * g0.w + b0.w;                    \
-        store4(xr_ + c0, y_);                                                                    \
+        const f32x4 y_ = {x0.x, x0.y, x0.z, x0.w};                                               \
+        const f32x4 q_ = store4r(xr_ + c0, y_);                                                  \
+        s1_ += (q_[0] + q_[1]) + (q_[2] + q_[3]);                                                \
+        s2_ += (q_[0] * q_[0] + q_[1] * q_[1]) + (q_[2] * q_[2] + q_[3] * q_[3]);                \
       }                                                                                          \
       if (on1) {                                                                                 \
         if (writer_) *reinterpret_cast<float4*>(a.h_out + (long)(r) * d + c1) = x1;              \
-        f32x4 y_;                                                                                \
-        y_[0] = ex_ * rstd_ * g1.x + b1.x; y_[1] = ey_ * rstd_ * g1.y + b1.y;                    \
-        y_[2] = ez_ * rstd_ * g1.z + b1.z; y_[3] = ew_ * rstd_ * g1.w + b1.w;                    \
-        store4(xr_ + c1, y_);                                                                    \
+        const f32x4 y_ = {x1.x, x1.y, x1.z, x1.w};                                               \
+        const f32x4 q_ = store4r(xr_ + c1, y_);                                                  \
+        s1_ += (q_[0] + q_[1]) + (q_[2] + q_[3]);                                                \
+        s2_ += (q_[0] * q_[0] + q_[1] * q_[1]) + (q_[2] * q_[2] + q_[3] * q_[3]);                \
       }                                                                                          \
+      s1_ = wave_sum(s1_);                                                                       \
+      s2_ = wave_sum(s2_);                                                                       \
+      if (lane == 0) { stat[((r) * 4 + wave) * 2] = s1_; stat[((r) * 4 + wave) * 2 + 1] = s2_; } \
     }
     VC_LOAD_ROW(A, 0, 1);
     VC_ISSUE_WEIGHTS(0);
@@ -462,6 +515,15 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
     }
+    if constexpr (PRO == PRO_LN) {   // LayerNorm fold: y = rstd * (W'x - mean * rowsum(W')) [+ cb in the epilogue]
+      const float4 sa = *reinterpret_cast<const float4*>(stat + m * 8), sb = *reinterpret_cast<const float4*>(stat + m * 8 + 4);
+      const float inv_d = 1.0f / (float)a.d;
+      const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * inv_d;
+      const float var = fmaxf(((sa.y + sa.w) + (sb.y + sb.w)) * inv_d - mean * mean, 0.f);
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);      // eps 1e-5 (transformer.py:30)
+      acc[0] = rstd * (acc[0] - mean * ewg.x); acc[1] = rstd * (acc[1] - mean * ewg.y);
+      acc[2] = rstd * (acc[2] - mean * ewg.z); acc[3] = rstd * (acc[3] - mean * ewg.w);
+    }
     gemm_epilogue<WT, EPI>(a, acc, m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
   }
   VC_KTS(6);
@@ -622,7 +684,8 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
 #undef VC_XQ_STORE
 }
 
-// h_new = h + prev_bias + sum of split-K slabs ; x = LayerNorm(h_new) as WT.  One block per row.
+// h_new = h + prev_bias + sum of split-K slabs ; x_hat = (h_new - mean) * rstd as WT (the affine part of the
+// LayerNorm lives in the folded weights, see the top of this file).  One block per row.
 template <typename WT>
 __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   __shared__ float s_sum[4], s_sq[4];
@@ -632,8 +695,8 @@ __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   const int nq = d >> 2;
   const bool on0 = tid < nq, on1 = tid + 256 < nq;
   const int c0 = on0 ? tid * 4 : 0, c1 = on1 ? (tid + 256) * 4 : 0;
-  // every operand is requested before anything is waited for (one round trip): the row, the bias,
-  // all VC_MAX_KSPLIT slabs (unused ones are read and discarded by a select) and the LayerNorm parameters
+  // every operand is requested before anything is waited for (one round trip): the row, the bias and
+  // all VC_MAX_KSPLIT slabs (unused ones are read and discarded by a select)
   const float* hp = a.h_in + (long)r * d;
   float4 x0 = *reinterpret_cast<const float4*>(hp + c0), x1 = *reinterpret_cast<const float4*>(hp + c1);
   const float4 pb0 = *reinterpret_cast<const float4*>(a.prev_bias + c0), pb1 = *reinterpret_cast<const float4*>(a.prev_bias + c1);
@@ -644,8 +707,6 @@ __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
     p0[s] = *reinterpret_cast<const float4*>(pp + c0);
     p1[s] = *reinterpret_cast<const float4*>(pp + c1);
   }
-  const float4 g0 = *reinterpret_cast<const float4*>(a.ln_w + c0), g1 = *reinterpret_cast<const float4*>(a.ln_w + c1);
-  const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + c0), b1 = *reinterpret_cast<const float4*>(a.ln_b + c1);
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
   if (a.has_prev_bias) {
@@ -673,12 +734,12 @@ __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   WT* xo = reinterpret_cast<WT*>(a.x_out) + (long)r * d;
   if (on0) {
     if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (long)r * d + c0) = x0;
-    f32x4 y = {dx * rstd * g0.x + b0.x, dy * rstd * g0.y + b0.y, dz * rstd * g0.z + b0.z, dw * rstd * g0.w + b0.w};
+    f32x4 y = {dx * rstd, dy * rstd, dz * rstd, dw * rstd};
     store4(xo + c0, y);
   }
   if (on1) {
     if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (long)r * d + c1) = x1;
-    f32x4 y = {ex * rstd * g1.x + b1.x, ey * rstd * g1.y + b1.y, ez * rstd * g1.z + b1.z, ew * rstd * g1.w + b1.w};
+    f32x4 y = {ex * rstd, ey * rstd, ez * rstd, ew * rstd};
     store4(xo + c1, y);
   }
 }
@@ -692,7 +753,7 @@ hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s) {
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   const int esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
   const size_t xs = (size_t)(a.K / ksplit) * esz + 16;
-  return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4);
+  return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4) + VC_ROWS * 4 * 2 * sizeof(float);   // X rows, K-reduce area, LN statistics
 }
 
 template <typename WT, int KTW, int PRO, int EPI>
