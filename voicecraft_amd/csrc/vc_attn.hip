@@ -45,7 +45,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hd = a.hd;
-  const int LPR = hd / EPL;            // lanes per cached row: 8, 16 or 32
+  const int LPR = hd / EPL;            // lanes per cached row: 4 (bf16, head_dim 32), 8, 16 or 32
   const int PPW = 64 / LPR;            // positions per wave per step
   const int sub = lane / LPR, li = lane - sub * LPR;
 
@@ -101,7 +101,8 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
         float sc = 0.f;
 #pragma unroll
         for (int j = 0; j < EPL; ++j) sc += q[j] * kf[j];
-        if (LPR == 8) sc = half_row_sum(sc);
+        if (LPR == 4) sc = quad_sum(sc);
+        else if (LPR == 8) sc = half_row_sum(sc);
         else { sc = row_sum(sc); if (LPR == 32) sc += __shfl_xor(sc, 16, 64); }
         if (pp[it] < p1) {
           const float mn = fmaxf(m, sc);

@@ -88,6 +88,11 @@ __device__ __forceinline__ float row_sum(float v) {        // every lane gets th
   v += dpp_f<VC_DPP_ROW_MIRROR>(v);
   return v;
 }
+__device__ __forceinline__ float quad_sum(float v) {       // sum over aligned groups of 4 lanes
+  v += dpp_f<VC_DPP_QP_1032>(v);
+  v += dpp_f<VC_DPP_QP_2301>(v);
+  return v;
+}
 __device__ __forceinline__ float half_row_sum(float v) {   // sum over aligned groups of 8 lanes
   v += dpp_f<VC_DPP_QP_1032>(v);
   v += dpp_f<VC_DPP_QP_2301>(v);

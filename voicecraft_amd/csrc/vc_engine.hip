@@ -559,7 +559,7 @@ extern "C" int vc_create(const vc_model_cfg* c, int hip_device, vc_engine** out)
     return fail(nullptr, VC_EINVAL, "d_model %d must be a multiple of 256 and <= 2048", c->d_model);
   if (c->nhead <= 0 || c->d_model % c->nhead) return fail(nullptr, VC_EINVAL, "nhead %d does not divide d_model", c->nhead);
   const int hd = c->d_model / c->nhead;
-  if (hd != 32 && hd != 64 && hd != 128)   // the attention kernel spreads a cached row over 8, 16 or 32 lanes
+  if (hd != 32 && hd != 64 && hd != 128)   // the attention kernel spreads a cached row over 4, 8, 16 or 32 lanes
     return fail(nullptr, VC_EINVAL, "head_dim %d must be 32, 64 or 128", hd);
   if ((hd & (hd - 1)) != 0) return fail(nullptr, VC_EINVAL, "head_dim %d must be a power of two", hd);
   if (c->n_codebooks < 1 || c->n_codebooks > VC_MAX_CODEBOOKS) return fail(nullptr, VC_EINVAL, "n_codebooks %d unsupported", c->n_codebooks);
