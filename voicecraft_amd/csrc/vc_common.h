@@ -286,27 +286,35 @@ struct PromptArgs {
   int logit_row_val;        //           whose hidden state feeds the heads)
 };
 
-struct SampleArgs {
-  const float* logits;      // [B][K][V]
-  int B, K, V, d;
+// Per-call values of the sampler: they live in device memory (written once per call), so that the captured
+// decode step does not depend on them and its hipGraphExec can be kept across calls (vc_engine.hip).
+struct SampleDyn {
   int top_k;
   float top_p, temperature;
   int stop_repetition, n_silence;
   int silence[VC_MAX_SILENCE];
+  int forced_mode;          // 0: the step's final tokens are replaced; 1: the raw draws are replaced (vc_sample_cfg.forced_mode)
+  int n_forced;
+  int logit_steps;
+  int max_steps;            // rows of the gen buffer per sequence this call may fill
+  int pad_;
   uint64_t seed;
+  const int64_t* forced;    // [n_forced][B][K] or null
+  float* logits_out;        // [logit_steps][B][K][V] or null
+  long long* dbg_ts;        // optional [16] shader-clock stamps of sequence 0 (diagnosis only)
+};
+
+struct SampleArgs {         // engine-constant part (kernel argument)
+  const float* logits;      // [B][K][V]
+  int B, K, V, d;
   int empty_token;
+  int gen_stride;           // rows of the gen buffer per sequence
+  const SampleDyn* dyn;
   SeqState* st;
   int* n_active;
-  int* samp;                // scratch [B][K]
-  int* cond;                // scratch [B]
-  int* amax;                // scratch [B]
-  int* gen;                 // [B][max_steps][K]
-  int max_steps;
-  const int64_t* forced;    // [n_forced][B][K] or null
-  int n_forced;
-  int forced_mode;          // 0: the step's final tokens are replaced; 1: the raw draws are replaced (vc_sample_cfg.forced_mode)
-  float* logits_out;        // [logit_steps][B][K][V] or null
-  int logit_steps;
+  int* host_active;         // pinned host word (device-visible): set to 0 by the block that retires the last sequence
+  int* samp;                // scratch [B][K + 2]
+  int* gen;                 // [B][gen_stride][K]
   // next-step rows
   int rps;                  // rows per sequence slot (1, or 3 for editing)
   float* dec_h;             // [B*rps][d]
@@ -318,7 +326,6 @@ struct SampleArgs {
   const float* pe;
   float alpha_audio;
   int max_positions;
-  long long* dbg_ts;        // optional [16] shader-clock stamps of sequence 0 (diagnosis only)
 };
 
 struct AssembleArgs {       // writes res [K][res_cap] from y and the generated spans

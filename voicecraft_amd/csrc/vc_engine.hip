@@ -14,6 +14,7 @@
 #include <chrono>
 #include <map>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "vc_common.h"
@@ -74,7 +75,12 @@ struct vc_engine {
   int gen_cap = 0;
   // pinned host staging
   SeqState *h_st = nullptr;
-  int *h_flag = nullptr;
+  int *h_flag = nullptr;                // [0] error/poll word, [1] staging, [8] "sequences still active" written by the device
+  SampleDyn *h_dyn = nullptr, *d_dyn = nullptr;   // per-call sampler values (vc_common.h)
+  // captured decode steps, kept across calls: key = (sequences, rows per sequence, best-of-N)
+  std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
+  int steps_per_graph = 8;              // VC_GRAPH_STEPS: decode steps captured into one graph launch
+  hipEvent_t ev_pace[2]{};
 
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
   int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
@@ -432,23 +438,39 @@ void fill_prompt_common(vc_engine* e, PromptArgs& pa, const int64_t* x, int Lx, 
   pa.text_rows = e->cfg.text_rows;
 }
 
-SampleArgs make_sample_args(vc_engine* e, const vc_sample_cfg* sc, int B, int rps) {
+// Engine-constant sampler arguments; the per-call values go through e->h_dyn -> e->d_dyn (push_sample_dyn).
+SampleArgs make_sample_args(vc_engine* e, int B, int rps) {
   SampleArgs a;
   memset(&a, 0, sizeof a);
   a.logits = e->logits; a.B = B; a.K = e->K; a.V = e->V; a.d = e->d;
-  a.top_k = sc->top_k; a.top_p = sc->top_p; a.temperature = sc->temperature;
-  a.stop_repetition = sc->stop_repetition;
-  a.n_silence = std::max(0, std::min(sc->n_silence, VC_MAX_SILENCE));
-  for (int i = 0; i < a.n_silence; ++i) a.silence[i] = sc->silence_tokens[i];
-  a.seed = sc->seed; a.empty_token = e->cfg.empty_token;
-  a.st = e->st; a.n_active = e->n_active; a.samp = e->samp; a.cond = e->cond; a.amax = e->amax;
-  a.gen = e->gen; a.max_steps = e->gen_cap;
+  a.empty_token = e->cfg.empty_token; a.gen_stride = e->gen_cap; a.dyn = e->d_dyn;
+  a.st = e->st; a.n_active = e->n_active; a.host_active = e->h_flag + 8; a.samp = e->samp;
+  a.gen = e->gen;
   a.rps = rps; a.dec_h = e->dec_h; a.row_seq = e->dec_row_seq; a.row_pos = e->dec_row_pos;
   a.logit_row = e->logit_row;
   a.audio_emb = e->audio_emb; a.mask_emb = e->mask_emb; a.pe = e->pe; a.alpha_audio = e->alpha_audio;
   a.max_positions = e->S_max;
-  a.dbg_ts = getenv("VC_SAMPLER_TS") ? e->dbg_ts : nullptr;
   return a;
+}
+
+int push_sample_dyn(vc_engine* e, const vc_sample_cfg* sc, const int64_t* forced, int n_forced, float* logits_out,
+                    int logit_steps, int max_steps, hipStream_t s) {
+  SampleDyn& d = *e->h_dyn;
+  memset(&d, 0, sizeof d);
+  d.top_k = sc->top_k; d.top_p = sc->top_p; d.temperature = sc->temperature;
+  d.stop_repetition = sc->stop_repetition;
+  if (sc->n_silence < 0 || sc->n_silence > VC_MAX_SILENCE)
+    return fail(e, VC_EINVAL, "n_silence %d outside [0,%d]", sc->n_silence, VC_MAX_SILENCE);
+  d.n_silence = sc->n_silence;
+  for (int i = 0; i < d.n_silence; ++i) d.silence[i] = sc->silence_tokens[i];
+  d.seed = sc->seed;
+  d.forced = forced; d.n_forced = forced ? n_forced : 0; d.forced_mode = sc->forced_mode;
+  d.logits_out = logits_out; d.logit_steps = logits_out ? logit_steps : 0;
+  (void)max_steps;
+  d.max_steps = e->gen_cap;                               // rows of the gen buffer per sequence
+  d.dbg_ts = getenv("VC_SAMPLER_TS") ? e->dbg_ts : nullptr;
+  HIPCHK(e, hipMemcpyAsync(e->d_dyn, e->h_dyn, sizeof(SampleDyn), hipMemcpyHostToDevice, s));
+  return VC_OK;
 }
 
 int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, hipStream_t s) {
@@ -463,48 +485,64 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   return VC_OK;
 }
 
-// The decode loop: every step is the same launch sequence (all step-dependent values live in
-// HBM), so it is captured once per call and replayed; the host only polls the active counter.
+// The decode loop: every step is the same launch sequence (all step-dependent values live in HBM, the
+// per-call sampler values behind a pointer), so `steps_per_graph` steps are captured ONCE per (sequences,
+// rows per sequence, best-of-N) into a hipGraphExec that is kept for the life of the engine and replayed.
+// The host never touches the stream inside the loop: the device clears a pinned host word when the last
+// sequence retires, and the host paces itself one graph behind the GPU with events, so a queued graph is
+// always waiting when the running one ends (measured before: ~8 us of idle GPU per graph launch and ~100 us
+// per blocking poll).  Steps replayed after the last sequence retired are no-ops (*n_active == 0).
 int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, const vc_sample_cfg* sc,
                 int max_steps, int* steps_run, hipStream_t s) {
-  const int poll = sc->poll_every > 0 ? sc->poll_every : 16;
-  hipGraph_t graph = nullptr;
+  const int G = std::max(1, e->steps_per_graph);
   hipGraphExec_t exec = nullptr;
   const double t0 = now_ms();
+  e->host_ms[1] = e->host_ms[2] = 0;
   if (sc->use_graph) {
-    HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    int rc = decode_step(e, sa, B, rps, grouped, s);
-    hipError_t ce = hipStreamEndCapture(s, &graph);
-    if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
-    HIPCHK(e, ce);
-    e->host_ms[1] = now_ms() - t0;
-    HIPCHK(e, hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0));
-    e->host_ms[2] = now_ms() - t0 - e->host_ms[1];
+    const auto key = std::make_tuple(B, rps, grouped ? 1 : 0);
+    auto it = e->graphs.find(key);
+    if (it != e->graphs.end()) {
+      exec = it->second;
+    } else {
+      hipGraph_t graph = nullptr;
+      HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+      int rc = VC_OK;
+      for (int i = 0; i < G && rc == VC_OK; ++i) rc = decode_step(e, sa, B, rps, grouped, s);
+      hipError_t ce = hipStreamEndCapture(s, &graph);
+      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+      HIPCHK(e, ce);
+      e->host_ms[1] = now_ms() - t0;
+      hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+      hipGraphDestroy(graph);
+      if (ie != hipSuccess) return fail(e, VC_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+      e->host_ms[2] = now_ms() - t0 - e->host_ms[1];
+      e->graphs[key] = exec;
+    }
   }
   const double t1 = now_ms();
-  int done_steps = 0, rc = VC_OK;
-  while (done_steps < max_steps) {
-    const int n = std::min(poll, max_steps - done_steps);
-    for (int i = 0; i < n && rc == VC_OK; ++i) {
-      if (exec) {
-        hipError_t le = hipGraphLaunch(exec, s);
-        if (le != hipSuccess) rc = fail(e, VC_EHIP, "hipGraphLaunch failed: %s", hipGetErrorString(le));
-      } else {
-        rc = decode_step(e, sa, B, rps, grouped, s);
-      }
+  volatile int* live = e->h_flag + 8;
+  int launched = 0, rc = VC_OK, batch = 0;
+  while (launched < max_steps && rc == VC_OK) {
+    if (batch >= 2) {   // pace: at most two batches in flight; the older one must have ended before a third is queued
+      hipError_t we = hipEventSynchronize(e->ev_pace[batch & 1]);
+      if (we != hipSuccess) { rc = fail(e, VC_EHIP, "pacing event: %s", hipGetErrorString(we)); break; }
+      if (*live <= 0) break;
+    }
+    if (exec) {
+      hipError_t le = hipGraphLaunch(exec, s);
+      if (le != hipSuccess) rc = fail(e, VC_EHIP, "hipGraphLaunch failed: %s", hipGetErrorString(le));
+    } else {
+      for (int i = 0; i < G && rc == VC_OK; ++i) rc = decode_step(e, sa, B, rps, grouped, s);
     }
     if (rc) break;
-    done_steps += n;
-    hipError_t me = hipMemcpyAsync(e->h_flag, e->n_active, sizeof(int), hipMemcpyDeviceToHost, s);
-    if (me == hipSuccess) me = hipStreamSynchronize(s);
-    if (me != hipSuccess) { rc = fail(e, VC_EHIP, "poll failed: %s", hipGetErrorString(me)); break; }
-    if (*e->h_flag <= 0) break;
+    launched += G;
+    hipError_t re = hipEventRecord(e->ev_pace[batch & 1], s);
+    if (re != hipSuccess) { rc = fail(e, VC_EHIP, "hipEventRecord: %s", hipGetErrorString(re)); break; }
+    ++batch;
   }
   e->host_ms[3] = now_ms() - t1;
-  if (exec) hipGraphExecDestroy(exec);
-  if (graph) hipGraphDestroy(graph);
-  e->host_ms[4] = now_ms() - t1 - e->host_ms[3];
-  if (steps_run) *steps_run = done_steps;
+  e->host_ms[4] = 0;
+  if (steps_run) *steps_run = launched;
   return rc;
 }
 
@@ -591,6 +629,9 @@ extern "C" void vc_destroy(vc_engine* e) {
   for (void* p : e->allocs) hipFree(p);
   if (e->h_st) hipHostFree(e->h_st);
   if (e->h_flag) hipHostFree(e->h_flag);
+  if (e->h_dyn) hipHostFree(e->h_dyn);
+  for (auto& kv : e->graphs) if (kv.second) hipGraphExecDestroy(kv.second);
+  for (auto& ev : e->ev_pace) if (ev) hipEventDestroy(ev);
   for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
   if (e->own_stream) hipStreamDestroy(e->own_stream);
   delete e;
@@ -769,6 +810,10 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   { const int one[4] = {1, 1, 1, 1}; HIPCHK(e, hipMemcpy(e->one, one, 16, hipMemcpyHostToDevice)); }
   HIPCHK(e, hipHostMalloc((void**)&e->h_st, sizeof(SeqState) * VC_ROWS));
   HIPCHK(e, hipHostMalloc((void**)&e->h_flag, 64));
+  memset(e->h_flag, 0, 64);
+  HIPCHK(e, hipHostMalloc((void**)&e->h_dyn, sizeof(SampleDyn)));
+  if ((rc = dalloc(e, &e->d_dyn, (size_t)1))) return rc;
+  for (auto& ev : e->ev_pace) HIPCHK(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
   for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
   // a blocking stream: implicitly ordered after work the caller queued on the null stream
   HIPCHK(e, hipStreamCreate(&e->own_stream));
@@ -779,6 +824,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));
     const char* ls = getenv("VC_LN_SPLIT_ROWS");
     if (ls) e->ln_split_rows = std::max(2, atoi(ls));
+    const char* gs = getenv("VC_GRAPH_STEPS");
+    if (gs) e->steps_per_graph = std::max(1, std::min(64, atoi(gs)));
   }
   HIPCHK(e, hipDeviceSynchronize());
   e->finalized = true;
@@ -844,13 +891,14 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   }
   HIPCHK(e, hipMemcpyAsync(e->st, e->h_st, sizeof(SeqState) * B, hipMemcpyHostToDevice, s));
   e->h_flag[1] = B;
+  e->h_flag[8] = B;
   HIPCHK(e, hipMemcpyAsync(e->n_active, e->h_flag + 1, sizeof(int), hipMemcpyHostToDevice, s));
-  int rc = check_err_flag(e, s);   // also orders the pinned-buffer reuse
+  int rc = push_sample_dyn(e, sc, forced, n_forced, logits_out, logit_steps, max_steps, s);
+  if (rc) return rc;
+  rc = check_err_flag(e, s);   // also orders the pinned-buffer reuse
   if (rc) return rc;
   // ---- first sample comes from the prefill logits, then the decode loop
-  SampleArgs sa = make_sample_args(e, sc, B, 1);
-  sa.forced = forced; sa.n_forced = forced ? n_forced : 0; sa.forced_mode = sc->forced_mode;
-  sa.logits_out = logits_out; sa.logit_steps = logits_out ? logit_steps : 0;
+  SampleArgs sa = make_sample_args(e, B, 1);
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   int steps_run = 0;
@@ -862,7 +910,12 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];
-  if (steps_out) *steps_out = steps_run;
+  if (steps_out) {   // steps really taken (the longest sequence), not the launched multiple of steps_per_graph
+    int m = 0;
+    for (int b = 0; b < B; ++b) m = std::max(m, e->h_st[b].total_steps);
+    *steps_out = m;
+  }
+  (void)steps_run;
   return VC_OK;
 }
 
@@ -999,13 +1052,14 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   e->h_st[0] = st;
   HIPCHK(e, hipMemcpyAsync(e->st, e->h_st, sizeof(SeqState), hipMemcpyHostToDevice, s));
   e->h_flag[1] = 1;
+  e->h_flag[8] = 1;
   HIPCHK(e, hipMemcpyAsync(e->n_active, e->h_flag + 1, sizeof(int), hipMemcpyHostToDevice, s));
+  rc = push_sample_dyn(e, sc, forced_dev, n_forced, logits_dev, logit_steps, max_steps, s);
+  if (rc) return rc;
   rc = check_err_flag(e, s);
   if (rc) return rc;
   const int rps = (M > 1) ? 3 : 1;
-  SampleArgs sa = make_sample_args(e, sc, 1, rps);
-  sa.forced = forced_dev; sa.n_forced = forced_dev ? n_forced : 0; sa.forced_mode = sc->forced_mode;
-  sa.logits_out = logits_dev; sa.logit_steps = logits_dev ? logit_steps : 0;
+  SampleArgs sa = make_sample_args(e, 1, rps);
   HIPCHK(e, vc_launch_sample(sa, false, s));
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   int steps_run = 0;
@@ -1017,7 +1071,8 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];
-  if (n_steps) *n_steps = steps_run;
+  if (n_steps) *n_steps = e->h_st[0].total_steps;
+  (void)steps_run;
   const SeqState& fs = e->h_st[0];
   if (!fs.done || fs.span < M)
     return fail(e, VC_ECAP, "editing ran out of room before it terminated (max_positions %d): raise max_positions", e->S_max);

@@ -151,11 +151,81 @@ __device__ __forceinline__ uint32_t fkey(float f) {   // order-preserving float 
   const uint32_t u = __float_as_uint(f);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
 }
-__device__ __forceinline__ bool is_silence(const SampleArgs& a, int tok) {
+__device__ __forceinline__ bool is_silence(const SampleDyn& dy, int tok) {
   bool r = false;
 #pragma unroll
-  for (int i = 0; i < VC_MAX_SILENCE; ++i) r |= (i < a.n_silence && a.silence[i] == tok);   // static indices: no scratch copy
+  for (int i = 0; i < VC_MAX_SILENCE; ++i) r |= (i < dy.n_silence && dy.silence[i] == tok);   // static indices: no scratch copy
   return r;
+}
+
+// inclusive prefix sum over the 64 lanes on the DPP path: Hillis-Steele inside each 16-lane row (row_shr
+// 1, 2, 4, 8; lanes shifted in from outside the row read 0), then the three row totals through v_readlane.
+__device__ __forceinline__ float wave_scan_incl(float v) {
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x111, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x112, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x114, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x118, 0xF, 0xF, true));
+  const float t0 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 15));
+  const float t1 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 31));
+  const float t2 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 47));
+  const int row = (threadIdx.x & 63) >> 4;
+  const float add = (row >= 1 ? t0 : 0.f) + (row >= 2 ? t1 : 0.f) + (row >= 3 ? t2 : 0.f);
+  return v + add;
+}
+
+// ---- k-th largest key of the row a wave holds in registers (kk >= 1), exact.
+// Bitwise binary search over all VC_VPL keys per lane: 32 steps of VC_VPL compares + a wave sum.
+__device__ __forceinline__ uint32_t kth_largest_full(const uint32_t (&key)[VC_VPL], int kk) {
+  uint32_t t = 0;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = t | (1u << bit);
+    int c = 0;
+#pragma unroll
+    for (int j = 0; j < VC_VPL; ++j) c += (key[j] >= cand) ? 1 : 0;
+    const int cs = wave_sum_i(c);
+    if (cs >= kk) {
+      t = cand;
+      if (cs == kk) break;        // exactly the kk largest keys are >= t already: the remaining bits cannot change the kept set
+    }
+  }
+  return t;
+}
+// Fast path for kk <= 64 (the path's top_k is 40): every lane keeps the 5 largest of its keys (a branch-free
+// max/min insertion), the search then runs on those 320 candidates with wave ballots (5 compares per step
+// instead of 34), and ONE count over the whole row proves the result: if the row holds exactly as many keys
+// >= t as the candidate set, no key outside the set reaches t, so t is the row's kk-th largest.  Otherwise
+// (a lane owns more than 5 of the kk largest: ~0.3 % of random rows at kk = 40) the full search runs.
+__device__ __forceinline__ uint32_t kth_largest(const uint32_t (&key)[VC_VPL], int kk) {
+  if (kk > 64) return kth_largest_full(key, kk);
+  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, m4 = 0;
+#pragma unroll
+  for (int j = 0; j < VC_VPL; ++j) {
+    uint32_t x = key[j], t_;
+    t_ = max(m0, x); x = min(m0, x); m0 = t_;
+    t_ = max(m1, x); x = min(m1, x); m1 = t_;
+    t_ = max(m2, x); x = min(m2, x); m2 = t_;
+    t_ = max(m3, x); x = min(m3, x); m3 = t_;
+    m4 = max(m4, x);
+  }
+  uint32_t t = 0;
+  int cu = 0;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const uint32_t cand = t | (1u << bit);
+    const int c = __popcll(__ballot(m0 >= cand)) + __popcll(__ballot(m1 >= cand)) + __popcll(__ballot(m2 >= cand)) +
+                  __popcll(__ballot(m3 >= cand)) + __popcll(__ballot(m4 >= cand));
+    if (c >= kk) {
+      t = cand; cu = c;
+      if (c == kk) break;
+    }
+  }
+  int ca = 0;
+#pragma unroll
+  for (int j = 0; j < VC_VPL; ++j) ca += (key[j] >= t) ? 1 : 0;
+  ca = wave_sum_i(ca);
+  if (ca != cu) t = kth_largest_full(key, kk);
+  return t;
 }
 
 // Phase 1 (one block per sequence, one wave per codebook): logit edits, top-k / top-p filter,
@@ -166,7 +236,7 @@ __device__ __forceinline__ bool is_silence(const SampleArgs& a, int tok) {
 // with rolled loops spends 34 us in the 32-step threshold search alone (LDS latency per element).
 // `sp` is the sequence state (in LDS); results go to xs (LDS in the fused kernel, HBM scratch when the
 // keep decision needs the kernel boundary): xs[0..K) tokens, xs[K] arg-max of codebook 0, xs[K+1] cond.
-#define VC_TS(i) do { if (a.dbg_ts && b == 0 && threadIdx.x == 0) a.dbg_ts[i] = clock64(); } while (0)
+#define VC_TS(i) do { if (dy.dbg_ts && b == 0 && threadIdx.x == 0) dy.dbg_ts[i] = clock64(); } while (0)
 // The logits row of codebook k = wave does not depend on the sequence state: the kernels request it
 // before anything else (v0), so that the state's round trip and the row's overlap.
 __device__ __forceinline__ void preload_row(const SampleArgs& a, int b, float (&v0)[VC_VPL]) {
@@ -177,39 +247,27 @@ __device__ __forceinline__ void preload_row(const SampleArgs& a, int b, float (&
 }
 // temperature -> top-k -> softmax -> top-p -> inverse-CDF draw for the row a wave holds in registers
 // (v: edited logits, padding -inf; bv: their maximum; u: the uniform of this draw).  Wave-uniform result.
-__device__ __forceinline__ int filter_draw(const SampleArgs& a, int b, float (&v)[VC_VPL], float bv, int V, float u) {
+__device__ __forceinline__ int filter_draw(int top_k, float top_p, float temperature, float (&v)[VC_VPL], float bv,
+                                           int V, float u) {
   const int lane = threadIdx.x & 63;
   // ---- temperature
   float mx = bv;
-  if (a.temperature != 1.0f) {
+  if (temperature != 1.0f) {
 #pragma unroll
-    for (int j = 0; j < VC_VPL; ++j) v[j] = v[j] / a.temperature;
-    mx = bv / a.temperature;                      // filters never remove the maximum
+    for (int j = 0; j < VC_VPL; ++j) v[j] = v[j] / temperature;
+    mx = bv / temperature;                      // filters never remove the maximum
   }
-  // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive).
-  // Bitwise binary search for the k-th largest order-preserving key, on registers.
-  if (a.top_k > 0) {
-    const int kk = min(max(a.top_k, 1), V);
+  // ---- top-k: keep everything >= the k-th largest value (ties at the threshold survive, as
+  // `logits < topk(...)[-1]` in the reference, voicecraft.py:38-44)
+  if (top_k > 0) {
+    const int kk = min(max(top_k, 1), V);
     uint32_t key[VC_VPL];
 #pragma unroll
     for (int j = 0; j < VC_VPL; ++j) key[j] = fkey(v[j]);       // padding: key(-inf) = 0x007fffff, below every finite key
-    uint32_t t = 0;
-#pragma unroll 1
-    for (int bit = 31; bit >= 0; --bit) {
-      const uint32_t cand = t | (1u << bit);
-      int c = 0;
-#pragma unroll
-      for (int j = 0; j < VC_VPL; ++j) c += (key[j] >= cand) ? 1 : 0;
-      const int cs = wave_sum_i(c);
-      if (cs >= kk) {
-        t = cand;
-        if (cs == kk) break;        // exactly the kk largest keys are >= t already: the remaining bits cannot change the kept set
-      }
-    }
+    const uint32_t t = kth_largest(key, kk);
 #pragma unroll
     for (int j = 0; j < VC_VPL; ++j) v[j] = (key[j] < t) ? -INFINITY : v[j];
   }
-  VC_TS(3);
   // ---- softmax numerators (v now holds p >= 0; 0 = filtered out)
   float ps = 0.f;
 #pragma unroll
@@ -217,8 +275,8 @@ __device__ __forceinline__ int filter_draw(const SampleArgs& a, int b, float (&v
   float tot = wave_sum(ps);
   // ---- top-p: drop a token when the mass of the strictly larger ones already exceeds top_p.
   // p is monotone in the logit, and the bits of a non-negative float order like the float.
-  if (a.top_p < 1.0f) {
-    const float lim = a.top_p * tot;
+  if (top_p < 1.0f) {
+    const float lim = top_p * tot;
     // t = the largest key whose strictly-larger mass still exceeds lim (key 0 always qualifies:
     // the whole row weighs tot > lim); exactly the keys <= t are dropped.
     uint32_t t = 0;
@@ -235,14 +293,9 @@ __device__ __forceinline__ int filter_draw(const SampleArgs& a, int b, float (&v
     for (int j = 0; j < VC_VPL; ++j) { v[j] = (__float_as_uint(v[j]) <= t) ? 0.f : v[j]; ps += v[j]; }
     tot = wave_sum(ps);
   }
-  VC_TS(4);
   // ---- categorical draw by inverse CDF, order = (lane, j)
   const float target = u * tot;
-  float incl = ps;
-  for (int off = 1; off < 64; off <<= 1) {
-    const float o = __shfl_up(incl, off, 64);
-    if (lane >= off) incl += o;
-  }
+  const float incl = wave_scan_incl(ps);
   const float excl = incl - ps;
   const bool mine = (ps > 0.f) && (target >= excl) && (target < incl);
   const uint64_t ball = __ballot(mine);
@@ -262,17 +315,18 @@ __device__ __forceinline__ int filter_draw(const SampleArgs& a, int b, float (&v
     last = nz ? lane + 64 * j : last;
     pick = (pick < 0 && nz && target < acc) ? lane + 64 * j : pick;
   }
-  int tok = (pick >= 0) ? pick : last;
-  tok = __shfl(tok, src_lane, 64);
-  return tok;
+  const int tok = (pick >= 0) ? pick : last;
+  return __builtin_amdgcn_readlane(tok, __builtin_amdgcn_readfirstlane(src_lane));
 }
 
-__device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const SeqState* sp, int* xs, float* s_rows,
-                                             const float (&v0)[VC_VPL]) {
-  const SeqState st = *sp;
+__device__ __forceinline__ void sample_phase(const SampleArgs& a, const SampleDyn& dy, int b, const SeqState* sp, int* xs,
+                                             float* s_rows, const float (&v0)[VC_VPL]) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (st.done) return;
-  const int step = st.total_steps;
+  // the fields this phase reads, fetched from LDS in one go
+  const int st_done = sp->done, step = sp->total_steps, term = sp->term_token, kill = sp->kill_token, n_eog = sp->n_eog;
+  const int min_gen = sp->min_gen, cur_num_gen = sp->cur_num_gen, prev_token = sp->prev_token, consec = sp->consec_silence;
+  const int y_len = sp->y_len, cap_len = sp->cap_len;
+  if (st_done) return;
   const int V = a.V;
   const int VP = ((V + 63) >> 6) << 6;
   for (int k = wave; k < a.K; k += 4) {
@@ -286,8 +340,8 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const S
 #pragma unroll
       for (int j = 0; j < VC_VPL; ++j) v[j] = row[min(lane + 64 * j, V - 1)];
     }
-    if (a.logits_out && step < a.logit_steps) {
-      float* lo = a.logits_out + (((long)step * a.B + b) * a.K + k) * V;
+    if (dy.logits_out && step < dy.logit_steps) {
+      float* lo = dy.logits_out + (((long)step * a.B + b) * a.K + k) * V;
 #pragma unroll
       for (int j = 0; j < VC_VPL; ++j) if (lane + 64 * j < V) lo[lane + 64 * j] = v[j];
     }
@@ -296,17 +350,15 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const S
     VC_TS(1);
     // ---- logit edits, in the reference's order; each touches one element, so lane 0 does them in LDS
     if (lane == 0) {
-      const int term = st.term_token;
-      if (st.kill_token >= 0) sv[st.kill_token] = -10000.f;
-      const bool kill_tl = (st.n_eog == 0) ? (k >= 1) : (k > st.n_eog);      // [term],[empty] on later codebooks
+      if (kill >= 0) sv[kill] = -10000.f;
+      const bool kill_tl = (n_eog == 0) ? (k >= 1) : (k > n_eog);      // [term],[empty] on later codebooks
       if (kill_tl) { sv[term] = -10000.f; sv[a.empty_token] = -10000.f; }
-      if (st.n_eog == 0 && k == 0) {
-        if (st.min_gen >= 0 && st.cur_num_gen <= st.min_gen) sv[term] = -10000.f;
-        if (a.stop_repetition > 0 && st.prev_token >= 0 && is_silence(a, st.prev_token) &&
-            st.consec_silence > a.stop_repetition) {
-          const float f = (float)(st.consec_silence - (a.stop_repetition - 1));
-          const float x = sv[st.prev_token];
-          sv[st.prev_token] = (x < 0.f) ? x * f : x / f;
+      if (n_eog == 0 && k == 0) {
+        if (min_gen >= 0 && cur_num_gen <= min_gen) sv[term] = -10000.f;
+        if (dy.stop_repetition > 0 && prev_token >= 0 && is_silence(dy, prev_token) && consec > dy.stop_repetition) {
+          const float f = (float)(consec - (dy.stop_repetition - 1));
+          const float x = sv[prev_token];
+          sv[prev_token] = (x < 0.f) ? x * f : x / f;
         }
       }
     }
@@ -323,14 +375,16 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const S
     for (int j = 0; j < VC_VPL; ++j) bv = fmaxf(bv, v[j]);
     bv = wave_max(bv);
     int bi = 0x7fffffff;
+    if (k == 0) {                                   // only codebook 0's arg-max is ever looked at (voicecraft.py:1041)
 #pragma unroll
-    for (int j = VC_VPL - 1; j >= 0; --j) bi = (v[j] == bv) ? lane + 64 * j : bi;     // padding is -inf, never equal
-    bi = wave_min_i(bi);
+      for (int j = VC_VPL - 1; j >= 0; --j) bi = (v[j] == bv) ? lane + 64 * j : bi;     // padding is -inf, never equal
+      bi = wave_min_i(bi);
+    }
     VC_TS(2);
-    const float u = philox_uniform(a.seed, (uint32_t)b, (uint32_t)step, (uint32_t)k);
-    int tok = filter_draw(a, b, v, bv, V, u);
-    if (a.forced && a.forced_mode == 1 && step < a.n_forced)      // replay of recorded reference draws (parity tests)
-      tok = (int)a.forced[((long)step * a.B + b) * a.K + k];
+    const float u = philox_uniform(dy.seed, (uint32_t)b, (uint32_t)step, (uint32_t)k);
+    int tok = filter_draw(dy.top_k, dy.top_p, dy.temperature, v, bv, V, u);
+    if (dy.forced && dy.forced_mode == 1 && step < dy.n_forced)      // replay of recorded reference draws (parity tests)
+      tok = (int)dy.forced[((long)step * a.B + b) * a.K + k];
     if (lane == 0) {
       xs[k] = tok;
       if (k == 0) xs[a.K] = bi;
@@ -340,97 +394,112 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, int b, const S
   __syncthreads();
   if (tid == 0) {
     int c = 0;
-    if (st.n_eog == 0) c = (xs[0] == st.term_token) || (xs[a.K] == st.term_token) || (st.y_len > st.cap_len);
+    if (n_eog == 0) c = (xs[0] == term) || (xs[a.K] == term) || (y_len > cap_len);
     xs[a.K + 1] = c;
   }
 }
 
 // Phase 2 (one block per sequence): advance the state machine, log the step's tokens and build
 // the next decode rows (embedding sum + position, voicecraft.py:1102-1116; span switch :838-858).
-__device__ void advance_phase(const SampleArgs& a, int b, bool grouped, SeqState* sp, const int* xs) {
+__device__ void advance_phase(const SampleArgs& a, const SampleDyn& dy, int b, bool grouped, SeqState* sp, const int* xs) {
   __shared__ int s_tok[VC_MAX_CODEBOOKS];
   __shared__ int s_mode;     // 0: row inactive, 1: one new row, 3: span switch (three rows)
   __shared__ int s_ylen, s_mask, s_Lx;
   const int tid = threadIdx.x;
   const int K = a.K;
   if (tid == 0) {
-    SeqState& st = *sp;                 // lives in LDS: the span arrays are indexed dynamically
-    s_mode = 0;
-    if (!st.done) {
+    // scalar fields in registers (fetched from LDS in one go); only the span arrays are indexed dynamically
+    const int done0 = sp->done, Lx = sp->Lx, term = sp->term_token, group = sp->group, n_spans = sp->n_spans;
+    int n_eog = sp->n_eog, cur = sp->cur_num_gen, prev = sp->prev_token, consec = sp->consec_silence;
+    int span = sp->span, total = sp->total_steps, y_len = sp->y_len;
+    int mode = 0, mask = 0, ylen_row = y_len;
+    if (!done0) {
       int tok[VC_MAX_CODEBOOKS];
 #pragma unroll
       for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) tok[k] = (k < K) ? xs[k] : 0;
       int cond = xs[K + 1];
       bool drop = false;
-      if (grouped && st.n_eog == 0) {
+      if (grouped && n_eog == 0) {
         // best-of-N (voicecraft.py:1296-1302): the LAST sample whose first codebook terminates is kept
         int keep = -1;
         for (int bb = 0; bb < a.B; ++bb)
-          if (a.st[bb].group == st.group && a.samp[bb * (VC_MAX_CODEBOOKS + 2) + K + 1]) keep = bb;
+          if (a.st[bb].group == group && a.samp[bb * (VC_MAX_CODEBOOKS + 2) + K + 1]) keep = bb;
         // (group ids are immutable and every member is still alive while n_eog == 0)
         if (keep >= 0 && keep != b) drop = true;
       }
-      const int step = st.total_steps;
-      const bool forced = a.forced && a.forced_mode == 0 && step < a.n_forced;
-      if (st.n_eog == 0) {
-        if (st.cur_num_gen < K - 1)
-          for (int jj = 1; jj < K - st.cur_num_gen; ++jj) tok[K - jj] = a.empty_token;
+      const int step = total;
+      const bool forced = dy.forced && dy.forced_mode == 0 && step < dy.n_forced;
+      if (n_eog == 0) {
+#pragma unroll
+        for (int k = 1; k < VC_MAX_CODEBOOKS; ++k)             // the first K-1 steps: codebooks cur+1.. are still `empty`
+          if (k < K && k > cur) tok[k] = a.empty_token;
         if (forced) {
-          for (int k = 0; k < K; ++k) tok[k] = (int)a.forced[((long)step * a.B + b) * K + k];
-          cond = (tok[0] == st.term_token);
+#pragma unroll
+          for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) tok[k] = (int)dy.forced[((long)step * a.B + b) * K + k];
+          cond = (tok[0] == term);
         }
-        if (cond) { tok[0] = st.term_token; st.n_eog = 1; }
-        if (is_silence(a, tok[0]) && tok[0] == st.prev_token) st.consec_silence += 1;
-        else st.consec_silence = 0;
-        st.prev_token = tok[0];
+        if (cond) { tok[0] = term; n_eog = 1; }
+        consec = (is_silence(dy, tok[0]) && tok[0] == prev) ? consec + 1 : 0;
+        prev = tok[0];
       } else {
-        for (int k = 0; k < st.n_eog; ++k) tok[k] = a.empty_token;
-        tok[st.n_eog] = st.term_token;
-        if (forced)
-          for (int k = 0; k < K; ++k) tok[k] = (int)a.forced[((long)step * a.B + b) * K + k];
-        st.n_eog += 1;
+#pragma unroll
+        for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) {
+          if (k < n_eog) tok[k] = a.empty_token;
+          if (k == n_eog) tok[k] = term;
+        }
+        if (forced) {
+#pragma unroll
+          for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) tok[k] = (int)dy.forced[((long)step * a.B + b) * K + k];
+        }
+        n_eog += 1;
       }
-      st.cur_num_gen += 1;
-      if (step < a.max_steps)
-        for (int k = 0; k < K; ++k) a.gen[((long)b * a.max_steps + step) * K + k] = tok[k];
-      st.total_steps = step + 1;
-      for (int k = 0; k < K; ++k) s_tok[k] = tok[k];
-      s_ylen = st.y_len;
-      s_Lx = st.Lx;
+      cur += 1;
+      if (step < dy.max_steps) {
+#pragma unroll
+        for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) a.gen[((long)b * a.gen_stride + step) * K + k] = tok[k];
+      }
+      total = step + 1;
+#pragma unroll
+      for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) s_tok[k] = tok[k];
+      int done = 0, kept = 1;
       if (drop) {
-        st.done = 1; st.kept = 0;
-        atomicSub(a.n_active, 1);
-      } else if (st.n_eog == K) {            // span finished
-        st.span_steps[st.span] = st.cur_num_gen;
-        st.cur_num_gen = 0;
-        st.n_eog = 0;
-        st.span += 1;
-        if (st.span >= st.n_spans || st.total_steps >= a.max_steps ||
-            st.Lx + st.y_len + 3 > a.max_positions) {
-          st.done = 1;
-          atomicSub(a.n_active, 1);
+        done = 1; kept = 0;
+      } else if (n_eog == K) {            // span finished
+        sp->span_steps[span] = cur;
+        cur = 0;
+        n_eog = 0;
+        span += 1;
+        if (span >= n_spans || total >= dy.max_steps || Lx + y_len + 3 > a.max_positions) {
+          done = 1;
         } else {
-          s_mode = 3;
-          s_mask = st.mask_value[st.span];
-          st.y_len += 3;
-          st.prev_token = -1;
-          st.consec_silence = 0;
+          mode = 3;
+          mask = sp->mask_value[span];
+          y_len += 3;
+          prev = -1;
+          consec = 0;
         }
-      } else if (st.total_steps >= a.max_steps ||
-                 st.Lx + st.y_len + 1 > a.max_positions) {   // capacity guard (never hit when sized right)
-        st.done = 1;
-        atomicSub(a.n_active, 1);
+      } else if (total >= dy.max_steps || Lx + y_len + 1 > a.max_positions) {   // capacity guard (never hit when sized right)
+        done = 1;
       } else {
-        s_mode = 1;
-        st.y_len += 1;
+        mode = 1;
+        y_len += 1;
       }
+      if (done) {
+        sp->done = 1;
+        if (atomicSub(a.n_active, 1) == 1)     // the last live sequence: tell the host loop without a stream operation
+          __hip_atomic_store(a.host_active, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      if (!kept) sp->kept = 0;
+      sp->n_eog = n_eog; sp->cur_num_gen = cur; sp->prev_token = prev; sp->consec_silence = consec;
+      sp->span = span; sp->total_steps = total; sp->y_len = y_len;
     }
+    s_mode = mode; s_mask = mask; s_ylen = ylen_row; s_Lx = Lx;
     const int r0 = b * a.rps;
     for (int i = 0; i < a.rps; ++i) {
       a.row_seq[r0 + i] = b;
-      a.row_pos[r0 + i] = (i < s_mode) ? (s_Lx + s_ylen + i) : -1;
+      a.row_pos[r0 + i] = (i < mode) ? (Lx + ylen_row + i) : -1;
     }
-    a.logit_row[b] = r0 + (s_mode == 3 ? 2 : 0);
+    a.logit_row[b] = r0 + (mode == 3 ? 2 : 0);
   }
   __syncthreads();
   const int mode = s_mode;
@@ -505,18 +574,19 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   __shared__ SeqState s_st;
   __shared__ int s_xs[VC_MAX_CODEBOOKS + 2];
   const int b = blockIdx.x;
-  VC_TS(0);
   float v0[VC_VPL];
   preload_row(a, blockIdx.x, v0);
   const int sw = fetch_state(a, blockIdx.x);
   const int active = *a.n_active;
+  const SampleDyn dy = *a.dyn;
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
+  VC_TS(0);
   park_state(&s_st, sw);
-  sample_phase(a, blockIdx.x, &s_st, s_xs, s_dyn, v0);
+  sample_phase(a, dy, blockIdx.x, &s_st, s_xs, s_dyn, v0);
   __syncthreads();
   VC_TS(6);
-  advance_phase(a, blockIdx.x, false, &s_st, s_xs);
+  advance_phase(a, dy, blockIdx.x, false, &s_st, s_xs);
   VC_TS(8);
   store_state(a, blockIdx.x, &s_st);
   VC_TS(9);
@@ -527,19 +597,22 @@ __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
   preload_row(a, blockIdx.x, v0);
   const int sw = fetch_state(a, blockIdx.x);
   const int active = *a.n_active;
+  const SampleDyn dy = *a.dyn;
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
   park_state(&s_st, sw);
-  sample_phase(a, blockIdx.x, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2), s_dyn, v0);
+  sample_phase(a, dy, blockIdx.x, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2), s_dyn, v0);
 }
 __global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
   const int sw = fetch_state(a, blockIdx.x);
   const int active = *a.n_active;
+  const SampleDyn dy = *a.dyn;
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
+  const int b = blockIdx.x;
   park_state(&s_st, sw);
-  advance_phase(a, blockIdx.x, true, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2));
+  advance_phase(a, dy, blockIdx.x, true, &s_st, a.samp + blockIdx.x * (VC_MAX_CODEBOOKS + 2));
   store_state(a, blockIdx.x, &s_st);
 }
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
@@ -557,7 +630,8 @@ hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
 // =============================================================== sampler test hook
 // n_draws independent draws from ONE logits row through the product filter_draw (the distribution test
 // of tests/test_gpu_sampler.py): draw i uses the Philox counter (seed, sequence i, step 0, codebook 0).
-__global__ __launch_bounds__(256) void sample_test_k(const SampleArgs a, int n_draws, int* __restrict__ out) {
+__global__ __launch_bounds__(256) void sample_test_k(const float* __restrict__ logits, int V, int top_k, float top_p,
+                                                     float temperature, uint64_t seed, int n_draws, int* __restrict__ out) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = blockIdx.x * 4 + wave;
   if (i >= n_draws) return;
@@ -565,25 +639,22 @@ __global__ __launch_bounds__(256) void sample_test_k(const SampleArgs a, int n_d
 #pragma unroll
   for (int j = 0; j < VC_VPL; ++j) {
     const int c = lane + 64 * j;
-    const float t = a.logits[min(c, a.V - 1)];
-    v[j] = (c < a.V) ? t : -INFINITY;
+    const float t = logits[min(c, V - 1)];
+    v[j] = (c < V) ? t : -INFINITY;
   }
   float bv = -INFINITY;
 #pragma unroll
   for (int j = 0; j < VC_VPL; ++j) bv = fmaxf(bv, v[j]);
   bv = wave_max(bv);
-  const float u = philox_uniform(a.seed, (uint32_t)i, 0u, 0u);
-  const int tok = filter_draw(a, 0, v, bv, a.V, u);
+  const float u = philox_uniform(seed, (uint32_t)i, 0u, 0u);
+  const int tok = filter_draw(top_k, top_p, temperature, v, bv, V, u);
   if (lane == 0) out[i] = tok;
 }
 extern "C" int vc_debug_sample(const float* logits_dev, int V, const vc_sample_cfg* sc, int n_draws,
                                int32_t* out_dev, void* stream) {
   if (!logits_dev || !sc || !out_dev || V < 1 || V > 64 * VC_VPL || n_draws < 1) return VC_EINVAL;
-  SampleArgs a;
-  memset(&a, 0, sizeof a);
-  a.logits = logits_dev; a.B = 1; a.K = 1; a.V = V;
-  a.top_k = sc->top_k; a.top_p = sc->top_p; a.temperature = sc->temperature; a.seed = sc->seed;
-  hipLaunchKernelGGL(sample_test_k, dim3((n_draws + 3) / 4), dim3(256), 0, (hipStream_t)stream, a, n_draws, out_dev);
+  hipLaunchKernelGGL(sample_test_k, dim3((n_draws + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits_dev, V,
+                     sc->top_k, sc->top_p, sc->temperature, sc->seed, n_draws, out_dev);
   return hipGetLastError() == hipSuccess ? VC_OK : VC_EHIP;
 }
 
