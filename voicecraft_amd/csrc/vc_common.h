@@ -10,7 +10,8 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define VC_ROWS 16          // rows (token positions) of one MFMA tile = the N dimension of the rows-GEMM
-#define VC_MAX_ROWS 128     // rows one forward pass may carry (prefill: 8 row tiles per weight burst)
+#define VC_MAX_ROWS 512     // rows one forward pass may carry (prefill: four 128-row tiles of the block GEMM)
+#define VC_SLAB_ROWS (VC_MAX_ROWS + 5)   // row stride of the split-K slabs: not a power of two, so the slabs of a row do not share a cache channel
 #define VC_MAX_NSPLIT 8     // split-S factor cap of the decode attention (the out-projection prologue loads this many partials)
 #define VC_MAX_KSPLIT 4     // cross-block split-K cap of the rows-GEMM (the LN prologue prefetches this many slabs)
 #define VC_MAX_SEG 32       // prompt segments (2*spans+1 pieces + placeholders)
@@ -196,7 +197,7 @@ struct GemmArgs {
   int r_lds;                // rows of X staged in LDS (<= VC_ROWS)
   int rows_cap;             // row stride of the split-K slabs: parts[s][rows_cap][N]
   int nt;                   // 1: stream the weights with non-temporal loads
-  int mt;                   // 1: multi-tile pass (rows_gemm_mt_k): n_rows may reach VC_MAX_ROWS, no LN prologue
+  int mt;                   // 1: prefill pass (rows_gemm_blk_k): n_rows may reach VC_MAX_ROWS, plain prologue only
   long w_group_stride;      // in uint4 units
   int bias_group_stride;
   // rows

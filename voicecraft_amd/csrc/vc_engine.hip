@@ -61,7 +61,8 @@ struct vc_engine {
   Plan p_qkv{}, p_o{}, p_f1{}, p_f2{}, p_h1{}, p_h2{};
 
   // activations / scratch
-  float *emb = nullptr;                 // prefill rows [S_max][d]
+  float *emb = nullptr;                 // prefill rows [emb_cap][d] (one or several prompts back to back)
+  int emb_cap = 0;
   int *pre_row_seq = nullptr, *pre_row_pos = nullptr;
   float *hA = nullptr, *hB = nullptr, *q = nullptr, *parts = nullptr, *att_o = nullptr, *att_ml = nullptr;
   void *act = nullptr, *hh = nullptr, *xn = nullptr;
@@ -228,7 +229,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   memset(&g, 0, sizeof g);
   g.N = N; g.K = Kdim; g.n_tiles = p.n_tiles; g.KT = p.KT; g.nchunk = p.nchunk;
   g.r_lds = std::min(rs.n_rows, VC_ROWS);
-  g.rows_cap = VC_MAX_ROWS;
+  g.rows_cap = VC_SLAB_ROWS;
   g.row_seq = rs.row_seq; g.row_pos = rs.row_pos; g.n_rows = rs.n_rows;
   g.n_active = rs.n_active ? rs.n_active : e->one;
   g.nt = (rs.n_active != nullptr || rs.nt) ? e->nt_decode : 0;   // decode steps (and the kernel microbenchmarks) stream once
@@ -236,6 +237,13 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
   return g;
+}
+
+int attn_nsplit(vc_engine* e, int rows) {
+  // 8-wave blocks: one decode row is covered by ~256 of them; several rows get ~512 (two per CU), which
+  // halves the positions each block walks while the merge in the out-projection stays <= 4 partials
+  int ns = (rows > 1 ? 512 : 256) / std::max(1, rows * e->H);
+  return std::max(1, std::min(ns, VC_MAX_NSPLIT));
 }
 
 // One pass of up to 16 rows through every layer (decode step, 3-row span switch, short prompts).
@@ -401,32 +409,52 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   return VC_OK;
 }
 
-int attn_nsplit(vc_engine* e, int rows) {
-  // 8-wave blocks: one decode row is covered by ~256 of them; several rows get ~512 (two per CU), which
-  // halves the positions each block walks while the merge in the out-projection stays <= 4 partials
-  int ns = (rows > 1 ? 512 : 256) / std::max(1, rows * e->H);
-  return std::max(1, std::min(ns, VC_MAX_NSPLIT));
-}
-
-// Prefill of one sequence slot: prompt rows -> emb, then 16-row passes; heads on the last row.
-int prefill_seq(vc_engine* e, PromptArgs& pa, int slot, hipStream_t s) {
-  const int rows = pa.Lx + pa.n_cols;
-  pa.seq = slot; pa.row0 = 0;
-  pa.emb = e->emb; pa.row_seq = e->pre_row_seq; pa.row_pos = e->pre_row_pos; pa.err = e->err_flag;
-  pa.logit_row = e->logit_row + slot;
+// Prefill of one or several prompts as ONE row stream: the prompts' rows are laid back to back in `emb`
+// (each row carries its own (sequence, position)), pushed through the decoder in passes of up to
+// prefill_rows_per_pass rows - so the weights are streamed once per pass for all sequences together, not
+// once per sequence - and the heads run on the last row of each prompt as soon as its pass is through.
+// pas[i] describes prompt i (x, y, segments); slots[i] is its sequence slot.
+int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<int>& slots, hipStream_t s) {
   const int chunk = e->prefill_rows_per_pass;
-  pa.logit_row_val = (rows - 1) % chunk;
-  HIPCHK(e, vc_launch_prompt(pa, s));
-  for (int r0 = 0; r0 < rows; r0 += chunk) {
-    RowSrc rs{};
-    rs.h_in = e->emb + (size_t)r0 * e->d;
-    rs.row_seq = e->pre_row_seq + r0; rs.row_pos = e->pre_row_pos + r0;
-    rs.n_rows = std::min(chunk, rows - r0);
-    rs.nsplit = attn_nsplit(e, rs.n_rows);
-    int rc = (chunk > VC_ROWS) ? prefill_rows(e, rs, s) : forward_rows(e, rs, s);
-    if (rc) return rc;
+  size_t i0 = 0;
+  while (i0 < pas.size()) {
+    // ---- a group of prompts that fits the row arena
+    size_t i1 = i0;
+    int R = 0;
+    while (i1 < pas.size() && (i1 == i0 || R + pas[i1].Lx + pas[i1].n_cols <= e->emb_cap)) {
+      R += pas[i1].Lx + pas[i1].n_cols;
+      ++i1;
+    }
+    if (R > e->emb_cap) return fail(e, VC_ECAP, "a prompt of %d rows does not fit the prefill arena of %d rows", R, e->emb_cap);
+    std::vector<int> last(i1 - i0);
+    int row0 = 0;
+    for (size_t i = i0; i < i1; ++i) {
+      PromptArgs& pa = pas[i];
+      const int rows = pa.Lx + pa.n_cols;
+      pa.seq = slots[i]; pa.row0 = row0;
+      pa.emb = e->emb; pa.row_seq = e->pre_row_seq; pa.row_pos = e->pre_row_pos; pa.err = e->err_flag;
+      last[i - i0] = row0 + rows - 1;
+      pa.logit_row = e->logit_row + slots[i];
+      pa.logit_row_val = last[i - i0] % chunk;            // index of the prompt's last row inside its pass
+      HIPCHK(e, vc_launch_prompt(pa, s));
+      row0 += rows;
+    }
+    for (int r0 = 0; r0 < R; r0 += chunk) {
+      RowSrc rs{};
+      rs.h_in = e->emb + (size_t)r0 * e->d;
+      rs.row_seq = e->pre_row_seq + r0; rs.row_pos = e->pre_row_pos + r0;
+      rs.n_rows = std::min(chunk, R - r0);
+      int rc;
+      if (rs.n_rows > VC_ROWS) { rs.nsplit = 1; rc = prefill_rows(e, rs, s); }
+      else { rs.nsplit = attn_nsplit(e, rs.n_rows); rc = forward_rows(e, rs, s); }
+      if (rc) return rc;
+      for (size_t i = i0; i < i1; ++i)
+        if (last[i - i0] >= r0 && last[i - i0] < r0 + rs.n_rows)
+          if ((rc = run_heads(e, e->logit_row + slots[i], 1, slots[i], nullptr, s))) return rc;
+    }
+    i0 = i1;
   }
-  return run_heads(e, e->logit_row + slot, 1, slot, nullptr, s);
+  return VC_OK;
 }
 
 void fill_prompt_common(vc_engine* e, PromptArgs& pa, const int64_t* x, int Lx, const int64_t* y, int T) {
@@ -773,15 +801,16 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   e->p_h1 = make_plan(K * P, d, e->dtype, false, nullptr);
   e->p_h2 = make_plan(V, P, e->dtype, false, nullptr);
   // ---- scratch arenas
-  if ((rc = dalloc(e, &e->emb, (size_t)e->S_max * d))) return rc;
-  if ((rc = dalloc(e, &e->pre_row_seq, (size_t)e->S_max + VC_MAX_ROWS))) return rc;
-  if ((rc = dalloc(e, &e->pre_row_pos, (size_t)e->S_max + VC_MAX_ROWS))) return rc;
+  e->emb_cap = std::max(e->S_max, 8 * VC_MAX_ROWS);
+  if ((rc = dalloc(e, &e->emb, (size_t)e->emb_cap * d))) return rc;
+  if ((rc = dalloc(e, &e->pre_row_seq, (size_t)e->emb_cap + VC_MAX_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->pre_row_pos, (size_t)e->emb_cap + VC_MAX_ROWS))) return rc;
   if ((rc = dalloc(e, &e->hA, (size_t)VC_MAX_ROWS * d))) return rc;
   if ((rc = dalloc(e, &e->hB, (size_t)VC_MAX_ROWS * d))) return rc;
   if ((rc = dalloc(e, &e->q, (size_t)VC_MAX_ROWS * d))) return rc;
-  if ((rc = dalloc(e, &e->parts, (size_t)VC_MAX_KSPLIT * VC_MAX_ROWS * d))) return rc;
-  if ((rc = dalloc(e, &e->att_o, (size_t)VC_MAX_ROWS * e->H * VC_MAX_NSPLIT * e->hd))) return rc;
-  if ((rc = dalloc(e, &e->att_ml, (size_t)VC_MAX_ROWS * e->H * VC_MAX_NSPLIT * 2))) return rc;
+  if ((rc = dalloc(e, &e->parts, (size_t)VC_MAX_KSPLIT * VC_SLAB_ROWS * d))) return rc;
+  if ((rc = dalloc(e, &e->att_o, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * e->hd))) return rc;     // split partials: decode-size passes only
+  if ((rc = dalloc(e, &e->att_ml, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * 2))) return rc;
   char* tmp;
   if ((rc = dalloc(e, &tmp, (size_t)VC_MAX_ROWS * 4 * d * e->esz))) return rc;
   e->act = tmp;
@@ -821,7 +850,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     const char* nv = getenv("VC_NT");
     e->nt_decode = nv ? atoi(nv) : 1;
     const char* pr = getenv("VC_PREFILL_ROWS");
-    if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));
+    if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));   // 16: decode kernels only
     const char* ls = getenv("VC_LN_SPLIT_ROWS");
     if (ls) e->ln_split_rows = std::max(2, atoi(ls));
     const char* gs = getenv("VC_GRAPH_STEPS");
@@ -864,17 +893,20 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   }
   max_steps = std::min(max_steps, e->gen_cap);
   HIPCHK(e, hipEventRecord(e->ev[0], s));
-  // ---- prompt + prefill per job; best-of-N prefills once and replicates the cache
-  for (int b = 0; b < (int)jobs.size(); ++b) {
-    const TtsJob& j = jobs[b];
-    PromptArgs pa;
-    fill_prompt_common(e, pa, j.x, j.Lx, j.y, j.T);
-    pa.n_seg = 1; pa.n_cols = j.T + 1;
-    pa.seg[0] = Segment{0, j.T + 1, 0, j.T, -1, -1};
-    int rc = prefill_seq(e, pa, b, s);
+  // ---- prompts + ONE prefill over all of them; best-of-N prefills once and replicates the cache
+  {
+    std::vector<PromptArgs> pas(jobs.size());
+    std::vector<int> slots(jobs.size());
+    for (int b = 0; b < (int)jobs.size(); ++b) {
+      const TtsJob& j = jobs[b];
+      fill_prompt_common(e, pas[b], j.x, j.Lx, j.y, j.T);
+      pas[b].n_seg = 1; pas[b].n_cols = j.T + 1;
+      pas[b].seg[0] = Segment{0, j.T + 1, 0, j.T, -1, -1};
+      slots[b] = b;
+      e->h_st[b] = init_state(e, j.Lx, j.T + 1, true, 1);
+    }
+    int rc = prefill_batch(e, pas, slots, s);
     if (rc) return rc;
-    SeqState st = init_state(e, j.Lx, j.T + 1, true, 1);
-    e->h_st[b] = st;
   }
   if (grouped) {
     const TtsJob& j = jobs[0];
@@ -1045,8 +1077,11 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
     max_steps = std::min(std::min(max_steps, room), e->gen_cap);
   }
   HIPCHK(e, hipEventRecord(e->ev[0], s));
-  rc = prefill_seq(e, pa, 0, s);
-  if (rc) return rc;
+  {
+    std::vector<PromptArgs> pas(1, pa);
+    rc = prefill_batch(e, pas, std::vector<int>(1, 0), s);
+    if (rc) return rc;
+  }
   SeqState st = init_state(e, Lx, col, false, M);
   for (int i = 1; i < M; ++i) st.mask_value[i] = mask_values[M + i];   // more_mask_value (:676)
   e->h_st[0] = st;
@@ -1109,8 +1144,8 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "hA") { src = e->hA; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "hB") { src = e->hB; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "q") { src = e->q; avail = (int64_t)VC_ROWS * e->d * 4; }
-  else if (n == "parts") { src = e->parts; avail = (int64_t)VC_MAX_KSPLIT * VC_MAX_ROWS * e->d * 4; }
-  else if (n == "emb") { src = e->emb; avail = (int64_t)e->S_max * e->d * 4; }
+  else if (n == "parts") { src = e->parts; avail = (int64_t)VC_MAX_KSPLIT * VC_SLAB_ROWS * e->d * 4; }
+  else if (n == "emb") { src = e->emb; avail = (int64_t)e->emb_cap * e->d * 4; }
   else if (n == "dec_h") { src = e->dec_h; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "gen") { src = e->gen; avail = (int64_t)e->B_max * e->gen_cap * e->K * 4; }
   else if (n == "state") { src = e->st; avail = (int64_t)sizeof(SeqState) * VC_ROWS; }
@@ -1155,7 +1190,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   HIPCHK(e, hipMemsetAsync(e->dec_h, 0, (size_t)VC_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->hA, 0, (size_t)VC_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->hB, 0, (size_t)VC_ROWS * d * 4, s));
-  HIPCHK(e, hipMemsetAsync(e->parts, 0, (size_t)VC_MAX_KSPLIT * VC_MAX_ROWS * d * 4, s));
+  HIPCHK(e, hipMemsetAsync(e->parts, 0, (size_t)VC_MAX_KSPLIT * VC_SLAB_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->act, 0, (size_t)VC_ROWS * 4 * d * e->esz, s));
   HIPCHK(e, hipMemsetAsync(e->att_o, 0, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * e->hd * 4, s));
   HIPCHK(e, hipMemsetAsync(e->att_ml, 0, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * 2 * 4, s));

@@ -530,158 +530,127 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   VC_KTS_FLUSH();
 }
 
-// ------------------------------------------------------------------ prefill: up to VC_MAX_ROWS rows per pass
-// Same weight fragments, but a workgroup holds NTW weight tiles (NTW x 4 waves) in registers and walks
-// the pass's rows in tiles of 16, so W is streamed once per 128 rows instead of once per 16, and every
-// 16-row X tile staged in LDS feeds NTW output tiles (the X traffic out of L2 - 64 KB per row tile per
-// workgroup at d = 2048 - is what bounds this kernel, not HBM).  The next row tile is requested
-// while the current one is in the MFMAs.  LayerNorm is hoisted into ln_rows_k (one block per row).
-template <typename WT, int KTW, int PRO, int EPI, int NTW>
-__global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
+// ------------------------------------------------------------------ prefill: block GEMM, up to VC_MAX_ROWS rows per pass
+// out[M][N] = X[M][K] W'[N][K]^T on the MFMA for M >> 16 (prompt rows of one or several sequences).  The weights
+// keep the decode layout - they are already MFMA A fragments in HBM, so a wave loads them straight into
+// registers (16 bytes per lane per fragment, no LDS, no transposition); only X goes through LDS.
+//   workgroup  = 4 waves as 2 (rows) x 2 (channels); tile = 128 rows x 8 weight tiles (128 channels; 96 for QKV)
+//   wave       = 4 row tiles x 4 weight tiles: per k-tile 4 A fragments (global) + 4 B fragments (ds_read_b128)
+//                feed 16 MFMAs, i.e. every LDS byte and every weight byte is used 4 times from registers
+//   K pipeline = chunks of 4 k-tiles: while chunk c is in the MFMAs, chunk c+1's weight fragments (a second
+//                register set) and X rows (8 x 16 B per thread, parked in LDS behind the barrier) are in flight
+// LDS: 2 x 128 rows x (256 B + 16 B pad) = 68 KB; the pad rotates rows by 4 banks, so a B-fragment read
+// (16 rows x 64 B) is conflict-free.  Epilogues are the decode ones (bias/ReLU, split-K slab, QKV with the cache
+// scatter), LayerNorm comes from ln_rows_k + the folded weights.
+#define VC_BLK_M 128
+#define VC_BLK_NT 8          // weight tiles per workgroup
+#define VC_BLK_KT 4          // k-tiles per pipeline chunk
+template <typename WT, int EPI>
+__global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   using T = WTr<WT>;
-  constexpr int NT = 256 * NTW;          // threads
-  constexpr int XP = 16 / NTW;           // X units (16 B) a thread carries for the next row tile (64 KB per workgroup)
+  constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;
+  constexpr int SPT = 4 * TH;
+  constexpr int ROWB = VC_BLK_KT * T::KW * (int)sizeof(WT);     // bytes of one X row per chunk (256)
+  constexpr int XS = ROWB + 16;                                 // LDS row stride
+  constexpr int UPR = ROWB / 16;                                // 16-byte units per row per chunk (16)
+  constexpr int XPT = VC_BLK_M * UPR / 256;                     // units per thread per chunk (8)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int g = wv >> 2, wave = wv & 3;  // weight tile of this workgroup, K quarter
-  const int nt_raw = blockIdx.x * NTW + g;
-  const bool tile_ok = nt_raw < a.n_tiles;
-  const int nt = tile_ok ? nt_raw : a.n_tiles - 1;
-  const int ks = blockIdx.y, grp = blockIdx.z;
+  const int wm = wv >> 1, wn = wv & 1;                          // wave's row half / channel half
+  const int m = lane & 15, kg = lane >> 4;
+  const int row_blk = blockIdx.y * VC_BLK_M;
+  const int nt0 = blockIdx.x * VC_BLK_NT + wn * 4;              // first weight tile of this wave
+  const int ks = blockIdx.z;
   const int n_rows = a.n_rows;
-  const int kt_blk = a.nchunk * 4 * KTW;
+  const int kt_blk = a.KT / (int)gridDim.z;                     // k-tiles this workgroup covers
   const int kt0 = ks * kt_blk;
-  const int kblk = kt_blk * T::KW;
-  const int k0 = kt0 * T::KW;
-  const int xs = kblk * (int)sizeof(WT) + 16;
-  char* xl = smem;
-  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)VC_ROWS * xs) + g * 256;
-  constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;    // see rows_gemm_k
-  constexpr int SPT = 4 * TH;
-  const int m = lane & 15;
-  const int kg = lane >> 4;
-  const bool wvalid = m < TH, nvalid = 4 * kg < TH;
-  const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * SPT + (kg * TH + min(m, TH - 1));
-  uint4 wf[KTW];
-  {
-    const int kt = kt0 + wave * KTW;
-#pragma unroll
-    for (int i = 0; i < KTW; ++i) {
-      wf[i] = wp[(long)(kt + i) * SPT];
-      if (TH < 16 && !wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
-    }
-  }
-  const int n = nt * TH + 4 * kg;
-  const int upr = kblk * (int)sizeof(WT) / 16;       // 16-byte units per X row slice
-  const char* xsrc = reinterpret_cast<const char*>(a.x_in) + ((long)grp * a.x_group_stride + k0) * (long)sizeof(WT);
+  const int nck = kt_blk / VC_BLK_KT;
+  const bool wvalid = m < TH;
+  // weight fragments of the wave's 4 tiles: tile j is j * KT * SPT units further (n_tiles is a multiple of
+  // VC_BLK_NT for every matrix of the path: d % 256 == 0)
+  const uint4* wp0 = a.Wp + ((long)nt0 * a.KT + kt0) * SPT + (kg * TH + min(m, TH - 1));
+  const long wtile = (long)a.KT * SPT;
+  // X source: thread t copies the 16-byte units t, t+256, ... of a chunk's 128 x UPR unit grid, i.e. row
+  // tid/UPR + 16 j, unit tid%UPR.  Rows past n_rows are read from the (VC_MAX_ROWS-row) buffer and dropped
+  // by the epilogue - rows never mix in a GEMM.
   const long rstride = (long)a.x_ld * (long)sizeof(WT);
-  const int sh = a.x_upr_shift;
-  uint4 xq0, xq1, xq2, xq3, xq4, xq5, xq6, xq7;   // explicit scalars: an indexed array is demoted to scratch
+  const char* xg0 = reinterpret_cast<const char*>(a.x_in) + (long)kt0 * T::KW * (long)sizeof(WT) +
+                    (long)(row_blk + tid / UPR) * rstride + (tid % UPR) * 16;
+  const int xl0 = (tid / UPR) * XS + (tid % UPR) * 16;
+  uint4 wA[VC_BLK_KT][4], wB[VC_BLK_KT][4];
+  uint4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7;     // explicit scalars: an indexed array that lives across the loop is demoted to scratch
+  static_assert(XPT == 8, "the X staging below is written for 8 units per thread");
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // X tile of rows [row0, row0 + nr): global -> registers (first XP * NT units) ...
-#define VC_XQ_LOAD(j, dst)                                                                       \
-  if constexpr ((j) < XP) {                                                                      \
-    const int i_ = min((j) * NT + tid, total - 1);                                               \
-    const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                          \
-    const int u_ = i_ - r_ * upr;                                                                \
-    dst = *reinterpret_cast<const uint4*>(xsrc + (long)(row0 + r_) * rstride + (long)u_ * 16);   \
-  }
-#define VC_XQ_STORE(j, val)                                                                      \
-  if constexpr ((j) < XP) {                                                                      \
-    const int i_ = (j) * NT + tid;                                                               \
-    if (i_ < total) {                                                                            \
-      const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                        \
-      const int u_ = i_ - r_ * upr;                                                              \
-      *reinterpret_cast<uint4*>(xl + (size_t)r_ * xs + (size_t)u_ * 16) = val;                   \
+#define VC_BLK_LOADW(W, c_)                                                                      \
+  _Pragma("unroll") for (int kt_ = 0; kt_ < VC_BLK_KT; ++kt_)                                     \
+    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                            \
+      W[kt_][j_] = wp0[j_ * wtile + (long)((c_) * VC_BLK_KT + kt_) * SPT];                        \
+    }
+#define VC_BLK_LX1(j_, c_) xr##j_ = *reinterpret_cast<const uint4*>(xg0 + (long)j_ * (256 / UPR) * rstride + (long)(c_) * ROWB);
+#define VC_BLK_LOADX(c_) VC_BLK_LX1(0, c_) VC_BLK_LX1(1, c_) VC_BLK_LX1(2, c_) VC_BLK_LX1(3, c_) VC_BLK_LX1(4, c_) VC_BLK_LX1(5, c_) VC_BLK_LX1(6, c_) VC_BLK_LX1(7, c_)
+#define VC_BLK_PX1(j_, buf_) *reinterpret_cast<uint4*>(smem + (buf_) * (VC_BLK_M * XS) + xl0 + j_ * (256 / UPR) * XS) = xr##j_;
+#define VC_BLK_PARKX(buf_) VC_BLK_PX1(0, buf_) VC_BLK_PX1(1, buf_) VC_BLK_PX1(2, buf_) VC_BLK_PX1(3, buf_) VC_BLK_PX1(4, buf_) VC_BLK_PX1(5, buf_) VC_BLK_PX1(6, buf_) VC_BLK_PX1(7, buf_)
+#define VC_BLK_COMPUTE(W, buf_)                                                                  \
+  {                                                                                              \
+    const char* xb_ = smem + (buf_) * (VC_BLK_M * XS) + (wm * 64 + m) * XS + kg * 16;             \
+    _Pragma("unroll") for (int kt_ = 0; kt_ < VC_BLK_KT; ++kt_) {                                 \
+      uint4 xf_[4];                                                                              \
+      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                            \
+        xf_[i_] = *reinterpret_cast<const uint4*>(xb_ + i_ * 16 * XS + kt_ * 64);                 \
+      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                          \
+        uint4 w_ = W[kt_][j_];                                                                   \
+        if (TH < 16 && !wvalid) w_ = make_uint4(0u, 0u, 0u, 0u);                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                          \
+          acc[i_][j_] = mfma_frag(w_, xf_[i_], acc[i_][j_], (WT*)nullptr);                        \
+      }                                                                                          \
     }                                                                                            \
   }
-  auto x_fetch = [&](int row0, int nr) {
-    if constexpr (PRO == PRO_PLAIN) {
-      const int total = nr * upr;
-      VC_XQ_LOAD(0, xq0) VC_XQ_LOAD(1, xq1) VC_XQ_LOAD(2, xq2) VC_XQ_LOAD(3, xq3)
-      VC_XQ_LOAD(4, xq4) VC_XQ_LOAD(5, xq5) VC_XQ_LOAD(6, xq6) VC_XQ_LOAD(7, xq7)
-    }
-  };
-  // ... -> LDS (plus whatever did not fit into the XP slots, copied directly)
-  auto x_park = [&](int row0, int nr) {
-    if constexpr (PRO == PRO_PLAIN) {
-      const int total = nr * upr;
-      VC_XQ_STORE(0, xq0) VC_XQ_STORE(1, xq1) VC_XQ_STORE(2, xq2) VC_XQ_STORE(3, xq3)
-      VC_XQ_STORE(4, xq4) VC_XQ_STORE(5, xq5) VC_XQ_STORE(6, xq6) VC_XQ_STORE(7, xq7)
-      for (int i = XP * NT + tid; i < total; i += NT) {
-        const int r = (sh >= 0) ? (i >> sh) : (i / upr);
-        const int u = i - r * upr;
-        *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) =
-            *reinterpret_cast<const uint4*>(xsrc + (long)(row0 + r) * rstride + (long)u * 16);
-      }
-    } else {   // PRO_ATT (short passes whose attention was split): merge the partials in place
-      const int q4 = kblk >> 2;
-      for (int idx = tid; idx < nr * q4; idx += NT) {
-        const int r = idx / q4, c = k0 + (idx - r * q4) * 4;
-        const int h = c / a.hd, e = c - h * a.hd;
-        const float2* ml = reinterpret_cast<const float2*>(a.att_ml) + (long)((row0 + r) * a.H + h) * a.nsplit;
-        const float* op = a.att_o + ((long)((row0 + r) * a.H + h) * a.nsplit) * a.hd + e;
-        float M = -INFINITY;
-        for (int sp = 0; sp < a.nsplit; ++sp) M = fmaxf(M, ml[sp].x);
-        float L = 0.f;
-        f32x4 o = {0.f, 0.f, 0.f, 0.f};
-        for (int sp = 0; sp < a.nsplit; ++sp) {
-          const float2 v = ml[sp];
-          const float w = (v.x == -INFINITY) ? 0.f : expf(v.x - M);
-          const float4 os = *reinterpret_cast<const float4*>(op + (long)sp * a.hd);
-          L += w * v.y;
-          o[0] += w * os.x; o[1] += w * os.y; o[2] += w * os.z; o[3] += w * os.w;
-        }
-        const float inv = (L > 0.f) ? 1.0f / L : 0.f;
-        o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
-        store4(reinterpret_cast<WT*>(xl + (size_t)r * xs) + (c - k0), o);
-      }
-    }
-  };
-
-  x_fetch(0, min(VC_ROWS, n_rows));
-  x_park(0, min(VC_ROWS, n_rows));
-  for (int row0 = 0; row0 < n_rows; row0 += VC_ROWS) {
-    const int nr = min(VC_ROWS, n_rows - row0);
-    const int row1 = row0 + VC_ROWS;
-    const int nr1 = min(VC_ROWS, n_rows - row1);
-    __syncthreads();                       // X(row0) is in LDS
-    if (nr1 > 0) x_fetch(row1, nr1);       // next tile on its way while this one is in the MFMAs
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int mrow = (m < nr) ? m : 0;
-    const char* xrow = xl + (size_t)mrow * xs + (size_t)(lane >> 4) * 16;
-    for (int c = 0; c < a.nchunk; ++c) {
-      if (a.nchunk > 1) {       // several chunks: the registers only ever hold one of them
-        const int kt = kt0 + (c * 4 + wave) * KTW;
-#pragma unroll
-        for (int i = 0; i < KTW; ++i) {
-          wf[i] = wp[(long)(kt + i) * SPT];
-          if (TH < 16 && !wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
-        }
-      }
-      const int ktl = (c * 4 + wave) * KTW;
-#pragma unroll
-      for (int i = 0; i < KTW; ++i) {
-        const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)(ktl + i) * 64);
-        acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);
-      }
-    }
-    red[wave * 64 + lane] = acc;
+  VC_BLK_LOADX(0)
+  VC_BLK_LOADW(wA, 0)
+  VC_BLK_PARKX(0)
+  __syncthreads();
+  for (int c = 0; c < nck; c += 2) {
+    // ---- even chunk: weights in wA, X in buffer 0
+    if (c + 1 < nck) { VC_BLK_LOADX(c + 1) VC_BLK_LOADW(wB, c + 1) }
+    VC_BLK_COMPUTE(wA, 0)
+    if (c + 1 < nck) { VC_BLK_PARKX(1) }
     __syncthreads();
-    if (wave == 0 && m < nr && nvalid && tile_ok) {
-      const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
-      acc = (acc + a1) + (a2 + a3);
+    if (c + 1 >= nck) break;
+    // ---- odd chunk: weights in wB, X in buffer 1
+    if (c + 2 < nck) { VC_BLK_LOADX(c + 2) VC_BLK_LOADW(wA, c + 2) }
+    VC_BLK_COMPUTE(wB, 1)
+    if (c + 2 < nck) { VC_BLK_PARKX(0) }
+    __syncthreads();
+  }
+#undef VC_BLK_LOADW
+#undef VC_BLK_LOADX
+#undef VC_BLK_PARKX
+#undef VC_BLK_LX1
+#undef VC_BLK_PX1
+#undef VC_BLK_COMPUTE
+  // ---- epilogue: lane holds channels n..n+3 of row (row tile i, m) for weight tile j
+  const bool nvalid = 4 * kg < TH;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int mg = row_blk + wm * 64 + i * 16 + m;
+    if (mg >= n_rows) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int nt = nt0 + j;
+      if (nt >= a.n_tiles || !nvalid) continue;
+      const int n = nt * TH + 4 * kg;
       float4 eb;
       int epos, eseq;
-      epi_preload<WT, EPI>(a, row0 + m, n, grp, eb, epos, eseq);
-      gemm_epilogue<WT, EPI>(a, acc, row0 + m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
+      epi_preload<WT, EPI>(a, mg, n, 0, eb, epos, eseq);
+      gemm_epilogue<WT, EPI>(a, acc[i][j], mg, n, ks, 0, 1, eb, epos, eseq);
     }
-    __syncthreads();            // x and red are rewritten for the next tile
-    if (nr1 > 0) x_park(row1, nr1);
   }
-#undef VC_XQ_LOAD
-#undef VC_XQ_STORE
 }
 
 // h_new = h + prev_bias + sum of split-K slabs ; x_hat = (h_new - mean) * rstd as WT (the affine part of the
@@ -761,12 +730,14 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   auto kern = rows_gemm_k<WT, KTW, PRO, EPI>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit);
   if (lds > 64 * 1024) {
-    static size_t granted = 0;   // per instantiation
-    if (lds > granted) {
+    static size_t granted[16] = {0};   // per instantiation and device
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && lds > granted[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
-      granted = lds;
+      granted[dev] = lds;
     }
   }
   GemmArgs b = a;
@@ -785,45 +756,34 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   return hipGetLastError();
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int NTW>
-static hipError_t launch_mt_n(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_mt_k<WT, KTW, PRO, EPI, NTW>;
-  GemmArgs b = a;
-  b.r_lds = VC_ROWS;
-  {
-    const int esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
-    const int upr = (a.K / ksplit) * esz / 16;
-    b.x_upr_shift = -1;
-    for (int sft = 0; sft < 20; ++sft)
-      if ((1 << sft) == upr) b.x_upr_shift = sft;
+template <typename WT, int EPI>
+static hipError_t launch_blk_e(const GemmArgs& a, int ksplit, hipStream_t s) {
+  auto kern = rows_gemm_blk_k<WT, EPI>;
+  constexpr size_t lds = 2 * (size_t)VC_BLK_M * (VC_BLK_KT * WTr<WT>::KW * sizeof(WT) + 16);
+  static size_t granted[16] = {0};                  // per instantiation and device
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (dev >= 0 && dev < 16 && granted[dev] < lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    granted[dev] = lds;
   }
-  const size_t lds = vc_gemm_lds_bytes(b, dtype, ksplit) + (size_t)(NTW - 1) * 4 * 64 * sizeof(f32x4);
-  if (lds > 64 * 1024) {
-    static size_t granted = 0;
-    if (lds > granted) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e != hipSuccess) return e;
-      granted = lds;
-    }
-  }
-  hipLaunchKernelGGL(kern, dim3((a.n_tiles + NTW - 1) / NTW, ksplit, groups), dim3(256 * NTW), lds, s, b);
+  if ((a.KT / ksplit) % VC_BLK_KT != 0) return hipErrorInvalidValue;
+  dim3 grid((a.n_tiles + VC_BLK_NT - 1) / VC_BLK_NT, (a.n_rows + VC_BLK_M - 1) / VC_BLK_M, ksplit);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
-
-template <typename WT, int KTW, int PRO, int EPI>
-static hipError_t launch_mt(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  if constexpr (PRO == PRO_LN) {
-    return hipErrorInvalidValue;       // multi-tile passes take their LayerNorm from ln_rows_k
-  } else {
-    // 4 weight tiles per workgroup when that still leaves >= 128 workgroups, else 2
-    if ((long)a.n_tiles * ksplit * groups >= 512) return launch_mt_n<WT, KTW, PRO, EPI, 4>(a, dtype, ksplit, groups, s);
-    return launch_mt_n<WT, KTW, PRO, EPI, 2>(a, dtype, ksplit, groups, s);
-  }
+template <typename WT>
+static hipError_t launch_blk(const GemmArgs& a, int pro, int epi, int ksplit, hipStream_t s) {
+  if (pro != PRO_PLAIN) return hipErrorInvalidValue;       // LayerNorm comes from ln_rows_k, attention normalises itself
+  if (epi == EPI_QKV) return launch_blk_e<WT, EPI_QKV>(a, ksplit, s);
+  if (epi == EPI_PART) return launch_blk_e<WT, EPI_PART>(a, ksplit, s);
+  if (epi == EPI_RELU) return launch_blk_e<WT, EPI_RELU>(a, ksplit, s);
+  return hipErrorInvalidValue;
 }
 
 template <typename WT, int KTW, int PRO, int EPI>
 static hipError_t launch_one(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  if (a.mt) return launch_mt<WT, KTW, PRO, EPI>(a, dtype, ksplit, groups, s);
   return launch_dec<WT, KTW, PRO, EPI>(a, dtype, ksplit, groups, s);
 }
 
@@ -858,6 +818,11 @@ static hipError_t launch_wt(const GemmArgs& a, int dtype, int pro, int epi, int 
 
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s) {
+  if (a.mt) {     // prefill pass: block GEMM
+    if (groups != 1) return hipErrorInvalidValue;
+    if (dtype == VC_DTYPE_BF16) return launch_blk<bf16_t>(a, pro, epi, ksplit, s);
+    return launch_blk<float>(a, pro, epi, ksplit, s);
+  }
   if (dtype == VC_DTYPE_BF16) return launch_wt<bf16_t>(a, dtype, pro, epi, ksplit, groups, s);
   return launch_wt<float>(a, dtype, pro, epi, ksplit, groups, s);
 }
