@@ -534,18 +534,24 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 // out[M][N] = X[M][K] W'[N][K]^T on the MFMA for M >> 16 (prompt rows of one or several sequences).  The weights
 // keep the decode layout - they are already MFMA A fragments in HBM, so a wave loads them straight into
 // registers (16 bytes per lane per fragment, no LDS, no transposition); only X goes through LDS.
-//   workgroup  = 4 waves as 2 (rows) x 2 (channels); tile = 128 rows x 8 weight tiles (128 channels; 96 for QKV)
-//   wave       = 4 row tiles x 4 weight tiles: per k-tile 4 A fragments (global) + 4 B fragments (ds_read_b128)
-//                feed 16 MFMAs, i.e. every LDS byte and every weight byte is used 4 times from registers
-//   K pipeline = chunks of 4 k-tiles: while chunk c is in the MFMAs, chunk c+1's weight fragments (a second
-//                register set) and X rows (8 x 16 B per thread, parked in LDS behind the barrier) are in flight
-// LDS: 2 x 128 rows x (256 B + 16 B pad) = 68 KB; the pad rotates rows by 4 banks, so a B-fragment read
-// (16 rows x 64 B) is conflict-free.  Epilogues are the decode ones (bias/ReLU, split-K slab, QKV with the cache
-// scatter), LayerNorm comes from ln_rows_k + the folded weights.
+//   workgroup  = 4 waves as 2 (rows) x 2 (channels); tile = 128 rows x 4 weight tiles (64 channels; 48 for QKV):
+//                a 231-row prompt still gives 256 workgroups on the two wide matrices; 68 KB of LDS and <= 256
+//                registers, so two workgroups share a CU (one in the MFMAs while the other waits for memory)
+//   wave       = 4 row tiles x 2 weight tiles: per k-tile 2 A fragments (global) + 4 B fragments (ds_read_b128)
+//                feed 8 MFMAs
+//   K pipeline = chunks of 4 k-tiles.  Weight fragments run through a ring of THREE register sets, i.e. they are
+//                requested two chunks (16 KB per wave) ahead of their MFMAs - at a few hundred rows the pass is as
+//                much a weight stream (HBM) as a GEMM.  X rows of the next chunk (8 x 16 B per thread) are requested
+//                BEFORE that chunk's weights (a wave's loads return in order: waiting for X must not drain the
+//                weight ring) and parked in the other LDS buffer behind the barrier.
+// LDS: 2 x 128 rows x (256 B + 16 B pad) = 68 KB; the pad rotates rows by 4 banks.  Epilogues are the decode ones
+// (bias/ReLU, split-K slab, QKV with the cache scatter), LayerNorm comes from ln_rows_k + the folded weights.
+// NTW = weight tiles per wave: 2 (64-channel workgroup tile, enough workgroups for one short prompt) or 4 (128
+// channels: each X byte staged in LDS feeds twice as many MFMAs - the L2->LDS traffic of X is what bounds the
+// 64-channel form once the grid is large enough).
 #define VC_BLK_M 128
-#define VC_BLK_NT 8          // weight tiles per workgroup
 #define VC_BLK_KT 4          // k-tiles per pipeline chunk
-template <typename WT, int EPI>
+template <typename WT, int EPI, int NTW>
 __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   using T = WTr<WT>;
   constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;
@@ -554,48 +560,61 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   constexpr int XS = ROWB + 16;                                 // LDS row stride
   constexpr int UPR = ROWB / 16;                                // 16-byte units per row per chunk (16)
   constexpr int XPT = VC_BLK_M * UPR / 256;                     // units per thread per chunk (8)
+  constexpr int RPJ = 256 / UPR;                                // rows between a thread's consecutive units (16)
+  static_assert(XPT == 8, "the X staging below is written for 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 1, wn = wv & 1;                          // wave's row half / channel half
   const int m = lane & 15, kg = lane >> 4;
   const int row_blk = blockIdx.y * VC_BLK_M;
-  const int nt0 = blockIdx.x * VC_BLK_NT + wn * 4;              // first weight tile of this wave
+  const int nt0 = (blockIdx.x * 2 + wn) * NTW;                  // first weight tile of this wave
   const int ks = blockIdx.z;
   const int n_rows = a.n_rows;
   const int kt_blk = a.KT / (int)gridDim.z;                     // k-tiles this workgroup covers
   const int kt0 = ks * kt_blk;
   const int nck = kt_blk / VC_BLK_KT;
   const bool wvalid = m < TH;
-  // weight fragments of the wave's 4 tiles: tile j is j * KT * SPT units further (n_tiles is a multiple of
+  // weight fragments of the wave's 2 tiles: tile j is j * KT * SPT units further (n_tiles is a multiple of
   // VC_BLK_NT for every matrix of the path: d % 256 == 0)
   const uint4* wp0 = a.Wp + ((long)nt0 * a.KT + kt0) * SPT + (kg * TH + min(m, TH - 1));
   const long wtile = (long)a.KT * SPT;
   // X source: thread t copies the 16-byte units t, t+256, ... of a chunk's 128 x UPR unit grid, i.e. row
-  // tid/UPR + 16 j, unit tid%UPR.  Rows past n_rows are read from the (VC_MAX_ROWS-row) buffer and dropped
+  // tid/UPR + RPJ j, unit tid%UPR.  Rows past n_rows are read from the (VC_MAX_ROWS-row) buffer and dropped
   // by the epilogue - rows never mix in a GEMM.
   const long rstride = (long)a.x_ld * (long)sizeof(WT);
   const char* xg0 = reinterpret_cast<const char*>(a.x_in) + (long)kt0 * T::KW * (long)sizeof(WT) +
                     (long)(row_blk + tid / UPR) * rstride + (tid % UPR) * 16;
   const int xl0 = (tid / UPR) * XS + (tid % UPR) * 16;
-  uint4 wA[VC_BLK_KT][4], wB[VC_BLK_KT][4];
-  uint4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7;     // explicit scalars: an indexed array that lives across the loop is demoted to scratch
-  static_assert(XPT == 8, "the X staging below is written for 8 units per thread");
-  f32x4 acc[4][4];
+  uint4 w0[VC_BLK_KT][NTW], w1[VC_BLK_KT][NTW], w2[NTW == 2 ? VC_BLK_KT : 1][NTW];     // the weight ring
+  uint4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7;   // explicit scalars: an indexed array living across the loop is demoted to scratch
+  f32x4 acc[4][NTW];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // (chunk indices past the end are clamped: a redundant load is cheaper than a branch around the burst)
 #define VC_BLK_LOADW(W, c_)                                                                      \
-  _Pragma("unroll") for (int kt_ = 0; kt_ < VC_BLK_KT; ++kt_)                                     \
-    _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                            \
-      W[kt_][j_] = wp0[j_ * wtile + (long)((c_) * VC_BLK_KT + kt_) * SPT];                        \
-    }
-#define VC_BLK_LX1(j_, c_) xr##j_ = *reinterpret_cast<const uint4*>(xg0 + (long)j_ * (256 / UPR) * rstride + (long)(c_) * ROWB);
-#define VC_BLK_LOADX(c_) VC_BLK_LX1(0, c_) VC_BLK_LX1(1, c_) VC_BLK_LX1(2, c_) VC_BLK_LX1(3, c_) VC_BLK_LX1(4, c_) VC_BLK_LX1(5, c_) VC_BLK_LX1(6, c_) VC_BLK_LX1(7, c_)
-#define VC_BLK_PX1(j_, buf_) *reinterpret_cast<uint4*>(smem + (buf_) * (VC_BLK_M * XS) + xl0 + j_ * (256 / UPR) * XS) = xr##j_;
-#define VC_BLK_PARKX(buf_) VC_BLK_PX1(0, buf_) VC_BLK_PX1(1, buf_) VC_BLK_PX1(2, buf_) VC_BLK_PX1(3, buf_) VC_BLK_PX1(4, buf_) VC_BLK_PX1(5, buf_) VC_BLK_PX1(6, buf_) VC_BLK_PX1(7, buf_)
+  {                                                                                              \
+    const long cw_ = (long)min((c_), nck - 1) * VC_BLK_KT * SPT;                                  \
+    _Pragma("unroll") for (int kt_ = 0; kt_ < VC_BLK_KT; ++kt_)                                   \
+      _Pragma("unroll") for (int j_ = 0; j_ < NTW; ++j_) {                                        \
+        W[kt_][j_] = wp0[j_ * wtile + cw_ + kt_ * SPT];                                          \
+      }                                                                                          \
+  }
+#define VC_BLK_LX1(j_) xr##j_ = *reinterpret_cast<const uint4*>(xc_ + (long)j_ * RPJ * rstride);
+#define VC_BLK_LOADX(c_)                                                                         \
+  {                                                                                              \
+    const char* xc_ = xg0 + (long)min((c_), nck - 1) * ROWB;                                      \
+    VC_BLK_LX1(0) VC_BLK_LX1(1) VC_BLK_LX1(2) VC_BLK_LX1(3) VC_BLK_LX1(4) VC_BLK_LX1(5) VC_BLK_LX1(6) VC_BLK_LX1(7) \
+  }
+#define VC_BLK_PX1(j_, buf_) *reinterpret_cast<uint4*>(smem + (buf_) * (VC_BLK_M * XS) + xl0 + j_ * RPJ * XS) = xr##j_;
+#define VC_BLK_PARKX(c_, buf_)                                                                   \
+  {                                                                                              \
+    VC_BLK_PX1(0, buf_) VC_BLK_PX1(1, buf_) VC_BLK_PX1(2, buf_) VC_BLK_PX1(3, buf_)               \
+    VC_BLK_PX1(4, buf_) VC_BLK_PX1(5, buf_) VC_BLK_PX1(6, buf_) VC_BLK_PX1(7, buf_)               \
+  }
 #define VC_BLK_COMPUTE(W, buf_)                                                                  \
   {                                                                                              \
     const char* xb_ = smem + (buf_) * (VC_BLK_M * XS) + (wm * 64 + m) * XS + kg * 16;             \
@@ -603,31 +622,56 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
       uint4 xf_[4];                                                                              \
       _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                            \
         xf_[i_] = *reinterpret_cast<const uint4*>(xb_ + i_ * 16 * XS + kt_ * 64);                 \
-      _Pragma("unroll") for (int j_ = 0; j_ < 4; ++j_) {                                          \
+      _Pragma("unroll") for (int j_ = 0; j_ < NTW; ++j_) {                                        \
         uint4 w_ = W[kt_][j_];                                                                   \
         if (TH < 16 && !wvalid) w_ = make_uint4(0u, 0u, 0u, 0u);                                 \
         _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                          \
           acc[i_][j_] = mfma_frag(w_, xf_[i_], acc[i_][j_], (WT*)nullptr);                        \
       }                                                                                          \
+      __builtin_amdgcn_sched_barrier(0);   /* keep the B fragments of later k-tiles out of the register file */ \
     }                                                                                            \
   }
-  VC_BLK_LOADX(0)
-  VC_BLK_LOADW(wA, 0)
-  VC_BLK_PARKX(0)
-  __syncthreads();
-  for (int c = 0; c < nck; c += 2) {
-    // ---- even chunk: weights in wA, X in buffer 0
-    if (c + 1 < nck) { VC_BLK_LOADX(c + 1) VC_BLK_LOADW(wB, c + 1) }
-    VC_BLK_COMPUTE(wA, 0)
-    if (c + 1 < nck) { VC_BLK_PARKX(1) }
-    __syncthreads();
-    if (c + 1 >= nck) break;
-    // ---- odd chunk: weights in wB, X in buffer 1
-    if (c + 2 < nck) { VC_BLK_LOADX(c + 2) VC_BLK_LOADW(wA, c + 2) }
-    VC_BLK_COMPUTE(wB, 1)
-    if (c + 2 < nck) { VC_BLK_PARKX(0) }
-    __syncthreads();
+  // one pipeline step: chunk c is computed from ring slot WC / LDS buffer BUF, chunk c+1's X and chunk c+2's
+  // weights (into slot WN, free since chunk c-1) are requested first - X before W, see above
+#define VC_BLK_STEP(c_, WC, WN, BUF, AHEAD)                                                      \
+  {                                                                                              \
+    VC_BLK_LOADX((c_) + 1)                                                                       \
+    VC_BLK_LOADW(WN, (c_) + (AHEAD))                                                             \
+    VC_BLK_COMPUTE(WC, BUF)                                                                      \
+    VC_BLK_PARKX((c_) + 1, 1 - (BUF))                                                            \
+    __syncthreads();                                                                             \
   }
+  if constexpr (NTW == 2) {     // ring of three sets: weights two chunks ahead
+    VC_BLK_LOADX(0)
+    VC_BLK_LOADW(w0, 0)
+    VC_BLK_LOADW(w1, 1)
+    VC_BLK_PARKX(0, 0)
+    __syncthreads();
+    for (int c = 0; c < nck; c += 6) {      // 6 = lcm(ring of 3, 2 LDS buffers)
+      VC_BLK_STEP(c, w0, w2, 0, 2)
+      if (c + 1 >= nck) break;
+      VC_BLK_STEP(c + 1, w1, w0, 1, 2)
+      if (c + 2 >= nck) break;
+      VC_BLK_STEP(c + 2, w2, w1, 0, 2)
+      if (c + 3 >= nck) break;
+      VC_BLK_STEP(c + 3, w0, w2, 1, 2)
+      if (c + 4 >= nck) break;
+      VC_BLK_STEP(c + 4, w1, w0, 0, 2)
+      if (c + 5 >= nck) break;
+      VC_BLK_STEP(c + 5, w2, w1, 1, 2)
+    }
+  } else {                      // 128-channel tile: two sets (the register file holds no third), one chunk ahead
+    VC_BLK_LOADX(0)
+    VC_BLK_LOADW(w0, 0)
+    VC_BLK_PARKX(0, 0)
+    __syncthreads();
+    for (int c = 0; c < nck; c += 2) {
+      VC_BLK_STEP(c, w0, w1, 0, 1)
+      if (c + 1 >= nck) break;
+      VC_BLK_STEP(c + 1, w1, w0, 1, 1)
+    }
+  }
+#undef VC_BLK_STEP
 #undef VC_BLK_LOADW
 #undef VC_BLK_LOADX
 #undef VC_BLK_PARKX
@@ -641,7 +685,7 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
     const int mg = row_blk + wm * 64 + i * 16 + m;
     if (mg >= n_rows) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NTW; ++j) {
       const int nt = nt0 + j;
       if (nt >= a.n_tiles || !nvalid) continue;
       const int n = nt * TH + 4 * kg;
@@ -756,9 +800,9 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   return hipGetLastError();
 }
 
-template <typename WT, int EPI>
-static hipError_t launch_blk_e(const GemmArgs& a, int ksplit, hipStream_t s) {
-  auto kern = rows_gemm_blk_k<WT, EPI>;
+template <typename WT, int EPI, int NTW>
+static hipError_t launch_blk_n(const GemmArgs& a, int ksplit, hipStream_t s) {
+  auto kern = rows_gemm_blk_k<WT, EPI, NTW>;
   constexpr size_t lds = 2 * (size_t)VC_BLK_M * (VC_BLK_KT * WTr<WT>::KW * sizeof(WT) + 16);
   static size_t granted[16] = {0};                  // per instantiation and device
   int dev = 0;
@@ -769,9 +813,17 @@ static hipError_t launch_blk_e(const GemmArgs& a, int ksplit, hipStream_t s) {
     granted[dev] = lds;
   }
   if ((a.KT / ksplit) % VC_BLK_KT != 0) return hipErrorInvalidValue;
-  dim3 grid((a.n_tiles + VC_BLK_NT - 1) / VC_BLK_NT, (a.n_rows + VC_BLK_M - 1) / VC_BLK_M, ksplit);
+  if (a.n_tiles % (2 * NTW) != 0) return hipErrorInvalidValue;
+  dim3 grid(a.n_tiles / (2 * NTW), (a.n_rows + VC_BLK_M - 1) / VC_BLK_M, ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   return hipGetLastError();
+}
+template <typename WT, int EPI>
+static hipError_t launch_blk_e(const GemmArgs& a, int ksplit, hipStream_t s) {
+  // 128-channel tiles once they still give every CU a workgroup, else 64-channel tiles
+  const long wide = (long)(a.n_tiles / 8) * ((a.n_rows + VC_BLK_M - 1) / VC_BLK_M) * ksplit;
+  if (a.n_tiles % 8 == 0 && wide >= 240) return launch_blk_n<WT, EPI, 4>(a, ksplit, s);
+  return launch_blk_n<WT, EPI, 2>(a, ksplit, s);
 }
 template <typename WT>
 static hipError_t launch_blk(const GemmArgs& a, int pro, int epi, int ksplit, hipStream_t s) {
