@@ -214,9 +214,10 @@ def test_multi_utterance_equals_single_fp32():
     assert np.array_equal(outs[0][0].cpu().numpy(), load_golden("tts_greedy")["res"])
 
 
-@pytest.mark.parametrize("B,dtype", [(8, "fp32"), (12, "fp32"), (16, "fp32"), (12, "bf16")])
+@pytest.mark.parametrize("B,dtype", [(8, "fp32"), (12, "fp32"), (16, "fp32"), (12, "bf16"), (24, "fp32")])
 def test_wide_batch_decode_equals_per_utterance_oracle(B, dtype):
-    """8 / 12 / 16 utterances decoded together on a 16-head model: the batched-decode kernel variants
+    """8 / 12 / 16 / 24 / 40 utterances decoded together on a 16-head model (more than 16 = more than one MFMA row
+    tile: the decode pass then runs on the block GEMM, the heads 16 rows at a time): the batched-decode kernel variants
     (per-row LayerNorm launch + plain prologue with 16 X slots, attention with 4 and 2 splits and the
     matching merge prologues, multi-row attention grid) against one oracle run per utterance.
     fp32: greedy tokens bit-equal.  bf16: shapes, token range and the first generated token (codebook 0 of the
@@ -231,8 +232,10 @@ def test_wide_batch_decode_equals_per_utterance_oracle(B, dtype):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype=dtype, max_seqs=B, max_positions=256)
     outs = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3)
     orc = VoiceCraftOracle(a, sd) if dtype == "fp32" else None
-    for (xx, xl, yy), (res, gen) in zip(prompts, outs):
+    for u, ((xx, xl, yy), (res, gen)) in enumerate(zip(prompts, outs)):
         got = res.cpu().numpy()
+        if B > 16 and u % 3:            # wide batches: every third utterance against the (slow) CPU oracle
+            continue
         if orc is not None:
             want = orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3)[0].numpy()
             assert got.shape == want.shape and np.array_equal(got, want)
@@ -418,7 +421,7 @@ def test_full_size_giga830M_long_context_bench_shape():
     assert_free_running_frames(gen, a, 650)
 
 
-@pytest.mark.parametrize("B", [8, 12])
+@pytest.mark.parametrize("B", [8, 12, 24])
 def test_bf16_batched_decode_logits_per_sequence(B):
     """bf16 batched decode (per-row LayerNorm launch, 16-slot plain prologue, 4- and 2-split attention merges):
     every sequence of a ragged batch is teacher-forced on ITS OWN oracle trajectory and its per-step head
@@ -435,6 +438,7 @@ def test_bf16_batched_decode_logits_per_sequence(B):
         tr = []
         want_res.append(orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3, trace=tr)[0].numpy())
         traces.append(tr)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
     n = max(len(t) for t in traces)
     forced = np.zeros((n, B, 4), dtype=np.int64)
     for b, tr in enumerate(traces):

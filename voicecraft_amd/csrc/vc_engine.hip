@@ -67,7 +67,8 @@ struct vc_engine {
   float *hA = nullptr, *hB = nullptr, *q = nullptr, *parts = nullptr, *att_o = nullptr, *att_ml = nullptr;
   void *act = nullptr, *hh = nullptr, *xn = nullptr;
   float *logits = nullptr;              // [B_max][K][V]
-  float *dec_h = nullptr;               // [VC_ROWS][d]
+  float *dec_h = nullptr;               // [max(VC_ROWS, max_seqs)][d]
+  int NS = VC_ROWS;                     // rows the per-sequence buffers are sized for
   int *dec_row_seq = nullptr, *dec_row_pos = nullptr, *logit_row = nullptr;
   SeqState *st = nullptr;
   long long* dbg_ts = nullptr;
@@ -242,7 +243,8 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
 int attn_nsplit(vc_engine* e, int rows) {
   // 8-wave blocks: one decode row is covered by ~256 of them; several rows get ~512 (two per CU), which
   // halves the positions each block walks while the merge in the out-projection stays <= 4 partials
-  int ns = (rows > 1 ? 512 : 256) / std::max(1, rows * e->H);
+  static const int blocks_multi = getenv("VC_ATTN_BLOCKS") ? atoi(getenv("VC_ATTN_BLOCKS")) : 512;
+  int ns = (rows > 1 ? blocks_multi : 256) / std::max(1, rows * e->H);
   return std::max(1, std::min(ns, VC_MAX_NSPLIT));
 }
 
@@ -322,16 +324,16 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
 }
 
 // final LayerNorm + the K prediction heads (voicecraft.py:181-185, :1084-1086) for n rows;
-// row r reads hidden row gather[r] and writes logits row (out_row0 + r).
-int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s) {
+// row r reads hidden row gather[r] (or in_row0 + r) and writes logits row (out_row0 + r).
+int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row0, const int* n_active, hipStream_t s) {
   if (gather && n > 1) return fail(e, VC_EINVAL, "internal: a gathered head pass carries one row");
   RowSrc rs{};
   rs.n_rows = n; rs.n_active = n_active;
   {  //                                                                   
     GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
     g.Wp = e->Wh1; g.bias = e->bh1;
-    g.h_in = e->hB; g.h_out = nullptr;
-    g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
+    g.h_in = e->hB + (size_t)in_row0 * e->d; g.h_out = nullptr;
+    g.parts = e->parts + (size_t)in_row0 * e->d; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     g.wg = e->wg_h1; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
     if (!gather && n >= e->ln_split_rows) {
@@ -350,6 +352,13 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
     g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits + (size_t)out_row0 * e->K * e->V;
     HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
+  }
+  return VC_OK;
+}
+int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s) {
+  for (int r0 = 0; r0 < n; r0 += VC_ROWS) {       // wide batches: the heads run 16 rows at a time
+    int rc = run_heads16(e, gather, std::min(VC_ROWS, n - r0), r0, out_row0 + r0, n_active, s);
+    if (rc) return rc;
   }
   return VC_OK;
 }
@@ -377,7 +386,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
-      a.n_active = e->one; a.dbg_ts = e->dbg_ts;
+      a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -506,7 +515,13 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = B * rps; rs.nsplit = attn_nsplit(e, B * rps); rs.n_active = e->n_active;
   int rc;
-  if ((rc = forward_rows(e, rs, s))) return rc;
+  if (rs.n_rows > VC_ROWS) {      // more than one MFMA row tile: the step runs on the block GEMM (per-row LayerNorm launch,
+    rs.nsplit = 1;                // attention one workgroup per (row, head), no split partials)
+    rc = prefill_rows(e, rs, s);
+  } else {
+    rc = forward_rows(e, rs, s);
+  }
+  if (rc) return rc;
   // rps == 1: logit_row[b] == b (vc_tokens.hip advance_phase); the 3-row span switch is single-sequence
   if ((rc = run_heads(e, rps == 1 ? nullptr : e->logit_row, B, 0, e->n_active, s))) return rc;
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
@@ -636,7 +651,7 @@ extern "C" int vc_create(const vc_model_cfg* c, int hip_device, vc_engine** out)
       c->audio_pad_token != c->audio_vocab_size + 2)   // voicecraft.py:132-134
     return fail(nullptr, VC_EINVAL, "special tokens must be empty=V, eog=V+1, pad=V+2");
   if (c->eos >= V || c->eog >= V) return fail(nullptr, VC_EINVAL, "eos/eog outside the vocabulary");
-  if (c->max_seqs < 1 || c->max_seqs > VC_ROWS) return fail(nullptr, VC_EINVAL, "max_seqs must be in [1,%d]", VC_ROWS);
+  if (c->max_seqs < 1 || c->max_seqs > VC_MAX_SEQS) return fail(nullptr, VC_EINVAL, "max_seqs must be in [1,%d]", VC_MAX_SEQS);
   if (c->max_positions < 32) return fail(nullptr, VC_EINVAL, "max_positions too small");
   if (c->max_n_spans < 1 || c->max_n_spans > VC_MAX_SPANS) return fail(nullptr, VC_EINVAL, "max_n_spans unsupported");
   hipError_t err = hipSetDevice(hip_device);
@@ -645,6 +660,7 @@ extern "C" int vc_create(const vc_model_cfg* c, int hip_device, vc_engine** out)
   e->cfg = *c; e->device = hip_device;
   e->d = c->d_model; e->H = c->nhead; e->hd = hd; e->L = c->num_layers; e->K = c->n_codebooks;
   e->V = V; e->P = c->head_hidden; e->S_max = c->max_positions; e->B_max = c->max_seqs;
+  e->NS = std::max(VC_ROWS, c->max_seqs);
   *out = e;
   return VC_OK;
 }
@@ -816,20 +832,20 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   e->act = tmp;
   if ((rc = dalloc(e, &tmp, (size_t)VC_MAX_ROWS * d * e->esz))) return rc;
   e->xn = tmp;
-  if ((rc = dalloc(e, &tmp, (size_t)VC_ROWS * K * P * e->esz))) return rc;
+  if ((rc = dalloc(e, &tmp, (size_t)e->NS * K * P * e->esz))) return rc;
   e->hh = tmp;
-  if ((rc = dalloc(e, &e->logits, (size_t)VC_ROWS * K * V))) return rc;
-  if ((rc = dalloc(e, &e->dec_h, (size_t)VC_ROWS * d))) return rc;
-  if ((rc = dalloc(e, &e->dec_row_seq, (size_t)VC_ROWS))) return rc;
-  if ((rc = dalloc(e, &e->dec_row_pos, (size_t)VC_ROWS))) return rc;
-  if ((rc = dalloc(e, &e->logit_row, (size_t)VC_ROWS))) return rc;
-  if ((rc = dalloc(e, &e->st, (size_t)VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->logits, (size_t)e->NS * K * V))) return rc;
+  if ((rc = dalloc(e, &e->dec_h, (size_t)e->NS * d))) return rc;
+  if ((rc = dalloc(e, &e->dec_row_seq, (size_t)e->NS))) return rc;
+  if ((rc = dalloc(e, &e->dec_row_pos, (size_t)e->NS))) return rc;
+  if ((rc = dalloc(e, &e->logit_row, (size_t)e->NS))) return rc;
+  if ((rc = dalloc(e, &e->st, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
-  if ((rc = dalloc(e, &e->samp, (size_t)VC_ROWS * (VC_MAX_CODEBOOKS + 2)))) return rc;
-  if ((rc = dalloc(e, &e->cond, (size_t)VC_ROWS))) return rc;
-  if ((rc = dalloc(e, &e->amax, (size_t)VC_ROWS))) return rc;
+  if ((rc = dalloc(e, &e->samp, (size_t)e->NS * (VC_MAX_CODEBOOKS + 2)))) return rc;
+  if ((rc = dalloc(e, &e->cond, (size_t)e->NS))) return rc;
+  if ((rc = dalloc(e, &e->amax, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->dbg_ts, (size_t)32))) return rc;
   HIPCHK(e, hipMemset(e->dbg_ts, 0, 32 * 8));
   e->gen_cap = e->S_max;
@@ -837,7 +853,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipMemset(e->err_flag, 0, 16));
   HIPCHK(e, hipMemset(e->n_active, 0, 16));
   { const int one[4] = {1, 1, 1, 1}; HIPCHK(e, hipMemcpy(e->one, one, 16, hipMemcpyHostToDevice)); }
-  HIPCHK(e, hipHostMalloc((void**)&e->h_st, sizeof(SeqState) * VC_ROWS));
+  HIPCHK(e, hipHostMalloc((void**)&e->h_st, sizeof(SeqState) * e->NS));
   HIPCHK(e, hipHostMalloc((void**)&e->h_flag, 64));
   memset(e->h_flag, 0, 64);
   HIPCHK(e, hipHostMalloc((void**)&e->h_dyn, sizeof(SampleDyn)));
@@ -1140,15 +1156,15 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   const void* host_src = nullptr;
   int64_t avail = 0;
   const std::string n = name ? name : "";
-  if (n == "logits") { src = e->logits; avail = (int64_t)VC_ROWS * e->K * e->V * 4; }
+  if (n == "logits") { src = e->logits; avail = (int64_t)e->NS * e->K * e->V * 4; }
   else if (n == "hA") { src = e->hA; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "hB") { src = e->hB; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "q") { src = e->q; avail = (int64_t)VC_ROWS * e->d * 4; }
   else if (n == "parts") { src = e->parts; avail = (int64_t)VC_MAX_KSPLIT * VC_SLAB_ROWS * e->d * 4; }
   else if (n == "emb") { src = e->emb; avail = (int64_t)e->emb_cap * e->d * 4; }
-  else if (n == "dec_h") { src = e->dec_h; avail = (int64_t)VC_ROWS * e->d * 4; }
+  else if (n == "dec_h") { src = e->dec_h; avail = (int64_t)e->NS * e->d * 4; }
   else if (n == "gen") { src = e->gen; avail = (int64_t)e->B_max * e->gen_cap * e->K * 4; }
-  else if (n == "state") { src = e->st; avail = (int64_t)sizeof(SeqState) * VC_ROWS; }
+  else if (n == "state") { src = e->st; avail = (int64_t)sizeof(SeqState) * e->NS; }
   else if (n == "kcache0") { src = e->layers[0].kc; avail = (int64_t)e->B_max * e->H * e->S_max * e->hd * e->esz; }
   else if (n == "vcache0") { src = e->layers[0].vc; avail = (int64_t)e->B_max * e->H * e->S_max * e->hd * e->esz; }
   else if (n == "pe") { src = e->pe; avail = (int64_t)e->S_max * e->d * 4; }

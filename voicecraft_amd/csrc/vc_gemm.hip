@@ -563,6 +563,7 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   constexpr int RPJ = 256 / UPR;                                // rows between a thread's consecutive units (16)
   static_assert(XPT == 8, "the X staging below is written for 8 units per thread");
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (*a.n_active == 0) return;                                 // a replayed decode step after the last sequence retired
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wv >> 1, wn = wv & 1;                          // wave's row half / channel half
