@@ -121,9 +121,17 @@ int vc_tts(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, int
  * (x, y) pairs decoded as one batch; each row follows inference_tts exactly.
  *   x_dev int64 [sum Lx], y_dev int64 [sum T][K] concatenated; *_off host arrays [B+1].
  *   res_dev int64 [B][K][res_cap]; gen_len host [B].
- *   forced_dev / logits_dev: as in vc_tts, indexed by each sequence's own step count. */
+ *   forced_dev / logits_dev: as in vc_tts, indexed by each sequence's own step count.
+ *   shared_text_prefix: the first P text tokens are IDENTICAL in every sequence (the sentence-chained
+ *     "Long TTS" of gradio_app.py:231-236, :249-313: every sentence is synthesised as
+ *     [transcript of the voice prompt ; sentence] against the same audio prompt).  Text precedes audio in the
+ *     sequence and attention is causal, so the K/V of those P positions do not depend on what follows: they
+ *     are computed once (sequence 0) and every sequence's attention reads them there - exact, no copy.
+ *     (The audio prompt's K/V DO depend on the whole text and cannot be shared.)  0 = nothing shared;
+ *     the caller guarantees the equality. */
 int vc_tts_multi(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_off,
                  const int64_t* y_dev, const int32_t* y_off, const vc_sample_cfg* sc,
+                 int shared_text_prefix,
                  const int64_t* forced_dev, int n_forced, int64_t* res_dev, int res_cap, int* gen_len,
                  float* logits_dev, int logit_steps, int* n_steps, void* stream);
 

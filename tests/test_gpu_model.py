@@ -453,3 +453,35 @@ def test_bf16_batched_decode_logits_per_sequence(B):
         want = torch.stack([t["logits"][0] for t in tr]).numpy()
         worst = max(worst, float(rel_l2(lg[: len(tr), b], want).max()))
     assert worst <= 2e-2, worst
+
+
+@pytest.mark.parametrize("dtype", ["fp32"])
+def test_long_tts_sentences_with_shared_prefix_equal_independent_calls(dtype):
+    """SURVEY §8f-2, gradio_app.py:231-236, :249-313: every sentence of a Long-TTS request is synthesised on the text
+    [transcript of the voice prompt ; sentence] with the same audio prompt.  inference_tts_long decodes them together and
+    computes the K/V of the shared transcript prefix once (vc_tts_multi shared_text_prefix): every sentence must be
+    token-identical (fp32, greedy) to an INDEPENDENT oracle call on its own full text, with and without the reuse."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("tiny")
+    sd = synth.make_state_dict(a, seed=21)
+    rs = np.random.RandomState(8)
+    x_prompt = torch.from_numpy(rs.randint(0, 100, size=(9,)).astype(np.int64))
+    sents = [torch.from_numpy(rs.randint(0, 100, size=(n,)).astype(np.int64)) for n in (5, 11, 3, 8, 6)]
+    _, _, y = synth.random_prompt(a, 1, 37, seed=9)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype=dtype, max_seqs=4, max_positions=512)   # 5 sentences -> chunks of 4 + 1
+    orc = VoiceCraftOracle(a, sd)
+    want = []
+    for sv in sents:
+        x = torch.cat([x_prompt, sv]).unsqueeze(0)
+        want.append(orc.inference_tts(x, torch.tensor([x.shape[1]]), y, top_k=1, stop_repetition=3)[0].numpy())
+    for reuse in (True, False):
+        outs = eng.inference_tts_long(x_prompt, sents, y, top_k=1, stop_repetition=3, reuse_prefix=reuse)
+        assert len(outs) == len(sents)
+        for (res, gen), w in zip(outs, want):
+            assert res.shape == w.shape and np.array_equal(res.cpu().numpy(), w), f"reuse={reuse}"
+    # a later plain call must not see a stale shared prefix
+    x = torch.cat([x_prompt, sents[1]]).unsqueeze(0)
+    res = eng.inference_tts(x.cuda(), torch.tensor([x.shape[1]]).cuda(), y.cuda(), top_k=1, stop_repetition=3)[0]
+    assert np.array_equal(res.cpu().numpy(), want[1])

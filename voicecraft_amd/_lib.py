@@ -41,7 +41,7 @@ PROTOTYPES = {
                          C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p, C.c_int,
                          C.POINTER(C.c_int), C.c_void_p]),
     "vc_tts_multi": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32),
-                               C.POINTER(SampleCfg), C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
+                               C.POINTER(SampleCfg), C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int),
                                C.c_void_p, C.c_int, C.POINTER(C.c_int), C.c_void_p]),
     "vc_debug_sample": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SampleCfg), C.c_int, C.c_void_p, C.c_void_p]),
     "vc_edit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int,

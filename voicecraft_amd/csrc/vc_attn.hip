@@ -42,6 +42,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
   const int active = *a.n_active;
   const int pos = a.row_pos[r];
   const int seq = a.row_seq[r];
+  const int share = *a.share_len;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hd = a.hd;
@@ -70,17 +71,20 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 #pragma unroll
       for (int j = 0; j < EPL / 4; ++j) qv[j] = qp[j];
     }
-    const long base = (long)seq * a.cache_seq_stride + (long)h * a.S_max * hd + li * EPL;
+    const long hbase = (long)h * a.S_max * hd + li * EPL;
+    const long base = (long)seq * a.cache_seq_stride + hbase;
     const WT* kb = reinterpret_cast<const WT*>(a.kcache) + base;
     const WT* vb = reinterpret_cast<const WT*>(a.vcache) + base;
+    const long own = (long)seq * a.cache_seq_stride;      // positions below `share` live in sequence 0's cache
     uint4 ku[4], vu[4];
     int pp[4];
 #define VC_KV_LOADS(pb_)                                                     \
     _Pragma("unroll") for (int it = 0; it < 4; ++it) {                       \
       pp[it] = (pb_) + (it * NW + wave) * PPW + sub;                         \
       const long pc = max(min(pp[it], p1 - 1), 0);                           \
-      ku[it] = *reinterpret_cast<const uint4*>(kb + pc * hd);                \
-      vu[it] = *reinterpret_cast<const uint4*>(vb + pc * hd);                \
+      const long po = pc * hd - ((pc < share) ? own : 0);                    \
+      ku[it] = *reinterpret_cast<const uint4*>(kb + po);                     \
+      vu[it] = *reinterpret_cast<const uint4*>(vb + po);                     \
     }
     VC_KV_LOADS(p0);
     __builtin_amdgcn_sched_barrier(0);

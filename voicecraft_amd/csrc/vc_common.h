@@ -252,6 +252,8 @@ struct AttnArgs {
   const int* row_pos;
   int n_rows;
   const int* n_active;      // never null
+  const int* share_len;     // never null: cached positions [0, *share_len) of EVERY sequence are read from sequence 0's cache
+                            // (text prefix shared by all utterances of a sentence-chained call, vc_tts_multi)
   float* att_o;
   float* att_ml;
   void* x_out;              // nsplit == 1 only: normalised output rows, WT [rows][d] (the out-projection then takes the plain prologue)
@@ -284,6 +286,7 @@ struct PromptArgs {
   int* row_pos;
   int* err;                 // set to 1 when an out-of-range token id is met
   int text_rows;
+  int skip;                 // leading rows NOT emitted (their K/V are shared with sequence 0): the grid covers rows [skip, Lx + n_cols)
   int* logit_row;           // optional: *logit_row = logit_row_val (row of the last prefill group
   int logit_row_val;        //           whose hidden state feeds the heads)
 };

@@ -73,6 +73,7 @@ struct vc_engine {
   SeqState *st = nullptr;
   long long* dbg_ts = nullptr;
   int *one = nullptr;                   // device word holding 1: the "always active" flag of prefill launches
+  int *share_len = nullptr;             // device word: text positions shared with sequence 0 (AttnArgs.share_len), 0 outside such calls
   int *n_active = nullptr, *samp = nullptr, *cond = nullptr, *amax = nullptr, *gen = nullptr, *err_flag = nullptr;
   int gen_cap = 0;
   // pinned host staging
@@ -286,7 +287,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
-      a.att_o = e->att_o; a.att_ml = e->att_ml;
+      a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {  // out-projection of the merged attention output -> split-K partial slabs
@@ -386,7 +387,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
-      a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
+      a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
       if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -430,8 +431,8 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
     // ---- a group of prompts that fits the row arena
     size_t i1 = i0;
     int R = 0;
-    while (i1 < pas.size() && (i1 == i0 || R + pas[i1].Lx + pas[i1].n_cols <= e->emb_cap)) {
-      R += pas[i1].Lx + pas[i1].n_cols;
+    while (i1 < pas.size() && (i1 == i0 || R + pas[i1].Lx + pas[i1].n_cols - pas[i1].skip <= e->emb_cap)) {
+      R += pas[i1].Lx + pas[i1].n_cols - pas[i1].skip;
       ++i1;
     }
     if (R > e->emb_cap) return fail(e, VC_ECAP, "a prompt of %d rows does not fit the prefill arena of %d rows", R, e->emb_cap);
@@ -439,7 +440,7 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
     int row0 = 0;
     for (size_t i = i0; i < i1; ++i) {
       PromptArgs& pa = pas[i];
-      const int rows = pa.Lx + pa.n_cols;
+      const int rows = pa.Lx + pa.n_cols - pa.skip;
       pa.seq = slots[i]; pa.row0 = row0;
       pa.emb = e->emb; pa.row_seq = e->pre_row_seq; pa.row_pos = e->pre_row_pos; pa.err = e->err_flag;
       last[i - i0] = row0 + rows - 1;
@@ -843,6 +844,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
+  if ((rc = dalloc(e, &e->share_len, (size_t)4))) return rc;
+  HIPCHK(e, hipMemset(e->share_len, 0, 16));
   if ((rc = dalloc(e, &e->samp, (size_t)e->NS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->amax, (size_t)e->NS))) return rc;
@@ -885,7 +888,7 @@ struct TtsJob { const int64_t* x; int Lx; const int64_t* y; int T; };
 // Shared by vc_tts (one prompt, n_samples >= 1) and vc_tts_multi (B prompts).
 int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const vc_sample_cfg* sc,
             const int64_t* forced, int n_forced, float* logits_out, int logit_steps, int* steps_out,
-            hipStream_t s) {
+            hipStream_t s, int shared_prefix = 0) {
   const int K = e->K;
   const bool grouped = n_samples > 1;
   const int B = grouped ? n_samples : (int)jobs.size();
@@ -918,9 +921,12 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
       fill_prompt_common(e, pas[b], j.x, j.Lx, j.y, j.T);
       pas[b].n_seg = 1; pas[b].n_cols = j.T + 1;
       pas[b].seg[0] = Segment{0, j.T + 1, 0, j.T, -1, -1};
+      pas[b].skip = (b > 0) ? shared_prefix : 0;          // the shared text prefix is prefilled once, in sequence 0
       slots[b] = b;
       e->h_st[b] = init_state(e, j.Lx, j.T + 1, true, 1);
     }
+    e->h_flag[2] = shared_prefix;
+    HIPCHK(e, hipMemcpyAsync(e->share_len, e->h_flag + 2, sizeof(int), hipMemcpyHostToDevice, s));
     int rc = prefill_batch(e, pas, slots, s);
     if (rc) return rc;
   }
@@ -958,6 +964,7 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];
+  if (shared_prefix) HIPCHK(e, hipMemsetAsync(e->share_len, 0, sizeof(int), s));
   if (steps_out) {   // steps really taken (the longest sequence), not the launched multiple of steps_per_graph
     int m = 0;
     for (int b = 0; b < B; ++b) m = std::max(m, e->h_st[b].total_steps);
@@ -1014,17 +1021,22 @@ extern "C" int vc_tts(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t*
 
 extern "C" int vc_tts_multi(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_off,
                             const int64_t* y_dev, const int32_t* y_off, const vc_sample_cfg* sc,
+                            int shared_text_prefix,
                             const int64_t* forced_dev, int n_forced, int64_t* res_dev, int res_cap, int* gen_len,
                             float* logits_dev, int logit_steps, int* n_steps, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
   if (B < 1 || !x_dev || !x_off || !y_dev || !y_off || !sc || !res_dev || !gen_len)
     return fail(e, VC_EINVAL, "null/invalid argument to vc_tts_multi");
+  for (int b = 0; b < B; ++b)
+    if (shared_text_prefix < 0 || shared_text_prefix >= x_off[b + 1] - x_off[b])
+      return fail(e, VC_EINVAL, "shared_text_prefix %d must be shorter than every text (sequence %d has %d tokens)",
+                  shared_text_prefix, b, x_off[b + 1] - x_off[b]);
   hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
   std::vector<TtsJob> jobs;
   for (int b = 0; b < B; ++b)
     jobs.push_back(TtsJob{x_dev + x_off[b], x_off[b + 1] - x_off[b], y_dev + (size_t)y_off[b] * e->K, y_off[b + 1] - y_off[b]});
-  rc = tts_run(e, jobs, 1, sc, forced_dev, n_forced, logits_dev, logit_steps, n_steps, s);
+  rc = tts_run(e, jobs, 1, sc, forced_dev, n_forced, logits_dev, logit_steps, n_steps, s, B > 1 ? shared_text_prefix : 0);
   if (rc) return rc;
   for (int b = 0; b < B; ++b) {
     rc = assemble_tts(e, jobs[b], b, res_dev + (size_t)b * e->K * res_cap, res_cap, &gen_len[b], s);
@@ -1208,6 +1220,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   HIPCHK(e, hipMemsetAsync(e->hB, 0, (size_t)VC_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->parts, 0, (size_t)VC_MAX_KSPLIT * VC_SLAB_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->act, 0, (size_t)VC_ROWS * 4 * d * e->esz, s));
+  HIPCHK(e, hipMemsetAsync(e->xn, 0, (size_t)VC_ROWS * d * e->esz, s));
   HIPCHK(e, hipMemsetAsync(e->att_o, 0, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * e->hd * 4, s));
   HIPCHK(e, hipMemsetAsync(e->att_ml, 0, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * 2 * 4, s));
   HIPCHK(e, hipMemsetAsync(e->logit_row, 0, VC_ROWS * 4, s));
@@ -1220,11 +1233,13 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   auto one = [&](int i) -> int {
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
+    const bool split_ln = n_rows >= e->ln_split_rows;   // the engine then normalises in ln_rows_k and takes the plain prologue
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
       g.prev_bias = ly.bo; g.has_prev_bias = 1; g.wg = ly.wg_1; g.out = e->act; g.out_ld = 4 * d;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
+      if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s)); }
+      else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
     } else if (w == "ffn2") {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W2; g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts;
@@ -1233,7 +1248,8 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.h_in = e->hB; g.h_out = e->hA; g.parts = e->parts; g.n_parts = e->p_f2.ksplit;
       g.prev_bias = ly.b2; g.has_prev_bias = 1; g.wg = ly.wg_qkv; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
+      if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s)); }
+      else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
     } else if (w == "oproj") {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts;
@@ -1244,7 +1260,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
-      a.n_active = e->one; a.dbg_ts = e->dbg_ts;
+      a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);

@@ -79,13 +79,13 @@ extern "C" int vc_pattern_unshift(const int64_t* span_dev, int N, int K, int64_t
 // contributes columns s = 0..ncols with token(q) = content[s-1-q] or `empty`; a mask placeholder
 // column takes mask_embedding[mask_value] instead of the 4-table sum.  Audio positions restart at 0.
 __global__ __launch_bounds__(256) void prompt_k(const PromptArgs a) {
-  const int row = blockIdx.x;
+  const int row = blockIdx.x + a.skip;        // row of the sequence = its cache position
   const int d = a.d;
-  float* dst = a.emb + (long)(a.row0 + row) * d;
+  float* dst = a.emb + (long)(a.row0 + blockIdx.x) * d;
   if (threadIdx.x == 0) {
-    a.row_seq[a.row0 + row] = a.seq;
-    a.row_pos[a.row0 + row] = row;
-    if (row == 0 && a.logit_row) *a.logit_row = a.logit_row_val;
+    a.row_seq[a.row0 + blockIdx.x] = a.seq;
+    a.row_pos[a.row0 + blockIdx.x] = row;
+    if (blockIdx.x == 0 && a.logit_row) *a.logit_row = a.logit_row_val;
   }
   if (row < a.Lx) {
     long tok = a.x[row];
@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void prompt_k(const PromptArgs a) {
   }
 }
 hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s) {
-  hipLaunchKernelGGL(prompt_k, dim3(a.Lx + a.n_cols), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(prompt_k, dim3(a.Lx + a.n_cols - a.skip), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

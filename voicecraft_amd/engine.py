@@ -222,7 +222,7 @@ class VoiceCraftEngine:
     @torch.no_grad()
     def inference_tts_multi(self, xs, ys, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
                             stop_repetition: int = 3, silence_tokens: Iterable[int] = (1388, 1898, 131), _seed=None,
-                            _forced=None, _forced_mode: str = "tokens", _logit_steps: int = 0):
+                            _forced=None, _forced_mode: str = "tokens", _logit_steps: int = 0, _shared_text_prefix: int = 0):
         """B different utterances as one batch (not in the reference: SURVEY.md §8f-1).
         xs: list of int64 [Lx_i]; ys: list of int64 [T_i,K].  Returns list of (res [1,K,T_i+Tg_i], gen)
         (+ the raw head logits [steps,B,K,V] as a third value when _logit_steps > 0)."""
@@ -252,7 +252,7 @@ class VoiceCraftEngine:
             V = self.args.audio_vocab_size + int(self.args.n_special)
             logits = torch.zeros((_logit_steps, B, K, V), dtype=torch.float32, device=self.device)
         rc = self.lib.vc_tts_multi(self._h, B, C.c_void_p(xcat.data_ptr()), x_off, C.c_void_p(ycat.data_ptr()), y_off,
-                                   C.byref(sc), forced_ptr, n_forced, C.c_void_p(res.data_ptr()), cap, gen_len,
+                                   C.byref(sc), int(_shared_text_prefix), forced_ptr, n_forced, C.c_void_p(res.data_ptr()), cap, gen_len,
                                    C.c_void_p(logits.data_ptr()) if logits is not None else None, int(_logit_steps),
                                    C.byref(n_steps), self._stream())
         check(rc, self._h, "vc_tts_multi")
@@ -266,6 +266,32 @@ class VoiceCraftEngine:
             outs.append((r, g))
         if logits is not None:
             return outs, logits
+        return outs
+
+    @torch.no_grad()
+    def inference_tts_long(self, x_prompt, x_sentences, y, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
+                           stop_repetition: int = 3, silence_tokens: Iterable[int] = (1388, 1898, 131), reuse_prefix: bool = True,
+                           _seed=None):
+        """Sentence-chained "Long TTS" (gradio_app.py:231-236, :249-313): the reference synthesises every sentence with
+        its own `inference_one_sample` call on the text [transcript of the voice prompt ; sentence] and the SAME audio
+        prompt.  Here all sentences are decoded together (chunks of max_seqs: the weights are streamed once per step
+        for all of them), each row following inference_tts exactly, and with reuse_prefix the K/V of the shared
+        transcript prefix are computed once per chunk and read by every sentence (include/vc_engine.h, vc_tts_multi).
+
+        x_prompt int64 [Lp] phonemes of the voice prompt's transcript, x_sentences list of int64 [Ls_i],
+        y int64 [1,T,K] (or [T,K]) codes of the voice prompt.  Returns a list of (res [1,K,T+Tg_i], gen [1,K,Tg_i])."""
+        xp = torch.as_tensor(x_prompt, dtype=torch.int64).reshape(-1)
+        K = self.args.n_codebooks
+        yy = torch.as_tensor(y, dtype=torch.int64).reshape(-1, K)
+        outs = []
+        for c0 in range(0, len(x_sentences), self.max_seqs):
+            chunk = x_sentences[c0: c0 + self.max_seqs]
+            xs = [torch.cat([xp, torch.as_tensor(v, dtype=torch.int64).reshape(-1)]) for v in chunk]
+            for v in xs:
+                assert v.numel() > xp.numel(), "every sentence needs at least one phoneme"
+            share = int(xp.numel()) if (reuse_prefix and len(chunk) > 1) else 0
+            outs += self.inference_tts_multi(xs, [yy] * len(chunk), top_k, top_p, temperature, stop_repetition, silence_tokens,
+                                             _seed=None if _seed is None else _seed + c0, _shared_text_prefix=share)
         return outs
 
     # ------------------------------------------------------------------ editing
