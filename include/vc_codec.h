@@ -38,6 +38,15 @@ typedef struct vc_codec_cfg {
   int32_t residual_kernel_size; /* 3                                                   */
   int32_t compress;             /* 2: residual unit hidden = dim / compress            */
   int32_t max_samples;          /* capacity: longest waveform (samples) per call       */
+  /* Architecture switches of the SEANet stacks.  Which values the reference's checkpoint
+   * (audiocraft encodec_4cb2048_giga.th, data/tokenizer.py:109-110) was trained with cannot be read from the
+   * reference tree, so they are configuration, named as in transformers.EncodecConfig: */
+  int32_t causal;               /* use_causal_conv: all padding on the left, transposed convs trimmed on the right */
+  int32_t pad_reflect;          /* pad_mode: 1 = "reflect", 0 = "constant" (zeros)     */
+  int32_t conv_shortcut;        /* use_conv_shortcut: 1x1 conv on the residual path (else identity) */
+  int32_t num_residual_layers;  /* residual units per stage (1)                        */
+  int32_t dilation_growth_rate; /* unit j dilates its first conv by rate**j (2)        */
+  int32_t max_batch;            /* capacity: clips per vc_codec_encode_batch / decode_batch call */
 } vc_codec_cfg;
 
 int vc_codec_create(const vc_codec_cfg* cfg, int hip_device, vc_codec** out);
@@ -62,6 +71,17 @@ int vc_codec_encode(vc_codec* c, const float* wav_dev, int n_samples, int64_t* c
 /* AudioTokenizer.decode (data/tokenizer.py:131-133): codes int64 [K][T] -> wav fp32 [hop*T]. */
 int vc_codec_decode(vc_codec* c, const int64_t* codes_dev, int T, float* wav_dev, int wav_cap,
                     void* stream);
+/* Bulk forms: the reference's dataset encoder pushes a zero-padded batch [B,1,N] through ONE model.encode call
+ * (data/phonemize_encodec_encode_hf.py:186-206) and AudioTokenizer.encode/decode take [B,...] tensors.
+ *   encode_batch: wav fp32 [B][n_samples] (already padded to a common length) -> codes int64 [B][K][T]
+ *   decode_batch: codes int64 [B][K][T] -> wav fp32 [B][hop*T]
+ * Every item gives bit for bit what the single-clip call gives on the same (padded) row: the batch is an extra
+ * grid dimension of the convolutions and the LSTM advances all B sequences per launch (one read of the
+ * recurrence weights for the whole batch).  codes_cap / wav_cap are per item. */
+int vc_codec_encode_batch(vc_codec* c, const float* wav_dev, int B, int n_samples, int64_t* codes_dev,
+                          int codes_cap, int* n_frames, void* stream);
+int vc_codec_decode_batch(vc_codec* c, const int64_t* codes_dev, int B, int T, float* wav_dev, int wav_cap,
+                          void* stream);
 /* Test hooks: the latent before quantisation ([T][hidden], channels-last) of the last encode,
  * and its timing (HIP events on the stream). */
 int vc_codec_debug_latent(vc_codec* c, float* host_dst, int64_t n_floats);

@@ -13,14 +13,18 @@ from __future__ import annotations
 import torch
 
 
-def build(state_dict: dict[str, torch.Tensor] | None = None):
+def build(state_dict: dict[str, torch.Tensor] | None = None, **overrides):
+    """overrides: the architecture switches the reference tree does not pin (use_causal_conv, pad_mode,
+    use_conv_shortcut, num_residual_layers, dilation_growth_rate), as EncodecConfig names them."""
     from transformers import EncodecConfig, EncodecModel
-    cfg = EncodecConfig(target_bandwidths=[2.2], sampling_rate=16000, audio_channels=1, normalize=False,
-                        chunk_length_s=None, hidden_size=128, num_filters=64, num_residual_layers=1,
-                        upsampling_ratios=[8, 5, 4, 2], norm_type="weight_norm", kernel_size=7, last_kernel_size=7,
-                        residual_kernel_size=3, dilation_growth_rate=2, use_causal_conv=False, pad_mode="reflect",
-                        compress=2, num_lstm_layers=2, trim_right_ratio=1.0, codebook_size=2048, codebook_dim=128,
-                        use_conv_shortcut=False)
+    kw = dict(target_bandwidths=[2.2], sampling_rate=16000, audio_channels=1, normalize=False,
+              chunk_length_s=None, hidden_size=128, num_filters=64, num_residual_layers=1,
+              upsampling_ratios=[8, 5, 4, 2], norm_type="weight_norm", kernel_size=7, last_kernel_size=7,
+              residual_kernel_size=3, dilation_growth_rate=2, use_causal_conv=False, pad_mode="reflect",
+              compress=2, num_lstm_layers=2, trim_right_ratio=1.0, codebook_size=2048, codebook_dim=128,
+              use_conv_shortcut=False)
+    kw.update(overrides)
+    cfg = EncodecConfig(**kw)
     m = EncodecModel(cfg).eval()
     if state_dict is not None:
         missing, unexpected = m.load_state_dict(state_dict, strict=False)

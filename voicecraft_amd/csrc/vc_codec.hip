@@ -38,6 +38,8 @@ struct ConvArgs {
   int s_in, dil, pad, reflect;
   int s_out, o_off, L_dst;
   long w_phase_stride;   // float4 units
+  int nphase;            // grid.z = nphase * batch: phase = z % nphase, batch item = z / nphase
+  long x_bstride, o_bstride;   // floats between consecutive batch items of x and of out/res
 };
 
 __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x); }
@@ -46,7 +48,9 @@ __device__ __forceinline__ float elu1(float x) { return x > 0.f ? x : expm1f(x);
 __global__ __launch_bounds__(256) void conv_gemm_k(const ConvArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int g = lane >> 4, m = lane & 15;
-  const int phase = blockIdx.z;
+  const int phase = blockIdx.z % a.nphase, bi = blockIdx.z / a.nphase;
+  const float* xbase = a.x + (long)bi * a.x_bstride;
+  const long obase = (long)bi * a.o_bstride;
   const int t0 = (blockIdx.x * 4 + wave) * 32;
   const int cot0 = blockIdx.y * 2;                       // first 16-channel tile
   if (t0 >= a.T) return;
@@ -78,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvArgs a) {
         p = max(0, min(p, a.L_in - 1));
       }
       ok[ni] = v;
-      xp[ni] = a.x + (long)p * a.Ci + 4 * g;
+      xp[ni] = xbase + (long)p * a.Ci + 4 * g;
     }
     const float4* w0 = wp0 + (long)k * ktpk * 64;
     const float4* w1 = wp1 + (long)k * ktpk * 64;
@@ -110,7 +114,7 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvArgs a) {
       const int o = t * a.s_out + a.o_off + phase;
       if (t >= a.T || o < 0 || o >= a.L_dst) continue;
       float4 v = make_float4(acc[mi][ni][0] + b.x, acc[mi][ni][1] + b.y, acc[mi][ni][2] + b.z, acc[mi][ni][3] + b.w);
-      const long off = (long)o * a.Co + co;
+      const long off = obase + (long)o * a.Co + co;
       if (a.res) {
         const float4 r = *reinterpret_cast<const float4*>(a.res + off);
         v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
@@ -146,39 +150,53 @@ __global__ void conv_pack_k(const float* __restrict__ W, float4* __restrict__ Wp
 
 // first layer: 1 -> Co channels, reflect padding (Ci = 1 has no 16-wide K tile)
 __global__ void conv_first_k(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                             float* __restrict__ out_raw, float* __restrict__ out_elu, int L, int Co, int Kw, int pad) {
+                             float* __restrict__ out_raw, float* __restrict__ out_elu, int L, int Co, int Kw, int pad,
+                             int reflect, int B) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int cq = Co >> 2;
-  if (idx >= (long)L * cq) return;
-  const int t = (int)(idx / cq), co = (int)(idx % cq) * 4;
+  if (idx >= (long)B * L * cq) return;
+  const long tg = idx / cq;                              // b * L + t
+  const int t = (int)(tg % L), co = (int)(idx % cq) * 4;
+  const float* xb = x + (tg - t);
   float4 v = *reinterpret_cast<const float4*>(bias + co);
   for (int k = 0; k < Kw; ++k) {
     int p = t + k - pad;
-    if (p < 0) p = -p;
-    if (p >= L) p = 2 * (L - 1) - p;
+    bool ok = true;
+    if (reflect) {
+      if (p < 0) p = -p;
+      if (p >= L) p = 2 * (L - 1) - p;
+    } else {
+      ok = (p >= 0 && p < L);
+    }
     p = max(0, min(p, L - 1));
-    const float xv = x[p];
+    const float xv = ok ? xb[p] : 0.f;
     v.x += W[(co + 0) * Kw + k] * xv; v.y += W[(co + 1) * Kw + k] * xv;
     v.z += W[(co + 2) * Kw + k] * xv; v.w += W[(co + 3) * Kw + k] * xv;
   }
-  const long off = (long)t * Co + co;
+  const long off = tg * Co + co;
   if (out_raw) *reinterpret_cast<float4*>(out_raw + off) = v;
   if (out_elu) *reinterpret_cast<float4*>(out_elu + off) = make_float4(elu1(v.x), elu1(v.y), elu1(v.z), elu1(v.w));
 }
 
 // last layer: Ci -> 1 channel.  W is [1][Ci][Kw]; x is the ELU'd [L][Ci].
 __global__ void conv_last_k(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                            float* __restrict__ out, int L, int Ci, int Kw, int pad) {
+                            float* __restrict__ out, int L, int Ci, int Kw, int pad, int reflect) {
   extern __shared__ float s_w[];                         // [Kw][Ci]
   for (int i = threadIdx.x; i < Kw * Ci; i += blockDim.x) { const int k = i / Ci, ci = i - k * Ci; s_w[i] = W[ci * Kw + k]; }
   __syncthreads();
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= L) return;
+  x += (long)blockIdx.y * L * Ci;                         // batch item
+  out += (long)blockIdx.y * L;
   float acc = bias[0];
   for (int k = 0; k < Kw; ++k) {
     int p = t + k - pad;
-    if (p < 0) p = -p;
-    if (p >= L) p = 2 * (L - 1) - p;
+    if (reflect) {
+      if (p < 0) p = -p;
+      if (p >= L) p = 2 * (L - 1) - p;
+    } else if (p < 0 || p >= L) {
+      continue;
+    }
     p = max(0, min(p, L - 1));
     const float4* xr = reinterpret_cast<const float4*>(x + (long)p * Ci);
     const float4* wr = reinterpret_cast<const float4*>(s_w + k * Ci);
@@ -254,14 +272,14 @@ struct LstmWaveArgs {
   const float* Whh[2];   // [4H][H], unit-major rows
   const float* Wih1;     // layer 1: [4H][H], unit-major rows
   const float* b1;       // layer 1: b_ih + b_hh, unit-major
-  const float* G0;       // layer 0: [T][4H] input projection + both biases
-  float* hs[2];          // [T][H] hidden sequences
-  float* c[2];           // [H] cell states
+  const float* G0;       // layer 0: [B][T][4H] input projection + both biases
+  float* hs[2];          // [B][T][H] hidden sequences
+  float* c[2];           // [B][H] cell states
   const float* hzero;    // [H] zeros
-  const float* skip;     // [T][H] block input (EncodecLSTM: lstm(x) + x)
-  float* out_raw;        // optional [T][H]
-  float* out_elu;        // optional [T][H]
-  int H, T, k;
+  const float* skip;     // [B][T][H] block input (EncodecLSTM: lstm(x) + x)
+  float* out_raw;        // optional [B][T][H]
+  float* out_elu;        // optional [B][T][H]
+  int H, T, k, B;        // B sequences advance together: the step's weights are read ONCE for all of them
 };
 template <int NQ>   // H = 256 * NQ
 __global__ __launch_bounds__(256) void lstm_wave_k(const LstmWaveArgs a) {
@@ -272,63 +290,73 @@ __global__ __launch_bounds__(256) void lstm_wave_k(const LstmWaveArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int u = blockIdx.x * 4 + wave;                   // hidden unit (grid.x = H / 4)
   const int nq = H >> 2;
+  const long TH = (long)a.T * H;
   const float4* whh = reinterpret_cast<const float4*>(a.Whh[n] + (long)(4 * u) * H);
-  const float4* hp = reinterpret_cast<const float4*>(t ? a.hs[n] + (long)(t - 1) * H : a.hzero);
-  float4 w[4][NQ], hv[NQ], wi[4][NQ], xv[NQ];
+  float4 w[4][NQ], wi[4][NQ];
 #pragma unroll
   for (int j = 0; j < NQ; ++j) {
-    hv[j] = hp[lane + 64 * j];
 #pragma unroll
     for (int g = 0; g < 4; ++g) w[g][j] = whh[(long)g * nq + lane + 64 * j];
   }
-  float4 gi;
-  if (n == 0) {
-    gi = *reinterpret_cast<const float4*>(a.G0 + (long)t * 4 * H + 4 * u);
-  } else {
+  float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n == 1) {
     const float4* wih = reinterpret_cast<const float4*>(a.Wih1 + (long)(4 * u) * H);
-    const float4* xp = reinterpret_cast<const float4*>(a.hs[0] + (long)t * H);
 #pragma unroll
     for (int j = 0; j < NQ; ++j) {
-      xv[j] = xp[lane + 64 * j];
 #pragma unroll
       for (int g = 0; g < 4; ++g) wi[g][j] = wih[(long)g * nq + lane + 64 * j];
     }
-    gi = *reinterpret_cast<const float4*>(a.b1 + 4 * u);
+    gb = *reinterpret_cast<const float4*>(a.b1 + 4 * u);
   }
-  const float c_prev = a.c[n][u];
-  const float sk = (n == 1 && a.skip) ? a.skip[(long)t * H + u] : 0.f;
-  float g4[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < a.B; ++b) {
+    const float4* hp = reinterpret_cast<const float4*>(t ? a.hs[n] + b * TH + (long)(t - 1) * H : a.hzero);
+    float4 hv[NQ], xv[NQ];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) {
+    for (int j = 0; j < NQ; ++j) hv[j] = hp[lane + 64 * j];
+    float4 gi = gb;
+    if (n == 0) {
+      gi = *reinterpret_cast<const float4*>(a.G0 + (b * (long)a.T + t) * 4 * H + 4 * u);
+    } else {
+      const float4* xp = reinterpret_cast<const float4*>(a.hs[0] + b * TH + (long)t * H);
 #pragma unroll
-    for (int j = 0; j < NQ; ++j)
-      g4[g] += (w[g][j].x * hv[j].x + w[g][j].y * hv[j].y) + (w[g][j].z * hv[j].z + w[g][j].w * hv[j].w);
-  }
-  if (n == 1) {
+      for (int j = 0; j < NQ; ++j) xv[j] = xp[lane + 64 * j];
+    }
+    const float c_prev = a.c[n][(long)b * H + u];
+    const float sk = (n == 1 && a.skip) ? a.skip[b * TH + (long)t * H + u] : 0.f;
+    float g4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      float acc = 0.f;
 #pragma unroll
       for (int j = 0; j < NQ; ++j)
-        acc += (wi[g][j].x * xv[j].x + wi[g][j].y * xv[j].y) + (wi[g][j].z * xv[j].z + wi[g][j].w * xv[j].w);
-      g4[g] += acc;
+        g4[g] += (w[g][j].x * hv[j].x + w[g][j].y * hv[j].y) + (w[g][j].z * hv[j].z + w[g][j].w * hv[j].w);
     }
-  }
+    if (n == 1) {
 #pragma unroll
-  for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
-  if (lane != 0) return;
-  const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
-  const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
-  const float gg = tanhf(g4[2] + gi.z);
-  const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
-  const float c = fg * c_prev + ig * gg;
-  const float h = og * tanhf(c);
-  a.c[n][u] = c;
-  a.hs[n][(long)t * H + u] = h;
-  if (n == 1 && a.skip) {
-    const float y = h + sk;
-    if (a.out_raw) a.out_raw[(long)t * H + u] = y;
-    if (a.out_elu) a.out_elu[(long)t * H + u] = elu1(y);
+      for (int g = 0; g < 4; ++g) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+          acc += (wi[g][j].x * xv[j].x + wi[g][j].y * xv[j].y) + (wi[g][j].z * xv[j].z + wi[g][j].w * xv[j].w);
+        g4[g] += acc;
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
+    if (lane == 0) {
+      const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
+      const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
+      const float gg = tanhf(g4[2] + gi.z);
+      const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
+      const float c = fg * c_prev + ig * gg;
+      const float h = og * tanhf(c);
+      a.c[n][(long)b * H + u] = c;
+      a.hs[n][b * TH + (long)t * H + u] = h;
+      if (n == 1 && a.skip) {
+        const float y = h + sk;
+        if (a.out_raw) a.out_raw[b * TH + (long)t * H + u] = y;
+        if (a.out_elu) a.out_elu[b * TH + (long)t * H + u] = elu1(y);
+      }
+    }
   }
 }
 
@@ -341,8 +369,10 @@ __global__ __launch_bounds__(256) void rvq_encode_k(const float* __restrict__ z,
   __shared__ float s_bv[4];
   __shared__ int s_bi[4];
   __shared__ int s_best;
-  const int t = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < D; i += blockDim.x) s_r[i] = z[(long)t * D + i];
+  const int tg = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;     // grid.x = B * T frames
+  const int t = tg % T;
+  codes += (long)(tg / T) * Q * T;                        // codes [B][Q][T]
+  for (int i = tid; i < D; i += blockDim.x) s_r[i] = z[(long)tg * D + i];
   __syncthreads();
   for (int qz = 0; qz < Q; ++qz) {
     float r2 = 0.f;
@@ -372,10 +402,12 @@ __global__ __launch_bounds__(256) void rvq_encode_k(const float* __restrict__ z,
   }
 }
 __global__ void rvq_decode_k(const int64_t* __restrict__ codes, const float* __restrict__ E, float* __restrict__ out,
-                             int T, int D, int C, int Q, int* err) {
+                             int T, int D, int C, int Q, int* err, int B) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long)T * D) return;
-  const int t = (int)(idx / D), i = (int)(idx % D);
+  if (idx >= (long)B * T * D) return;
+  const long tg = idx / D;                                // b * T + t
+  const int t = (int)(tg % T), i = (int)(idx % D);
+  codes += (tg / T) * (long)Q * T;                        // codes [B][Q][T]
   float v = 0.f;
   for (int q = 0; q < Q; ++q) {                          // quantized_out = 0 + q0 + q1 + ... in this order
     long c = codes[(long)q * T + t];
@@ -421,6 +453,11 @@ struct Conv {
   float4* Wp = nullptr;     // packed (all phases)
   long phase_stride = 0;
 };
+struct ResUnit {            // EncodecResnetBlock: ELU, conv(k = residual_kernel_size, dilation), ELU, conv(k = 1) + shortcut
+  Conv c3, c1, sc;
+  int dil = 1;
+  bool has_sc = false;
+};
 struct Lstm {
   int H = 0, layers = 0;
   std::vector<float*> Whh;   // permuted [4H][H]
@@ -440,16 +477,19 @@ struct vc_codec {
   int hop = 1;
   // encoder
   Conv enc_first, enc_last;
-  std::vector<Conv> enc_res3, enc_res1, enc_down;
+  std::vector<std::vector<ResUnit>> enc_res;   // [stage][residual layer]
+  std::vector<Conv> enc_down;
   Lstm enc_lstm;
   // decoder
   Conv dec_first, dec_last;
-  std::vector<Conv> dec_up, dec_res3, dec_res1;
+  std::vector<Conv> dec_up;
+  std::vector<std::vector<ResUnit>> dec_res;
   Lstm dec_lstm;
   // quantizer
   float *E = nullptr, *Et = nullptr, *e2 = nullptr;
   // activations
-  float *A_raw = nullptr, *A_elu = nullptr, *B_elu = nullptr, *H_elu = nullptr, *latent = nullptr;
+  float *A_raw = nullptr, *C_raw = nullptr, *S_raw = nullptr, *A_elu = nullptr, *B_elu = nullptr, *H_elu = nullptr, *latent = nullptr;
+  int B_max = 1;
   float *G = nullptr, *HS0 = nullptr, *HS1 = nullptr, *cstate = nullptr, *hzero = nullptr;
   int* err_flag = nullptr;
   int* h_flag = nullptr;
@@ -564,29 +604,37 @@ int make_lstm(vc_codec* c, const std::string& prefix, int H, int layers, Lstm* L
   return VC_OK;
 }
 
-// out positions of a strided / plain convolution, padding split as EncodecConv1d does
-// (non-causal: right = total//2, left = total - right; the "extra" right padding is reflect too)
+// out positions of a strided / plain convolution, padding as EncodecConv1d does (transformers modeling_encodec:
+// padding_total = (Kw - 1) * dilation + 1 - stride; non-causal: right = total // 2, left = total - right;
+// causal: everything on the left; the "extra" right padding that completes the last frame is padded the same way).
+// x / out / res hold B items of L_in (T) positions back to back.
 int run_conv(vc_codec* c, const Conv& cv, const float* x, int L_in, const float* res, float* out_raw, float* out_elu,
-             int* L_out, hipStream_t s) {
-  const int pt = cv.Kw - cv.stride;
-  const int pr = pt / 2, pl = pt - pr;
+             int* L_out, hipStream_t s, int B = 1, int dil = 1) {
+  const int pt = (cv.Kw - 1) * dil + 1 - cv.stride;
+  const int pl = c->cfg.causal ? pt : pt - pt / 2;
   const int T = (L_in + cv.stride - 1) / cv.stride;
+  const int prt = (T - 1) * cv.stride + (cv.Kw - 1) * dil + 1 - pl - L_in;      // right padding incl. the extra part
+  if (c->cfg.pad_reflect && L_in <= std::max(pl, prt))   // the reference zero-extends then reflects here (_pad1d): not reproduced
+    return cfail(c, VC_EINVAL, "input of %d positions is shorter than the reflect padding of a layer (clips of fewer than 4 frames are not supported)", L_in);
   ConvArgs a;
   memset(&a, 0, sizeof a);
   a.x = x; a.Wp = cv.Wp; a.bias = cv.bias; a.res = res; a.out_raw = out_raw; a.out_elu = out_elu;
   a.L_in = L_in; a.T = T; a.Ci = cv.Ci; a.Co = cv.Co; a.Kw = cv.Kw;
-  a.s_in = cv.stride; a.dil = 1; a.pad = pl; a.reflect = 1;
+  a.s_in = cv.stride; a.dil = dil; a.pad = pl; a.reflect = c->cfg.pad_reflect;
   a.s_out = 1; a.o_off = 0; a.L_dst = T; a.w_phase_stride = cv.phase_stride;
-  hipLaunchKernelGGL(conv_gemm_k, dim3((T + 127) / 128, (cv.Co + 31) / 32, 1), dim3(256), 0, s, a);
+  a.nphase = 1; a.x_bstride = (long)L_in * cv.Ci; a.o_bstride = (long)T * cv.Co;
+  hipLaunchKernelGGL(conv_gemm_k, dim3((T + 127) / 128, (cv.Co + 31) / 32, B), dim3(256), 0, s, a);
   CCHK(c, hipGetLastError());
   *L_out = T;
   return VC_OK;
 }
-// EncodecConvTranspose1d: full length (L-1)*s + 2s, trimmed by (left = total - total//2, right = total//2)
-int run_convT(vc_codec* c, const Conv& cv, const float* x, int L_in, float* out_raw, float* out_elu, int* L_out, hipStream_t s) {
+// EncodecConvTranspose1d: full length (L-1)*s + 2s, trimmed by (left = total - right; right = total // 2, or
+// everything when causal with trim_right_ratio = 1)
+int run_convT(vc_codec* c, const Conv& cv, const float* x, int L_in, float* out_raw, float* out_elu, int* L_out, hipStream_t s,
+              int B = 1) {
   const int st = cv.stride;
   const int pt = cv.Kw - st;
-  const int pr = pt / 2, pl = pt - pr;
+  const int pr = c->cfg.causal ? pt : pt / 2, pl = pt - pr;
   const int L_dst = L_in * st;
   ConvArgs a;
   memset(&a, 0, sizeof a);
@@ -594,28 +642,66 @@ int run_convT(vc_codec* c, const Conv& cv, const float* x, int L_in, float* out_
   a.L_in = L_in; a.T = L_in + 1; a.Ci = cv.Ci; a.Co = cv.Co; a.Kw = 2;
   a.s_in = 1; a.dil = -1; a.pad = 0; a.reflect = 0;
   a.s_out = st; a.o_off = -pl; a.L_dst = L_dst; a.w_phase_stride = cv.phase_stride;
-  hipLaunchKernelGGL(conv_gemm_k, dim3((a.T + 127) / 128, (cv.Co + 31) / 32, st), dim3(256), 0, s, a);
+  a.nphase = st; a.x_bstride = (long)L_in * cv.Ci; a.o_bstride = (long)L_dst * cv.Co;
+  hipLaunchKernelGGL(conv_gemm_k, dim3((a.T + 127) / 128, (cv.Co + 31) / 32, st * B), dim3(256), 0, s, a);
   CCHK(c, hipGetLastError());
   *L_out = L_dst;
   return VC_OK;
 }
 
-// EncodecLSTM: y = lstm(x) + x over [T][H]; x is raw, the block output is written raw and/or ELU'd
-int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, float* out_elu, hipStream_t s) {
+// A stage's residual units (EncodecResnetBlock x num_residual_layers).  In: raw tensor in *raw, its ELU in *elu.
+// Out: *elu holds the ELU of the last unit's output (what the following ELU + conv consumes); *raw its raw value
+// only when want_raw.  Buffers ping-pong between (A_raw, A_elu) and (C_raw, B_elu).
+int run_res_units(vc_codec* c, const std::vector<ResUnit>& units, float** raw, float** elu, int L, bool want_raw,
+                  hipStream_t s, int B) {
+  int rc, Lo;
+  for (size_t j = 0; j < units.size(); ++j) {
+    const ResUnit& u = units[j];
+    float* nraw = (*raw == c->A_raw) ? c->C_raw : c->A_raw;
+    float* nelu = (*elu == c->A_elu) ? c->B_elu : c->A_elu;
+    const bool keep_raw = want_raw || j + 1 < units.size();
+    if ((rc = run_conv(c, u.c3, *elu, L, nullptr, nullptr, c->H_elu, &Lo, s, B, u.dil))) return rc;
+    const float* res = *raw;
+    if (u.has_sc) {                                       // shortcut = 1x1 conv of the block input (no activation)
+      if ((rc = run_conv(c, u.sc, *raw, L, nullptr, c->S_raw, nullptr, &Lo, s, B))) return rc;
+      res = c->S_raw;
+    }
+    if ((rc = run_conv(c, u.c1, c->H_elu, L, res, keep_raw ? nraw : nullptr, nelu, &Lo, s, B))) return rc;
+    *raw = nraw; *elu = nelu;
+  }
+  return VC_OK;
+}
+
+// a linear layer over every position as a 1x1 implicit GEMM (the LSTM input projection)
+int run_conv1x1(vc_codec* c, const Conv& cv, const float* x, int T, float* out_raw, hipStream_t s, int B) {
+  ConvArgs a;
+  memset(&a, 0, sizeof a);
+  a.x = x; a.Wp = cv.Wp; a.bias = cv.bias; a.out_raw = out_raw;
+  a.L_in = T; a.T = T; a.Ci = cv.Ci; a.Co = cv.Co; a.Kw = 1;
+  a.s_in = 1; a.dil = 1; a.pad = 0; a.reflect = 0;
+  a.s_out = 1; a.o_off = 0; a.L_dst = T; a.w_phase_stride = cv.phase_stride;
+  a.nphase = 1; a.x_bstride = (long)T * cv.Ci; a.o_bstride = (long)T * cv.Co;
+  hipLaunchKernelGGL(conv_gemm_k, dim3((T + 127) / 128, (cv.Co + 31) / 32, B), dim3(256), 0, s, a);
+  CCHK(c, hipGetLastError());
+  return VC_OK;
+}
+
+// EncodecLSTM: y = lstm(x) + x over [B][T][H]; x is raw, the block output is written raw and/or ELU'd
+int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, float* out_elu, hipStream_t s, int B = 1) {
   const int H = L.H;
   const float* in = x;
   float* seq[2] = {c->HS0, c->HS1};
   if (L.layers == 2 && H % 256 == 0 && H <= 1024 && !getenv("VC_LSTM_SEQUENTIAL")) {
     // two-layer wavefront: T + 1 launches (lstm_wave_k)
     int Lo;
-    int rc = run_conv(c, L.Wih[0], x, T, nullptr, c->G, nullptr, &Lo, s);        // layer 0: G = x W_ih^T + b_ih + b_hh
+    int rc = run_conv1x1(c, L.Wih[0], x, T, c->G, s, B);                          // layer 0: G = x W_ih^T + b_ih + b_hh
     if (rc) return rc;
-    CCHK(c, hipMemsetAsync(c->cstate, 0, (size_t)2 * H * 4, s));
+    CCHK(c, hipMemsetAsync(c->cstate, 0, (size_t)2 * B * H * 4, s));
     LstmWaveArgs a;
     memset(&a, 0, sizeof a);
     a.Whh[0] = L.Whh[0]; a.Whh[1] = L.Whh[1]; a.Wih1 = L.WihP[1]; a.b1 = L.bP[1]; a.G0 = c->G;
-    a.hs[0] = seq[0]; a.hs[1] = seq[1]; a.c[0] = c->cstate; a.c[1] = c->cstate + H; a.hzero = c->hzero;
-    a.skip = x; a.out_raw = out_raw; a.out_elu = out_elu; a.H = H; a.T = T;
+    a.hs[0] = seq[0]; a.hs[1] = seq[1]; a.c[0] = c->cstate; a.c[1] = c->cstate + (size_t)B * H; a.hzero = c->hzero;
+    a.skip = x; a.out_raw = out_raw; a.out_elu = out_elu; a.H = H; a.T = T; a.B = B;
     const dim3 grid(H / 4, 2);
     for (int k = 0; k <= T; ++k) {
       a.k = k;
@@ -627,9 +713,9 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
     CCHK(c, hipGetLastError());
     return VC_OK;
   }
+  if (B != 1) return cfail(c, VC_EINVAL, "batched LSTM needs the two-layer wavefront (2 layers, hidden a multiple of 256 <= 1024)");
   for (int n = 0; n < L.layers; ++n) {
-    int Lo;
-    int rc = run_conv(c, L.Wih[n], in, T, nullptr, c->G, nullptr, &Lo, s);      // G = in W_ih^T + b_ih + b_hh
+    int rc = run_conv1x1(c, L.Wih[n], in, T, c->G, s, 1);                        // G = in W_ih^T + b_ih + b_hh
     if (rc) return rc;
     CCHK(c, hipMemsetAsync(c->cstate, 0, (size_t)H * 4, s));
     float* hs = seq[n & 1];
@@ -663,6 +749,9 @@ extern "C" int vc_codec_create(const vc_codec_cfg* cfg, int hip_device, vc_codec
   if (cfg->compress != 2) return cfail(nullptr, VC_EINVAL, "compress must be 2");
   if (cfg->n_q < 1 || cfg->n_q > VC_MAX_CODEBOOKS) return cfail(nullptr, VC_EINVAL, "n_q out of range");
   if (cfg->max_samples < 1) return cfail(nullptr, VC_EINVAL, "max_samples must be positive");
+  if (cfg->num_residual_layers < 1 || cfg->num_residual_layers > 4) return cfail(nullptr, VC_EINVAL, "num_residual_layers must be in [1,4]");
+  if (cfg->dilation_growth_rate < 1 || cfg->dilation_growth_rate > 4) return cfail(nullptr, VC_EINVAL, "dilation_growth_rate must be in [1,4]");
+  if (cfg->max_batch < 1 || cfg->max_batch > 64) return cfail(nullptr, VC_EINVAL, "max_batch must be in [1,64]");
   hipError_t e = hipSetDevice(hip_device);
   if (e != hipSuccess) return cfail(nullptr, VC_EHIP, "hipSetDevice(%d): %s", hip_device, hipGetErrorString(e));
   vc_codec* c = new vc_codec();
@@ -711,17 +800,29 @@ extern "C" int vc_codec_finalize(vc_codec* c) {
   const int F = g.n_filters, R = g.n_ratios;
   int rc;
   // ---- encoder: module indices as transformers.EncodecEncoder enumerates them
+  const int NR = g.num_residual_layers;
+  auto make_unit = [&](const std::string& rb, int ch, int j, ResUnit* u) -> int {
+    int r;
+    u->dil = 1;
+    for (int q = 0; q < j; ++q) u->dil *= g.dilation_growth_rate;              // dilation_growth_rate ** j
+    if ((r = make_conv(c, rb + "block.1.conv", ch, ch / g.compress, g.residual_kernel_size, 1, 0, &u->c3, true))) return r;
+    if ((r = make_conv(c, rb + "block.3.conv", ch / g.compress, ch, 1, 1, 0, &u->c1, true))) return r;
+    u->has_sc = g.conv_shortcut != 0;
+    if (u->has_sc && (r = make_conv(c, rb + "shortcut.conv", ch, ch, 1, 1, 0, &u->sc, true))) return r;
+    return VC_OK;
+  };
   int idx = 0;
   if ((rc = make_conv(c, "encoder.layers.0.conv", 1, F, g.kernel_size, 1, 0, &c->enc_first, false))) return rc;
   idx = 1;
   int ch = F;
-  c->enc_res3.resize(R); c->enc_res1.resize(R); c->enc_down.resize(R);
+  c->enc_res.assign(R, std::vector<ResUnit>(NR)); c->enc_down.resize(R);
   for (int i = 0; i < R; ++i) {
     const int ratio = g.ratios[R - 1 - i];               // reversed(upsampling_ratios)
-    const std::string rb = "encoder.layers." + std::to_string(idx) + ".block.";
-    if ((rc = make_conv(c, rb + "1.conv", ch, ch / 2, g.residual_kernel_size, 1, 0, &c->enc_res3[i], true))) return rc;
-    if ((rc = make_conv(c, rb + "3.conv", ch / 2, ch, 1, 1, 0, &c->enc_res1[i], true))) return rc;
-    idx += 2;                                            // resblock, ELU
+    for (int j = 0; j < NR; ++j) {
+      if ((rc = make_unit("encoder.layers." + std::to_string(idx) + ".", ch, j, &c->enc_res[i][j]))) return rc;
+      idx += 1;                                          // one module per resblock
+    }
+    idx += 1;                                            // ELU
     if ((rc = make_conv(c, "encoder.layers." + std::to_string(idx) + ".conv", ch, ch * 2, ratio * 2, ratio, 0, &c->enc_down[i], true))) return rc;
     idx += 1;
     ch *= 2;
@@ -735,16 +836,16 @@ extern "C" int vc_codec_finalize(vc_codec* c) {
   if ((rc = make_lstm(c, "decoder.layers.1.lstm", top, g.lstm_layers, &c->dec_lstm))) return rc;
   idx = 2;
   ch = top;
-  c->dec_up.resize(R); c->dec_res3.resize(R); c->dec_res1.resize(R);
+  c->dec_up.resize(R); c->dec_res.assign(R, std::vector<ResUnit>(NR));
   for (int i = 0; i < R; ++i) {
     const int ratio = g.ratios[i];
     idx += 1;                                            // ELU
     if ((rc = make_conv(c, "decoder.layers." + std::to_string(idx) + ".conv", ch, ch / 2, ratio * 2, ratio, 1, &c->dec_up[i], true))) return rc;
     idx += 1;
-    const std::string rb = "decoder.layers." + std::to_string(idx) + ".block.";
-    if ((rc = make_conv(c, rb + "1.conv", ch / 2, ch / 4, g.residual_kernel_size, 1, 0, &c->dec_res3[i], true))) return rc;
-    if ((rc = make_conv(c, rb + "3.conv", ch / 4, ch / 2, 1, 1, 0, &c->dec_res1[i], true))) return rc;
-    idx += 1;
+    for (int j = 0; j < NR; ++j) {
+      if ((rc = make_unit("decoder.layers." + std::to_string(idx) + ".", ch / 2, j, &c->dec_res[i][j]))) return rc;
+      idx += 1;
+    }
     ch /= 2;
   }
   idx += 1;                                              // ELU
@@ -764,17 +865,21 @@ extern "C" int vc_codec_finalize(vc_codec* c) {
   CCHK(c, hipGetLastError());
   // ---- activation arenas
   const size_t N = (size_t)g.max_samples;
+  const size_t NB = (size_t)g.max_batch;
+  c->B_max = g.max_batch;
   c->T_max = (int)((N + c->hop - 1) / c->hop) + 1;
-  const size_t big = std::max(N * F, (size_t)c->T_max * top) + 1024;
+  const size_t big = NB * std::max(N * F, (size_t)c->T_max * top) + 1024;
   if ((rc = calloc_dev(c, &c->A_raw, big))) return rc;
   if ((rc = calloc_dev(c, &c->A_elu, big))) return rc;
   if ((rc = calloc_dev(c, &c->B_elu, big))) return rc;
-  if ((rc = calloc_dev(c, &c->H_elu, big / 2 + 1024))) return rc;
-  if ((rc = calloc_dev(c, &c->latent, (size_t)c->T_max * D))) return rc;
-  if ((rc = calloc_dev(c, &c->G, (size_t)c->T_max * 4 * top))) return rc;
-  if ((rc = calloc_dev(c, &c->HS0, (size_t)c->T_max * top))) return rc;
-  if ((rc = calloc_dev(c, &c->HS1, (size_t)c->T_max * top))) return rc;
-  if ((rc = calloc_dev(c, &c->cstate, (size_t)2 * top))) return rc;
+  if ((rc = calloc_dev(c, &c->H_elu, big))) return rc;
+  if (NR > 1 && (rc = calloc_dev(c, &c->C_raw, big))) return rc;
+  if (g.conv_shortcut && (rc = calloc_dev(c, &c->S_raw, big))) return rc;
+  if ((rc = calloc_dev(c, &c->latent, NB * c->T_max * D))) return rc;
+  if ((rc = calloc_dev(c, &c->G, NB * c->T_max * 4 * top))) return rc;
+  if ((rc = calloc_dev(c, &c->HS0, NB * c->T_max * top))) return rc;
+  if ((rc = calloc_dev(c, &c->HS1, NB * c->T_max * top))) return rc;
+  if ((rc = calloc_dev(c, &c->cstate, NB * 2 * top))) return rc;
   if ((rc = calloc_dev(c, &c->hzero, (size_t)top))) return rc;
   if ((rc = calloc_dev(c, &c->err_flag, (size_t)4))) return rc;
   CCHK(c, hipMemset(c->hzero, 0, (size_t)top * 4));
@@ -788,11 +893,14 @@ extern "C" int vc_codec_finalize(vc_codec* c) {
   return VC_OK;
 }
 
-extern "C" int vc_codec_encode(vc_codec* c, const float* wav_dev, int n_samples, int64_t* codes_dev, int codes_cap,
-                               int* n_frames, void* stream) {
+extern "C" int vc_codec_encode_batch(vc_codec* c, const float* wav_dev, int B, int n_samples, int64_t* codes_dev,
+                                     int codes_cap, int* n_frames, void* stream) {
   if (!c || !c->finalized) return cfail(c, VC_ESTATE, "codec not finalized");
   if (!wav_dev || !codes_dev || !n_frames) return cfail(c, VC_EINVAL, "null argument to vc_codec_encode");
-  if (n_samples < 16 || n_samples > c->cfg.max_samples) return cfail(c, VC_ECAP, "n_samples %d outside [16, %d]", n_samples, c->cfg.max_samples);
+  if (B < 1 || B > c->B_max) return cfail(c, VC_ECAP, "batch %d outside [1, %d]", B, c->B_max);
+  if (n_samples < 4 * c->hop - c->hop + 1 || n_samples > c->cfg.max_samples)
+    return cfail(c, VC_ECAP, "n_samples %d outside [%d, %d] (clips of fewer than 4 frames are not supported)", n_samples,
+                 3 * c->hop + 1, c->cfg.max_samples);
   CCHK(c, hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
   const vc_codec_cfg& g = c->cfg;
@@ -800,25 +908,29 @@ extern "C" int vc_codec_encode(vc_codec* c, const float* wav_dev, int n_samples,
   CCHK(c, hipEventRecord(c->ev[0], s));
   int L = n_samples;
   {
-    const long tot = (long)L * (F / 4);
-    const int pad = (g.kernel_size - 1) - (g.kernel_size - 1) / 2;
+    const long tot = (long)B * L * (F / 4);
+    const int pt = g.kernel_size - 1;
+    const int pad = g.causal ? pt : pt - pt / 2;
     hipLaunchKernelGGL(conv_first_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, wav_dev, c->enc_first.w_raw,
-                       c->enc_first.bias, c->A_raw, c->A_elu, L, F, g.kernel_size, pad);
+                       c->enc_first.bias, c->A_raw, c->A_elu, L, F, g.kernel_size, pad, g.pad_reflect, B);
   }
   int rc, Lo;
   const int R = g.n_ratios;
+  float *raw = c->A_raw, *elu = c->A_elu;
   for (int i = 0; i < R; ++i) {
-    if ((rc = run_conv(c, c->enc_res3[i], c->A_elu, L, nullptr, nullptr, c->H_elu, &Lo, s))) return rc;
-    if ((rc = run_conv(c, c->enc_res1[i], c->H_elu, L, c->A_raw, nullptr, c->B_elu, &Lo, s))) return rc;
+    if ((rc = run_res_units(c, c->enc_res[i], &raw, &elu, L, false, s, B))) return rc;
     const bool last = (i == R - 1);
-    if ((rc = run_conv(c, c->enc_down[i], c->B_elu, L, nullptr, c->A_raw, last ? nullptr : c->A_elu, &Lo, s))) return rc;
+    float* nelu = (elu == c->A_elu) ? c->B_elu : c->A_elu;
+    // the down-sampling conv writes the next stage's raw input (A_raw) and, unless the LSTM follows, its ELU
+    if ((rc = run_conv(c, c->enc_down[i], elu, L, nullptr, c->A_raw, last ? nullptr : nelu, &Lo, s, B))) return rc;
+    raw = c->A_raw; elu = nelu;
     L = Lo;
   }
   const int T = L;
   if (T > codes_cap) return cfail(c, VC_ECAP, "codes capacity %d < %d frames", codes_cap, T);
-  if ((rc = run_lstm(c, c->enc_lstm, c->A_raw, T, nullptr, c->B_elu, s))) return rc;
-  if ((rc = run_conv(c, c->enc_last, c->B_elu, T, nullptr, c->latent, nullptr, &Lo, s))) return rc;
-  hipLaunchKernelGGL(rvq_encode_k, dim3(T), dim3(256), (size_t)g.hidden * 4, s, c->latent, c->Et, c->E, c->e2, codes_dev, T,
+  if ((rc = run_lstm(c, c->enc_lstm, c->A_raw, T, nullptr, c->B_elu, s, B))) return rc;
+  if ((rc = run_conv(c, c->enc_last, c->B_elu, T, nullptr, c->latent, nullptr, &Lo, s, B))) return rc;
+  hipLaunchKernelGGL(rvq_encode_k, dim3(B * T), dim3(256), (size_t)g.hidden * 4, s, c->latent, c->Et, c->E, c->e2, codes_dev, T,
                      g.hidden, g.codebook_size, g.n_q);
   CCHK(c, hipGetLastError());
   CCHK(c, hipEventRecord(c->ev[1], s));
@@ -828,10 +940,16 @@ extern "C" int vc_codec_encode(vc_codec* c, const float* wav_dev, int n_samples,
   *n_frames = T;
   return VC_OK;
 }
+extern "C" int vc_codec_encode(vc_codec* c, const float* wav_dev, int n_samples, int64_t* codes_dev, int codes_cap,
+                               int* n_frames, void* stream) {
+  return vc_codec_encode_batch(c, wav_dev, 1, n_samples, codes_dev, codes_cap, n_frames, stream);
+}
 
-extern "C" int vc_codec_decode(vc_codec* c, const int64_t* codes_dev, int T, float* wav_dev, int wav_cap, void* stream) {
+extern "C" int vc_codec_decode_batch(vc_codec* c, const int64_t* codes_dev, int B, int T, float* wav_dev, int wav_cap,
+                                     void* stream) {
   if (!c || !c->finalized) return cfail(c, VC_ESTATE, "codec not finalized");
   if (!codes_dev || !wav_dev) return cfail(c, VC_EINVAL, "null argument to vc_codec_decode");
+  if (B < 1 || B > c->B_max) return cfail(c, VC_ECAP, "batch %d outside [1, %d]", B, c->B_max);
   if (T < 4 || T > c->T_max - 1) return cfail(c, VC_ECAP, "T %d outside [4, %d]", T, c->T_max - 1);
   if ((long)T * c->hop > wav_cap) return cfail(c, VC_ECAP, "wav capacity %d < %ld", wav_cap, (long)T * c->hop);
   CCHK(c, hipSetDevice(c->device));
@@ -839,24 +957,28 @@ extern "C" int vc_codec_decode(vc_codec* c, const int64_t* codes_dev, int T, flo
   const vc_codec_cfg& g = c->cfg;
   CCHK(c, hipEventRecord(c->ev[0], s));
   {
-    const long tot = (long)T * g.hidden;
+    const long tot = (long)B * T * g.hidden;
     hipLaunchKernelGGL(rvq_decode_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, codes_dev, c->E, c->latent, T, g.hidden,
-                       g.codebook_size, g.n_q, c->err_flag);
+                       g.codebook_size, g.n_q, c->err_flag, B);
   }
   int rc, Lo, L = T;
-  if ((rc = run_conv(c, c->dec_first, c->latent, L, nullptr, c->A_raw, nullptr, &Lo, s))) return rc;
-  if ((rc = run_lstm(c, c->dec_lstm, c->A_raw, L, nullptr, c->B_elu, s))) return rc;
+  if ((rc = run_conv(c, c->dec_first, c->latent, L, nullptr, c->A_raw, nullptr, &Lo, s, B))) return rc;
+  if ((rc = run_lstm(c, c->dec_lstm, c->A_raw, L, nullptr, c->B_elu, s, B))) return rc;
+  float* elu = c->B_elu;
   for (int i = 0; i < g.n_ratios; ++i) {
-    if ((rc = run_convT(c, c->dec_up[i], c->B_elu, L, c->A_raw, c->A_elu, &Lo, s))) return rc;
+    float* nelu = (elu == c->A_elu) ? c->B_elu : c->A_elu;
+    if ((rc = run_convT(c, c->dec_up[i], elu, L, c->A_raw, nelu, &Lo, s, B))) return rc;
     L = Lo;
-    if ((rc = run_conv(c, c->dec_res3[i], c->A_elu, L, nullptr, nullptr, c->H_elu, &Lo, s))) return rc;
-    if ((rc = run_conv(c, c->dec_res1[i], c->H_elu, L, c->A_raw, nullptr, c->B_elu, &Lo, s))) return rc;
+    float* raw = c->A_raw;
+    elu = nelu;
+    if ((rc = run_res_units(c, c->dec_res[i], &raw, &elu, L, false, s, B))) return rc;
   }
   {
     const int Ci = g.n_filters, Kw = g.last_kernel_size;
-    const int pad = (Kw - 1) - (Kw - 1) / 2;
-    hipLaunchKernelGGL(conv_last_k, dim3((L + 255) / 256), dim3(256), (size_t)Kw * Ci * 4, s, c->B_elu, c->dec_last.w_raw,
-                       c->dec_last.bias, wav_dev, L, Ci, Kw, pad);
+    const int pt = Kw - 1;
+    const int pad = g.causal ? pt : pt - pt / 2;
+    hipLaunchKernelGGL(conv_last_k, dim3((L + 255) / 256, B), dim3(256), (size_t)Kw * Ci * 4, s, elu, c->dec_last.w_raw,
+                       c->dec_last.bias, wav_dev, L, Ci, Kw, pad, g.pad_reflect);
   }
   CCHK(c, hipGetLastError());
   CCHK(c, hipEventRecord(c->ev[1], s));
@@ -869,10 +991,13 @@ extern "C" int vc_codec_decode(vc_codec* c, const int64_t* codes_dev, int T, flo
   }
   return VC_OK;
 }
+extern "C" int vc_codec_decode(vc_codec* c, const int64_t* codes_dev, int T, float* wav_dev, int wav_cap, void* stream) {
+  return vc_codec_decode_batch(c, codes_dev, 1, T, wav_dev, wav_cap, stream);
+}
 
 extern "C" int vc_codec_debug_latent(vc_codec* c, float* host_dst, int64_t n_floats) {
   if (!c || !c->finalized || !host_dst) return VC_EINVAL;
-  if (n_floats > (int64_t)c->T_max * c->cfg.hidden) return cfail(c, VC_ECAP, "latent holds %lld floats", (long long)c->T_max * c->cfg.hidden);
+  if (n_floats > (int64_t)c->B_max * c->T_max * c->cfg.hidden) return cfail(c, VC_ECAP, "latent holds %lld floats", (long long)c->B_max * c->T_max * c->cfg.hidden);
   CCHK(c, hipDeviceSynchronize());
   CCHK(c, hipMemcpy(host_dst, c->latent, (size_t)n_floats * 4, hipMemcpyDeviceToHost));
   return VC_OK;

@@ -122,7 +122,7 @@ def random_prompt(args: Namespace, Lx: int, T: int, seed: int = 1):
     return x, torch.tensor([Lx], dtype=torch.int64), y
 
 
-def make_codec_state_dict(seed: int = 0) -> dict[str, torch.Tensor]:
+def make_codec_state_dict(seed: int = 0, use_conv_shortcut: bool = False, num_residual_layers: int = 1) -> dict[str, torch.Tensor]:
     """Synthetic EnCodec weights in transformers.EncodecModel naming (weight-norm g/v pairs, LSTM,
     codebooks) at the VoiceCraft codec shape.  Magnitudes keep activations O(1) through 16 layers."""
     rs = np.random.RandomState(seed)
@@ -151,10 +151,17 @@ def make_codec_state_dict(seed: int = 0) -> dict[str, torch.Tensor]:
     F, ratios, hidden = 64, [8, 5, 4, 2], 128
     conv("encoder.layers.0", F, 1, 7)
     idx, ch = 1, F
+    def res_unit(prefix, dim):
+        conv(prefix + ".block.1", dim // 2, dim, 3)
+        conv(prefix + ".block.3", dim, dim // 2, 1)
+        if use_conv_shortcut:
+            conv(prefix + ".shortcut", dim, dim, 1)
+
     for r in reversed(ratios):
-        conv(f"encoder.layers.{idx}.block.1", ch // 2, ch, 3)
-        conv(f"encoder.layers.{idx}.block.3", ch, ch // 2, 1)
-        idx += 2
+        for _ in range(num_residual_layers):
+            res_unit(f"encoder.layers.{idx}", ch)
+            idx += 1
+        idx += 1
         conv(f"encoder.layers.{idx}", ch * 2, ch, 2 * r)
         idx += 1
         ch *= 2
@@ -168,9 +175,9 @@ def make_codec_state_dict(seed: int = 0) -> dict[str, torch.Tensor]:
         idx += 1
         conv(f"decoder.layers.{idx}", ch // 2, ch, 2 * r, transposed=True)
         idx += 1
-        conv(f"decoder.layers.{idx}.block.1", ch // 4, ch // 2, 3)
-        conv(f"decoder.layers.{idx}.block.3", ch // 2, ch // 4, 1)
-        idx += 1
+        for _ in range(num_residual_layers):
+            res_unit(f"decoder.layers.{idx}", ch // 2)
+            idx += 1
         ch //= 2
     idx += 1
     conv(f"decoder.layers.{idx}", 1, F, 7)
