@@ -86,6 +86,8 @@ int vc_codec_decode_batch(vc_codec* c, const int64_t* codes_dev, int B, int T, f
  * and its timing (HIP events on the stream). */
 int vc_codec_debug_latent(vc_codec* c, float* host_dst, int64_t n_floats);
 int vc_codec_last_ms(const vc_codec* c, float* ms);
+/* Duration of the LSTM recurrence (T+1 wavefront launches) of the last call and the weight bytes one launch reads. */
+int vc_codec_last_lstm_ms(vc_codec* c, float* ms, double* bytes_per_step);
 
 #ifdef __cplusplus
 }

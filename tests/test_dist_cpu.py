@@ -20,9 +20,11 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("use_oracle", [0, 1])
-def test_two_rank_shard_and_gather(use_oracle, tmp_path):
-    world, n_total = 2, 5
+@pytest.mark.parametrize("use_oracle,n_total", [(0, 5), (1, 5), (0, 1), (0, 2)])
+def test_two_rank_shard_and_gather(use_oracle, n_total, tmp_path):
+    """n_total = 5: ragged lengths and an empty slot on rank 1; n_total = 1: rank 1 has NO utterance at all
+    (n_total < world) and still takes part in the collective with an all-empty block."""
+    world = 2
     port = _free_port()
     procs = []
     for r in range(world):

@@ -45,6 +45,7 @@ PROTOTYPES = {
     "vc_codec_decode_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "vc_codec_debug_latent": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64]),
     "vc_codec_last_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "vc_codec_last_lstm_ms": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_double)]),
 }
 
 # the VoiceCraft codec (README.md:198 of the reference; config.py:51; phonemize_encodec_encode_hf.py:11-13)
@@ -281,6 +282,11 @@ class AudioTokenizer:
         out = torch.empty((T, hidden), dtype=torch.float32)
         self._check(self.lib.vc_codec_debug_latent(self._h, C.c_void_p(out.data_ptr()), out.numel()), "vc_codec_debug_latent")
         return out
+
+    def last_lstm_ms(self):
+        ms, by = C.c_float(0), C.c_double(0)
+        self.lib.vc_codec_last_lstm_ms(self._h, C.byref(ms), C.byref(by))
+        return ms.value, by.value
 
     def last_ms(self) -> float:
         ms = C.c_float(0)

@@ -496,7 +496,8 @@ struct vc_codec {
   int T_max = 0;
   int last_T = 0;
   hipEvent_t ev[2]{};
-  float last_ms = 0;
+  float last_ms = 0, last_lstm_ms = 0;
+  hipEvent_t ev_l[2]{};
   hipStream_t own_stream = nullptr;
 };
 
@@ -703,6 +704,7 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
     a.hs[0] = seq[0]; a.hs[1] = seq[1]; a.c[0] = c->cstate; a.c[1] = c->cstate + (size_t)B * H; a.hzero = c->hzero;
     a.skip = x; a.out_raw = out_raw; a.out_elu = out_elu; a.H = H; a.T = T; a.B = B;
     const dim3 grid(H / 4, 2);
+    CCHK(c, hipEventRecord(c->ev_l[0], s));
     for (int k = 0; k <= T; ++k) {
       a.k = k;
       if (H == 256) hipLaunchKernelGGL(lstm_wave_k<1>, grid, dim3(256), 0, s, a);
@@ -711,6 +713,7 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
       else hipLaunchKernelGGL(lstm_wave_k<4>, grid, dim3(256), 0, s, a);
     }
     CCHK(c, hipGetLastError());
+    CCHK(c, hipEventRecord(c->ev_l[1], s));
     return VC_OK;
   }
   if (B != 1) return cfail(c, VC_EINVAL, "batched LSTM needs the two-layer wavefront (2 layers, hidden a multiple of 256 <= 1024)");
@@ -770,6 +773,7 @@ extern "C" void vc_codec_destroy(vc_codec* c) {
   for (void* p : c->allocs) hipFree(p);
   if (c->h_flag) hipHostFree(c->h_flag);
   for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+  for (auto& ev : c->ev_l) if (ev) hipEventDestroy(ev);
   if (c->own_stream) hipStreamDestroy(c->own_stream);
   delete c;
 }
@@ -886,6 +890,7 @@ extern "C" int vc_codec_finalize(vc_codec* c) {
   CCHK(c, hipMemset(c->err_flag, 0, 16));
   CCHK(c, hipHostMalloc((void**)&c->h_flag, 64));
   for (auto& ev : c->ev) CCHK(c, hipEventCreate(&ev));
+  for (auto& ev : c->ev_l) CCHK(c, hipEventCreate(&ev));
   CCHK(c, hipStreamCreate(&c->own_stream));
   CCHK(c, hipDeviceSynchronize());
   // the packed images are all that is needed of the conv weights; first/last convs and the LSTM keep their raw rows
@@ -1006,5 +1011,12 @@ extern "C" int vc_codec_debug_latent(vc_codec* c, float* host_dst, int64_t n_flo
 extern "C" int vc_codec_last_ms(const vc_codec* c, float* ms) {
   if (!c || !ms) return VC_EINVAL;
   *ms = c->last_ms;
+  return VC_OK;
+}
+extern "C" int vc_codec_last_lstm_ms(vc_codec* c, float* ms, double* bytes_per_step) {
+  if (!c || !ms) return VC_EINVAL;
+  if (hipEventElapsedTime(&c->last_lstm_ms, c->ev_l[0], c->ev_l[1]) != hipSuccess) c->last_lstm_ms = 0;
+  *ms = c->last_lstm_ms;
+  if (bytes_per_step) *bytes_per_step = 3.0 * 4.0 * c->enc_lstm.H * c->enc_lstm.H * 4.0;    // W_hh0, W_hh1, W_ih1 in fp32
   return VC_OK;
 }

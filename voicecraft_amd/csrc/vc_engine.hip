@@ -1204,7 +1204,9 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
                                double* alg_bytes, void* stream) {
   int rc = check_ready(e);
   if (rc) return rc;
-  if (!which || n_rows < 1 || n_rows > VC_ROWS || iters < 1 || !avg_ms) return fail(e, VC_EINVAL, "bad argument to vc_bench_kernel");
+  if (!which || n_rows < 1 || iters < 1 || !avg_ms) return fail(e, VC_EINVAL, "bad argument to vc_bench_kernel");
+  const bool pf = std::string(which).rfind("pf_", 0) == 0;      // prefill block GEMM: up to VC_MAX_ROWS rows
+  if (n_rows > (pf ? VC_MAX_ROWS : VC_ROWS)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed %d", n_rows, pf ? VC_MAX_ROWS : VC_ROWS);
   hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
   const std::string w = which;
   const int d = e->d;
@@ -1262,6 +1264,10 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
+    } else if (w == "pf_ffn1") {      // the prefill pass's FFN up-projection on the MFMA block GEMM (X = xn, n_rows rows)
+      GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
+      g.Wp = ly.W1; g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = 1;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);
       if (r) return r;
@@ -1288,6 +1294,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     else if (w == "qkv") b = 3.0 * d * d * es + n_rows * (d * 4.0 + 3.0 * d * es);
     else if (w == "oproj") b = 1.0 * d * d * es + n_rows * (d * 4.0 * 2);
     else if (w == "attn") b = n_rows * 2.0 * d * es * (std::min(e->S_max - 1, 883) + 1);   // K and V of every cached position
+    else if (w == "pf_ffn1") b = 2.0 * n_rows * (double)d * 4.0 * d;                       // FLOPs, not bytes (MFMA roofline)
     else b = (double)e->L * (12.0 * d * d + 13.0 * d) * es + 2.0 * d * es +
              (double)e->K * ((double)d * e->P + e->P + (double)e->P * e->V + e->V) * es;
     *alg_bytes = b;
