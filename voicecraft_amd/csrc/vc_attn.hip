@@ -199,3 +199,210 @@ hipError_t vc_launch_copy_kv(void* cache, long seq_stride, int H, int S_max, int
                      (long)S_max * hd * esz, (long)len * hd * esz, H, src_seq, dst_seq0);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------- prefill attention on the MFMA (flash style)
+// A prefill pass lays every prompt's rows back to back, each prompt starting on a multiple of 16 rows (vc_engine.hip
+// prefill_batch), so a tile of 16 consecutive rows belongs to ONE sequence and holds consecutive positions
+// pos0 .. pos0+na-1 (na <= 16: the tail of a prompt's last tile is padding, row_pos = -1).  rows_attn_k walks the
+// whole prefix once per ROW (2 GB of K/V out of L2 per layer for a 700-row prompt - that was 45 % of the prefill);
+// here a workgroup owns (row tile, head), its 4 waves take every 4th key tile, and per key tile of KW keys
+// (bf16: 32, fp32: 16):
+//   S = Q K^T   MFMA: A = Q fragments (registers, pre-scaled), B = K straight from the cache (a cached row IS a B fragment)
+//   online softmax on the D layout (lane = 4 query rows x 1 key): row max / row sum are 16-lane DPP reductions
+//   O += P V    MFMA: A = P (re-laid out through a 1 KB wave-private LDS tile), B = V^T (the V tile is transposed
+//               into wave-private LDS while it is copied: the contraction index of this product is the KEY)
+// The four partial (max, sum, O) sets are merged through LDS at the end.  No block barrier inside the key loop.
+template <typename WT, int HD>
+__global__ __launch_bounds__(256) void tile_attn_k(const AttnArgs a) {
+  using T = WTr<WT>;
+  constexpr int EPL = T::EPL, KW = T::KW;            // elements per 16-byte fragment; keys per tile = k-extent of a fragment
+  constexpr int NSUB = KW / 16;                      // 16-key sub-tiles of S per key tile
+  constexpr int NKS = HD / KW;                       // k-steps of Q K^T
+  constexpr int NDT = HD / 16;                       // 16-wide dim tiles of O
+  constexpr int SZ = (int)sizeof(WT);
+  constexpr int VS = KW * SZ + 16;                   // LDS row stride of V^T [HD][KW] and of P [16][KW]
+  constexpr int WAVE_LDS = (HD + 16) * VS;
+  constexpr int NPK = 4 / SZ;                        // keys packed into one 32-bit LDS word of V^T (bf16: 2)
+  constexpr int VITEMS = (KW / NPK) * (HD / EPL) / 64;   // (key group, dim group) items per lane per tile
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kg = lane >> 4;
+  const int r0 = blockIdx.x * 16, h = blockIdx.y;
+  const int share = *a.share_len;
+  const int rp = (r0 + m < a.n_rows) ? a.row_pos[r0 + m] : -1;
+  const int pos0 = __builtin_amdgcn_readfirstlane(rp);
+  const int seq = a.row_seq[r0];
+  const int na = __popcll(__ballot(rp >= 0 && lane < 16));       // active rows: positions pos0 .. pos0+na-1
+  char* vt = smem + wave * WAVE_LDS;                   // V^T tile of this wave
+  char* pt = vt + HD * VS;                             // P tile of this wave
+  float mrun[4], lrun[4];
+  f32x4 o[NDT];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (na > 0 && pos0 >= 0) {
+    const int last = pos0 + na - 1;
+    // ---- Q fragments (A operand): lane holds Q[row m][dims KW*ks + EPL*kg ..), pre-scaled, as WT
+    uint4 qf[NKS];
+    {
+      const float* qp = a.q + (long)min(r0 + m, a.n_rows - 1) * a.d + h * HD + EPL * kg;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        WT tmp[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) T::st(&tmp[j], qp[KW * ks + j] * a.scale);
+        qf[ks] = *reinterpret_cast<const uint4*>(tmp);
+      }
+    }
+    const long hbase = (long)h * a.S_max * HD;
+    const WT* kc = reinterpret_cast<const WT*>(a.kcache) + hbase;
+    const WT* vc = reinterpret_cast<const WT*>(a.vcache) + hbase;
+    const long own = (long)seq * a.cache_seq_stride;   // positions below `share` live in sequence 0's cache
+    for (int kt0 = wave * KW; kt0 <= last; kt0 += 4 * KW) {
+      // ---- requests: K fragments (B operand: lane = key kt0 + 16 sub + m, dims KW ks + EPL kg), V items
+      uint4 kf[NSUB][NKS];
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const int kp = min(kt0 + sub * 16 + m, last);
+        const WT* kr = kc + ((kp < share) ? 0 : own) + (long)kp * HD + EPL * kg;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) kf[sub][ks] = *reinterpret_cast<const uint4*>(kr + KW * ks);
+      }
+      uint4 vu[VITEMS][NPK];
+#pragma unroll
+      for (int it = 0; it < VITEMS; ++it) {
+        const int item = it * 64 + lane;
+        const int kgrp = item / (HD / EPL), dgrp = item - kgrp * (HD / EPL);
+#pragma unroll
+        for (int q = 0; q < NPK; ++q) {
+          const int kp = min(kt0 + kgrp * NPK + q, last);
+          vu[it][q] = *reinterpret_cast<const uint4*>(vc + ((kp < share) ? 0 : own) + (long)kp * HD + dgrp * EPL);
+        }
+      }
+      // ---- S = Q K^T : D[row 4 kg + r][key 16 sub + m]
+      f32x4 sc[NSUB];
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) sc[sub] = mfma_frag(qf[ks], kf[sub][ks], sc[sub], (WT*)nullptr);
+      }
+      // ---- V tile -> V^T in LDS (wave-private): word (dim, key group) = the NPK keys' values of that dim
+#pragma unroll
+      for (int it = 0; it < VITEMS; ++it) {
+        const int item = it * 64 + lane;
+        const int kgrp = item / (HD / EPL), dgrp = item - kgrp * (HD / EPL);
+        char* dst = vt + (dgrp * EPL) * VS + kgrp * 4;
+        if constexpr (NPK == 2) {
+          const uint32_t a0[4] = {vu[it][0].x, vu[it][0].y, vu[it][0].z, vu[it][0].w};
+          const uint32_t a1[4] = {vu[it][1].x, vu[it][1].y, vu[it][1].z, vu[it][1].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {                  // dims 2j, 2j+1 of both keys
+            *reinterpret_cast<uint32_t*>(dst + (2 * j) * VS) = (a0[j] & 0xffffu) | (a1[j] << 16);
+            *reinterpret_cast<uint32_t*>(dst + (2 * j + 1) * VS) = (a0[j] >> 16) | (a1[j] & 0xffff0000u);
+          }
+        } else {
+          const uint32_t a0[4] = {vu[it][0].x, vu[it][0].y, vu[it][0].z, vu[it][0].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t*>(dst + j * VS) = a0[j];
+        }
+      }
+      // ---- causal mask + online softmax (rows of a DPP row = the 16 keys of a sub-tile)
+      float p[NSUB][4], corr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qrow = 4 * kg + r;
+        const int qpos = (qrow < na) ? pos0 + qrow : -1;
+        float mx = -INFINITY;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+          const int kp = kt0 + sub * 16 + m;
+          p[sub][r] = (kp <= qpos) ? sc[sub][r] : -INFINITY;
+          mx = fmaxf(mx, p[sub][r]);
+        }
+        mx = fmaxf(mx, dpp_f<VC_DPP_QP_1032>(mx));
+        mx = fmaxf(mx, dpp_f<VC_DPP_QP_2301>(mx));
+        mx = fmaxf(mx, dpp_f<VC_DPP_ROW_HALF_MIRROR>(mx));
+        mx = fmaxf(mx, dpp_f<VC_DPP_ROW_MIRROR>(mx));
+        const float mn = fmaxf(mrun[r], mx);
+        corr[r] = (mn == -INFINITY) ? 0.f : expf(mrun[r] - mn);          // exp(-inf) = 0 on the first tile
+        float ps = 0.f;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub) {
+          p[sub][r] = (p[sub][r] == -INFINITY) ? 0.f : expf(p[sub][r] - mn);
+          ps += p[sub][r];
+        }
+        lrun[r] = lrun[r] * corr[r] + row_sum(ps);
+        mrun[r] = mn;
+      }
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) { o[dt][0] *= corr[0]; o[dt][1] *= corr[1]; o[dt][2] *= corr[2]; o[dt][3] *= corr[3]; }
+      // ---- P -> LDS as [row][key], read back as the A fragment (row m, keys EPL kg ..)
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T::st(reinterpret_cast<WT*>(pt + (4 * kg + r) * VS) + sub * 16 + m, p[sub][r]);
+      const uint4 pf = *reinterpret_cast<const uint4*>(pt + m * VS + kg * 16);
+      // ---- O += P V : D[row 4 kg + r][dim 16 dt + m]
+#pragma unroll
+      for (int dt = 0; dt < NDT; ++dt) {
+        const uint4 vf = *reinterpret_cast<const uint4*>(vt + (dt * 16 + m) * VS + kg * 16);
+        o[dt] = mfma_frag(pf, vf, o[dt], (WT*)nullptr);
+      }
+    }
+  }
+  // ---- merge the four waves' partials, normalise, store (rows past na get zeros)
+  __syncthreads();                                       // every wave is done with its V^T / P tiles
+  float* mo = reinterpret_cast<float*>(smem);            // [4 waves][16 rows][HD]
+  float* mm = mo + 4 * 16 * HD;                          // [4][16][2]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qrow = 4 * kg + r;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) mo[(wave * 16 + qrow) * HD + dt * 16 + m] = o[dt][r];
+    if (m == 0) { mm[(wave * 16 + qrow) * 2] = mrun[r]; mm[(wave * 16 + qrow) * 2 + 1] = lrun[r]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < 16 * HD; e += 256) {
+    const int qrow = e / HD, dim = e - qrow * HD;
+    if (r0 + qrow >= a.n_rows) continue;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) M = fmaxf(M, mm[(w * 16 + qrow) * 2]);
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const float mw = mm[(w * 16 + qrow) * 2];
+      const float c = (mw == -INFINITY) ? 0.f : expf(mw - M);
+      L += c * mm[(w * 16 + qrow) * 2 + 1];
+      O += c * mo[(w * 16 + qrow) * HD + dim];
+    }
+    T::st(reinterpret_cast<WT*>(a.x_out) + (long)(r0 + qrow) * a.d + h * HD + dim, (L > 0.f) ? O / L : 0.f);
+  }
+}
+
+template <typename WT, int HD>
+static hipError_t launch_tile_attn(const AttnArgs& a, hipStream_t s) {
+  constexpr int VS = WTr<WT>::KW * (int)sizeof(WT) + 16;
+  constexpr size_t wave_lds = (size_t)(HD + 16) * VS;
+  constexpr size_t merge = (size_t)(4 * 16 * HD + 4 * 16 * 2) * sizeof(float);
+  constexpr size_t lds = (4 * wave_lds > merge) ? 4 * wave_lds : merge;
+  hipLaunchKernelGGL((tile_attn_k<WT, HD>), dim3((a.n_rows + 15) / 16, a.H), dim3(256), lds, s, a);
+  return hipGetLastError();
+}
+// Prefill passes whose rows come in 16-row tiles of one sequence each (vc_engine.hip prefill_batch).
+hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s) {
+  if (!a.x_out) return hipErrorInvalidValue;
+  if (dtype == VC_DTYPE_BF16) {
+    if (a.hd == 128) return launch_tile_attn<bf16_t, 128>(a, s);
+    if (a.hd == 64) return launch_tile_attn<bf16_t, 64>(a, s);
+    if (a.hd == 32) return launch_tile_attn<bf16_t, 32>(a, s);
+  } else {
+    if (a.hd == 128) return launch_tile_attn<float, 128>(a, s);
+    if (a.hd == 64) return launch_tile_attn<float, 64>(a, s);
+    if (a.hd == 32) return launch_tile_attn<float, 32>(a, s);
+  }
+  return hipErrorInvalidValue;
+}

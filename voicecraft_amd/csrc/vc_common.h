@@ -354,6 +354,7 @@ hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ks
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);
+hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s);
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s);
 hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s);

@@ -224,6 +224,7 @@ struct RowSrc {
   int nsplit;
   const int* n_active;
   int nt;           // force the streaming-load policy (microbenchmarks)
+  int tiled;        // 1: every 16-row tile holds consecutive positions of ONE sequence (prefill_batch): MFMA attention
 };
 
 GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdim) {
@@ -389,7 +390,8 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
       if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
-      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
+      if (rs.tiled && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
+      else HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
@@ -429,13 +431,19 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
   size_t i0 = 0;
   while (i0 < pas.size()) {
     // ---- a group of prompts that fits the row arena
+    // (every prompt starts on a multiple of 16 rows, so that a 16-row tile never mixes sequences: the MFMA
+    // attention of the prefill works on such tiles; the padding rows are inactive, row_pos = -1)
     size_t i1 = i0;
     int R = 0;
-    while (i1 < pas.size() && (i1 == i0 || R + pas[i1].Lx + pas[i1].n_cols - pas[i1].skip <= e->emb_cap)) {
-      R += pas[i1].Lx + pas[i1].n_cols - pas[i1].skip;
+    auto rows_of = [](const PromptArgs& pa) { return ((pa.Lx + pa.n_cols - pa.skip) + 15) & ~15; };
+    while (i1 < pas.size() && (i1 == i0 || R + rows_of(pas[i1]) <= e->emb_cap)) {
+      R += rows_of(pas[i1]);
       ++i1;
     }
     if (R > e->emb_cap) return fail(e, VC_ECAP, "a prompt of %d rows does not fit the prefill arena of %d rows", R, e->emb_cap);
+    HIPCHK(e, hipMemsetAsync(e->pre_row_pos, 0xFF, (size_t)R * sizeof(int), s));      // -1 everywhere
+    HIPCHK(e, hipMemsetAsync(e->pre_row_seq, 0, (size_t)R * sizeof(int), s));
+    HIPCHK(e, hipMemsetAsync(e->emb, 0, (size_t)R * e->d * sizeof(float), s));
     std::vector<int> last(i1 - i0);
     int row0 = 0;
     for (size_t i = i0; i < i1; ++i) {
@@ -447,7 +455,7 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
       pa.logit_row = e->logit_row + slots[i];
       pa.logit_row_val = last[i - i0] % chunk;            // index of the prompt's last row inside its pass
       HIPCHK(e, vc_launch_prompt(pa, s));
-      row0 += rows;
+      row0 += (rows + 15) & ~15;
     }
     for (int r0 = 0; r0 < R; r0 += chunk) {
       RowSrc rs{};
@@ -455,7 +463,7 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
       rs.row_seq = e->pre_row_seq + r0; rs.row_pos = e->pre_row_pos + r0;
       rs.n_rows = std::min(chunk, R - r0);
       int rc;
-      if (rs.n_rows > VC_ROWS) { rs.nsplit = 1; rc = prefill_rows(e, rs, s); }
+      if (rs.n_rows > VC_ROWS) { rs.nsplit = 1; rs.tiled = getenv("VC_NO_TILE_ATTN") ? 0 : 1; rc = prefill_rows(e, rs, s); }
       else { rs.nsplit = attn_nsplit(e, rs.n_rows); rc = forward_rows(e, rs, s); }
       if (rc) return rc;
       for (size_t i = i0; i < i1; ++i)
