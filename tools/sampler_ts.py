@@ -18,6 +18,8 @@ for rep in range(2):
     else:
         eng.inference_tts_multi([p[0][0].cuda() for p in prompts], [p[2][0].cuda() for p in prompts], top_k=40, _seed=1)
     ts = eng.debug_read("sampler_ts", (16,), dtype=torch.int64).numpy()
-    d = np.diff(ts[:10])
-    names = ["load_state+rows->LDS", "logits_out/edits/argmax", "temperature+top-k", "exp/softmax(+top-p)", "draw", "cond+sync", "advance(thread0)", "embedding", "store_state"]
-    print("sampler stamps (shader clocks, last step):", {n: int(v) for n, v in zip(names, d)}, "total", int(ts[9] - ts[0]), flush=True)
+    idx = [0, 1, 2, 5, 6, 7, 8, 9]          # the stamps the kernel sets (vc_tokens.hip VC_TS)
+    d = np.diff(ts[idx])
+    names = ["state parked + row in LDS", "edits + arg-max", "temperature/top-k/softmax/top-p/draw", "cond + sync", "advance (thread 0)",
+             "next-row embedding", "store state"]
+    print(f"sampler stamps, sequence 0 of {B} (shader clocks, last step):", {n: int(v) for n, v in zip(names, d)}, "total", int(ts[9] - ts[0]), flush=True)

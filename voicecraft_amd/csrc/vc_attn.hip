@@ -27,7 +27,9 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
   f[6] = __uint_as_float(u.w << 16); f[7] = __uint_as_float(u.w & 0xffff0000u);
 }
 
+#ifndef VC_ATT_WAVES
 #define VC_ATT_WAVES 8
+#endif
 template <typename WT>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;
