@@ -17,7 +17,9 @@ for rep in range(2):
         eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, _seed=1)
     else:
         eng.inference_tts_multi([p[0][0].cuda() for p in prompts], [p[2][0].cuda() for p in prompts], top_k=40, _seed=1)
-    ts = eng.debug_read("sampler_ts", (16,), dtype=torch.int64).numpy()
+    ts = eng.debug_read("kernel_ts", (32,), dtype=torch.int64).numpy()
+    blk = ts[16:32].reshape(8, 2)
+    print("per-block (entry -> TS0 of block 0 is", int(ts[0] - blk[0, 0]), "clk); in-kernel clocks per block:", [int(e - s) for s, e in blk[:B]], flush=True)
     idx = [0, 1, 2, 5, 6, 7, 8, 9]          # the stamps the kernel sets (vc_tokens.hip VC_TS)
     d = np.diff(ts[idx])
     names = ["state parked + row in LDS", "edits + arg-max", "temperature/top-k/softmax/top-p/draw", "cond + sync", "advance (thread 0)",

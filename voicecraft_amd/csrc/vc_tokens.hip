@@ -574,6 +574,7 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   __shared__ SeqState s_st;
   __shared__ int s_xs[VC_MAX_CODEBOOKS + 2];
   const int b = blockIdx.x;
+  const long long t_entry = clock64();
   float v0[VC_VPL];
   preload_row(a, blockIdx.x, v0);
   const int sw = fetch_state(a, blockIdx.x);
@@ -582,6 +583,7 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
   VC_TS(0);
+  if (dy.dbg_ts && b < 8 && threadIdx.x == 0) dy.dbg_ts[16 + 2 * b] = t_entry;   // diagnosis: entry / exit clock of every block
   park_state(&s_st, sw);
   sample_phase(a, dy, blockIdx.x, &s_st, s_xs, s_dyn, v0);
   __syncthreads();
@@ -590,6 +592,7 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   VC_TS(8);
   store_state(a, blockIdx.x, &s_st);
   VC_TS(9);
+  if (dy.dbg_ts && b < 8 && threadIdx.x == 0) dy.dbg_ts[17 + 2 * b] = clock64();
 }
 __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
