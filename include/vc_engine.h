@@ -76,7 +76,10 @@ typedef struct vc_sample_cfg {
   int32_t stop_repetition;  /* <=0: silence-run penalty off                   */
   int32_t n_silence;        /* number of entries used in silence_tokens       */
   int32_t silence_tokens[VC_MAX_SILENCE];
-  uint64_t seed;            /* Philox key; stream = (seed, sequence, step, codebook) */
+  uint64_t seed;            /* Philox key; stream = (seed, sequence, step, codebook).  The draws follow the
+                             * DISTRIBUTION of topk_sampling (voicecraft.py:71-86), not torch's generator stream; ties at
+                             * the k-th value survive as in the reference; exact ties at the nucleus boundary are kept or
+                             * dropped together (the reference's sort splits them arbitrarily) */
   int32_t use_graph;        /* 1: replay the decode step as a captured hipGraph */
   int32_t poll_every;       /* host polls the done flag every N steps (0 = default 16) */
   int32_t forced_mode;      /* parity hook, meaning of forced_dev: 0 = the step's FINAL tokens (teacher forcing

@@ -111,3 +111,26 @@ def test_draws_are_seeded_and_streams_differ():
     c = debug_sample(row, 4096, top_k=40, seed=2).cpu().numpy()
     assert np.array_equal(a, b) and not np.array_equal(a, c)
     assert len(np.unique(a)) > 20                            # not one value repeated
+
+
+def test_top_k_fallback_when_one_lane_owns_many_of_the_largest():
+    """The fast top-k path keeps 5 candidates per lane (lane = index mod 64) and proves its threshold with one count
+    over the row; when a lane owns more than 5 of the k largest logits the proof fails and the full search runs.
+    Rows built to force that (6 and 9 of the top values on one lane, with ties) must still give exactly the
+    reference's kept set and distribution."""
+    from voicecraft_amd.engine import debug_sample
+    for n_same_lane, seed in ((6, 1), (9, 2)):
+        rs = np.random.RandomState(seed)
+        lg = (rs.standard_normal(V) * 0.5).astype(np.float32)
+        idx = 7 + 64 * np.arange(n_same_lane)                 # all on lane 7
+        lg[idx] = 4.0 + 0.1 * np.arange(n_same_lane)
+        lg[idx[1]] = lg[idx[0]]                               # a tie among the largest
+        row = torch.from_numpy(lg)
+        for top_k in (8, 40):
+            probs, filt = expected_probs(row, top_k, 1.0, 1.0)
+            toks = debug_sample(row.cuda(), N_DRAWS, top_k=top_k, seed=77 + top_k).cpu().numpy()
+            counts = np.bincount(toks, minlength=V)
+            support = np.isfinite(filt.numpy())
+            assert counts[~support].sum() == 0 and (counts[probs * N_DRAWS >= 30] > 0).all()
+            stat, dof = chi_square(counts, probs, N_DRAWS)
+            assert stat < stats.chi2.ppf(1 - 1e-6, dof), (n_same_lane, top_k, stat, dof)

@@ -551,8 +551,10 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 // 64-channel form once the grid is large enough).
 #define VC_BLK_M 128
 #define VC_BLK_KT 4          // k-tiles per pipeline chunk
-template <typename WT, int EPI, int NTW>
+template <typename WT, int EPI, int NTW, int WM>
 __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
+  constexpr int WN = 4 / WM;                                    // waves along the channels
+  constexpr int MT = 8 / WM;                                    // 16-row tiles per wave
   using T = WTr<WT>;
   constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;
   constexpr int SPT = 4 * TH;
@@ -566,10 +568,10 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   if (*a.n_active == 0) return;                                 // a replayed decode step after the last sequence retired
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wv >> 1, wn = wv & 1;                          // wave's row half / channel half
+  const int wm = (WM == 2) ? (wv >> 1) : 0, wn = (WM == 2) ? (wv & 1) : wv;   // wave's row part / channel part
   const int m = lane & 15, kg = lane >> 4;
   const int row_blk = blockIdx.y * VC_BLK_M;
-  const int nt0 = (blockIdx.x * 2 + wn) * NTW;                  // first weight tile of this wave
+  const int nt0 = (blockIdx.x * WN + wn) * NTW;                 // first weight tile of this wave
   const int ks = blockIdx.z;
   const int n_rows = a.n_rows;
   const int kt_blk = a.KT / (int)gridDim.z;                     // k-tiles this workgroup covers
@@ -587,11 +589,12 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   const char* xg0 = reinterpret_cast<const char*>(a.x_in) + (long)kt0 * T::KW * (long)sizeof(WT) +
                     (long)(row_blk + tid / UPR) * rstride + (tid % UPR) * 16;
   const int xl0 = (tid / UPR) * XS + (tid % UPR) * 16;
-  uint4 w0[VC_BLK_KT][NTW], w1[VC_BLK_KT][NTW], w2[NTW == 2 ? VC_BLK_KT : 1][NTW];     // the weight ring
+  constexpr bool RING3 = (WM == 2 && NTW == 2);                 // a third weight set fits the register file
+  uint4 w0[VC_BLK_KT][NTW], w1[VC_BLK_KT][NTW], w2[RING3 ? VC_BLK_KT : 1][NTW];     // the weight ring
   uint4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7;   // explicit scalars: an indexed array living across the loop is demoted to scratch
-  f32x4 acc[4][NTW];
+  f32x4 acc[MT][NTW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MT; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
@@ -618,15 +621,15 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   }
 #define VC_BLK_COMPUTE(W, buf_)                                                                  \
   {                                                                                              \
-    const char* xb_ = smem + (buf_) * (VC_BLK_M * XS) + (wm * 64 + m) * XS + kg * 16;             \
+    const char* xb_ = smem + (buf_) * (VC_BLK_M * XS) + (wm * (16 * MT) + m) * XS + kg * 16;      \
     _Pragma("unroll") for (int kt_ = 0; kt_ < VC_BLK_KT; ++kt_) {                                 \
-      uint4 xf_[4];                                                                              \
-      _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                            \
+      uint4 xf_[MT];                                                                             \
+      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                           \
         xf_[i_] = *reinterpret_cast<const uint4*>(xb_ + i_ * 16 * XS + kt_ * 64);                 \
       _Pragma("unroll") for (int j_ = 0; j_ < NTW; ++j_) {                                        \
         uint4 w_ = W[kt_][j_];                                                                   \
         if (TH < 16 && !wvalid) w_ = make_uint4(0u, 0u, 0u, 0u);                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                          \
+        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                         \
           acc[i_][j_] = mfma_frag(w_, xf_[i_], acc[i_][j_], (WT*)nullptr);                        \
       }                                                                                          \
       __builtin_amdgcn_sched_barrier(0);   /* keep the B fragments of later k-tiles out of the register file */ \
@@ -642,7 +645,7 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
     VC_BLK_PARKX((c_) + 1, 1 - (BUF))                                                            \
     __syncthreads();                                                                             \
   }
-  if constexpr (NTW == 2) {     // ring of three sets: weights two chunks ahead
+  if constexpr (RING3) {        // ring of three sets: weights two chunks ahead
     VC_BLK_LOADX(0)
     VC_BLK_LOADW(w0, 0)
     VC_BLK_LOADW(w1, 1)
@@ -682,8 +685,8 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   // ---- epilogue: lane holds channels n..n+3 of row (row tile i, m) for weight tile j
   const bool nvalid = 4 * kg < TH;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int mg = row_blk + wm * 64 + i * 16 + m;
+  for (int i = 0; i < MT; ++i) {
+    const int mg = row_blk + wm * (16 * MT) + i * 16 + m;
     if (mg >= n_rows) continue;
 #pragma unroll
     for (int j = 0; j < NTW; ++j) {
@@ -801,9 +804,10 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   return hipGetLastError();
 }
 
-template <typename WT, int EPI, int NTW>
+template <typename WT, int EPI, int NTW, int WM>
 static hipError_t launch_blk_n(const GemmArgs& a, int ksplit, hipStream_t s) {
-  auto kern = rows_gemm_blk_k<WT, EPI, NTW>;
+  auto kern = rows_gemm_blk_k<WT, EPI, NTW, WM>;
+  constexpr int WN = 4 / WM;
   constexpr size_t lds = 2 * (size_t)VC_BLK_M * (VC_BLK_KT * WTr<WT>::KW * sizeof(WT) + 16);
   static size_t granted[16] = {0};                  // per instantiation and device
   int dev = 0;
@@ -814,8 +818,8 @@ static hipError_t launch_blk_n(const GemmArgs& a, int ksplit, hipStream_t s) {
     granted[dev] = lds;
   }
   if ((a.KT / ksplit) % VC_BLK_KT != 0) return hipErrorInvalidValue;
-  if (a.n_tiles % (2 * NTW) != 0) return hipErrorInvalidValue;
-  dim3 grid(a.n_tiles / (2 * NTW), (a.n_rows + VC_BLK_M - 1) / VC_BLK_M, ksplit);
+  if (a.n_tiles % (WN * NTW) != 0) return hipErrorInvalidValue;
+  dim3 grid(a.n_tiles / (WN * NTW), (a.n_rows + VC_BLK_M - 1) / VC_BLK_M, ksplit);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
   return hipGetLastError();
 }
@@ -823,8 +827,15 @@ template <typename WT, int EPI>
 static hipError_t launch_blk_e(const GemmArgs& a, int ksplit, hipStream_t s) {
   // 128-channel tiles once they still give every CU a workgroup, else 64-channel tiles
   const long wide = (long)(a.n_tiles / 8) * ((a.n_rows + VC_BLK_M - 1) / VC_BLK_M) * ksplit;
-  if (a.n_tiles % 8 == 0 && wide >= 240) return launch_blk_n<WT, EPI, 4>(a, ksplit, s);
-  return launch_blk_n<WT, EPI, 2>(a, ksplit, s);
+  static const int form = getenv("VC_BLK_FORM") ? atoi(getenv("VC_BLK_FORM")) : 1;
+  if (a.n_tiles % 8 == 0 && wide >= 240) {
+    // 128-channel tile.  form 1: four waves side by side, each owning ALL 8 row tiles and 2 weight tiles of its own -
+    // no weight fragment is requested twice in a workgroup; form 0: 2 x 2 waves, 4 x 4 tiles each (weights requested
+    // by both row halves)
+    if (form == 1) return launch_blk_n<WT, EPI, 2, 1>(a, ksplit, s);
+    return launch_blk_n<WT, EPI, 4, 2>(a, ksplit, s);
+  }
+  return launch_blk_n<WT, EPI, 2, 2>(a, ksplit, s);
 }
 template <typename WT>
 static hipError_t launch_blk(const GemmArgs& a, int pro, int epi, int ksplit, hipStream_t s) {
