@@ -551,8 +551,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
 // 64-channel form once the grid is large enough).
 #define VC_BLK_M 128
 #define VC_BLK_KT 4          // k-tiles per pipeline chunk
-template <typename WT, int EPI, int NTW, int WM>
-__global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
+template <typename WT, int EPI, int NTW, int WM, int OCC>
+__global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
   constexpr int WN = 4 / WM;                                    // waves along the channels
   constexpr int MT = 8 / WM;                                    // 16-row tiles per wave
   using T = WTr<WT>;
@@ -589,7 +589,7 @@ __global__ __launch_bounds__(256) void rows_gemm_blk_k(const GemmArgs a) {
   const char* xg0 = reinterpret_cast<const char*>(a.x_in) + (long)kt0 * T::KW * (long)sizeof(WT) +
                     (long)(row_blk + tid / UPR) * rstride + (tid % UPR) * 16;
   const int xl0 = (tid / UPR) * XS + (tid % UPR) * 16;
-  constexpr bool RING3 = (WM == 2 && NTW == 2);                 // a third weight set fits the register file
+  constexpr bool RING3 = (WM == 2 && NTW == 2 && OCC == 1);     // a third weight set fits the register file
   uint4 w0[VC_BLK_KT][NTW], w1[VC_BLK_KT][NTW], w2[RING3 ? VC_BLK_KT : 1][NTW];     // the weight ring
   uint4 xr0, xr1, xr2, xr3, xr4, xr5, xr6, xr7;   // explicit scalars: an indexed array living across the loop is demoted to scratch
   f32x4 acc[MT][NTW];
@@ -804,9 +804,9 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   return hipGetLastError();
 }
 
-template <typename WT, int EPI, int NTW, int WM>
+template <typename WT, int EPI, int NTW, int WM, int OCC = 1>
 static hipError_t launch_blk_n(const GemmArgs& a, int ksplit, hipStream_t s) {
-  auto kern = rows_gemm_blk_k<WT, EPI, NTW, WM>;
+  auto kern = rows_gemm_blk_k<WT, EPI, NTW, WM, OCC>;
   constexpr int WN = 4 / WM;
   constexpr size_t lds = 2 * (size_t)VC_BLK_M * (VC_BLK_KT * WTr<WT>::KW * sizeof(WT) + 16);
   static size_t granted[16] = {0};                  // per instantiation and device
@@ -832,6 +832,7 @@ static hipError_t launch_blk_e(const GemmArgs& a, int ksplit, hipStream_t s) {
     // 128-channel tile.  form 1: four waves side by side, each owning ALL 8 row tiles and 2 weight tiles of its own -
     // no weight fragment is requested twice in a workgroup; form 0: 2 x 2 waves, 4 x 4 tiles each (weights requested
     // by both row halves)
+    if (form == 2) return launch_blk_n<WT, EPI, 2, 2, 2>(a, ksplit, s);   // 64-channel tiles, two workgroups per CU
     if (form == 1) return launch_blk_n<WT, EPI, 2, 1>(a, ksplit, s);
     return launch_blk_n<WT, EPI, 4, 2>(a, ksplit, s);
   }
