@@ -369,6 +369,9 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
 // multi-tile rows-GEMM (weights streamed once per pass).  Same buffers and slabs as the decode pass.
 int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
+  // prefill passes run on the block GEMM (mt = 1); decode passes of 17..64 rows (n_active set) are still weight
+  // streams: they take the weight-stationary multi-tile kernel (mt = 2), which reads every weight once at the decode rate
+  const int mtv = (rs.n_active != nullptr && rs.n_rows <= VC_MAX_SEQS && !getenv("VC_WIDE_BLK")) ? 2 : 1;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
     {
@@ -378,7 +381,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.prev_bias = (l == 0) ? ly.bo : e->layers[l - 1].b2; g.has_prev_bias = (l == 0) ? 0 : 1;
       g.x_out = e->xn;
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
-      g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = 1;
+      g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = mtv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
     }
@@ -395,7 +398,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     }
     {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
-      g.Wp = ly.Wo; g.part_out = e->parts; g.mt = 1;
+      g.Wp = ly.Wo; g.part_out = e->parts; g.mt = mtv;
       if (rs.nsplit == 1) {
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_o.ksplit, 1, s));
@@ -409,12 +412,12 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.x_out = e->xn;
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
-      g.Wp = ly.W1; g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = 1;
+      g.Wp = ly.W1; g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = mtv;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
     }
     {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
-      g.Wp = ly.W2; g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts; g.mt = 1;
+      g.Wp = ly.W2; g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts; g.mt = mtv;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     }
   }

@@ -530,6 +530,163 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   VC_KTS_FLUSH();
 }
 
+// ------------------------------------------------------------------ wide decode passes: 17..64 rows
+// (round 1's prefill kernel, kept for decode passes that carry more than one 16-row tile - 17..64 sequences: such a
+// pass is still a weight stream, and here the weights are read from HBM exactly once at the decode kernel's rate.)
+// Same weight fragments, but a workgroup holds NTW weight tiles (NTW x 4 waves) in registers and walks
+// the pass's rows in tiles of 16, so W is streamed once per 128 rows instead of once per 16, and every
+// 16-row X tile staged in LDS feeds NTW output tiles (the X traffic out of L2 - 64 KB per row tile per
+// workgroup at d = 2048 - is what bounds this kernel, not HBM).  The next row tile is requested
+// while the current one is in the MFMAs.  LayerNorm is hoisted into ln_rows_k (one block per row).
+template <typename WT, int KTW, int PRO, int EPI, int NTW>
+__global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
+  using T = WTr<WT>;
+  constexpr int NT = 256 * NTW;          // threads
+  constexpr int XP = 16 / NTW;           // X units (16 B) a thread carries for the next row tile (64 KB per workgroup)
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (*a.n_active == 0) return;          // a replayed decode step after the last sequence retired
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int g = wv >> 2, wave = wv & 3;  // weight tile of this workgroup, K quarter
+  const int nt_raw = blockIdx.x * NTW + g;
+  const bool tile_ok = nt_raw < a.n_tiles;
+  const int nt = tile_ok ? nt_raw : a.n_tiles - 1;
+  const int ks = blockIdx.y, grp = blockIdx.z;
+  const int n_rows = a.n_rows;
+  const int kt_blk = a.nchunk * 4 * KTW;
+  const int kt0 = ks * kt_blk;
+  const int kblk = kt_blk * T::KW;
+  const int k0 = kt0 * T::KW;
+  const int xs = kblk * (int)sizeof(WT) + 16;
+  char* xl = smem;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)VC_ROWS * xs) + g * 256;
+  constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;    // see rows_gemm_k
+  constexpr int SPT = 4 * TH;
+  const int m = lane & 15;
+  const int kg = lane >> 4;
+  const bool wvalid = m < TH, nvalid = 4 * kg < TH;
+  const uint4* wp = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT) * SPT + (kg * TH + min(m, TH - 1));
+  uint4 wf[KTW];
+  {
+    const int kt = kt0 + wave * KTW;
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) {
+      wf[i] = wp[(long)(kt + i) * SPT];
+      if (TH < 16 && !wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
+    }
+  }
+  const int n = nt * TH + 4 * kg;
+  const int upr = kblk * (int)sizeof(WT) / 16;       // 16-byte units per X row slice
+  const char* xsrc = reinterpret_cast<const char*>(a.x_in) + ((long)grp * a.x_group_stride + k0) * (long)sizeof(WT);
+  const long rstride = (long)a.x_ld * (long)sizeof(WT);
+  const int sh = a.x_upr_shift;
+  uint4 xq0, xq1, xq2, xq3, xq4, xq5, xq6, xq7;   // explicit scalars: an indexed array is demoted to scratch
+
+  // X tile of rows [row0, row0 + nr): global -> registers (first XP * NT units) ...
+#define VC_XQ_LOAD(j, dst)                                                                       \
+  if constexpr ((j) < XP) {                                                                      \
+    const int i_ = min((j) * NT + tid, total - 1);                                               \
+    const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                          \
+    const int u_ = i_ - r_ * upr;                                                                \
+    dst = *reinterpret_cast<const uint4*>(xsrc + (long)(row0 + r_) * rstride + (long)u_ * 16);   \
+  }
+#define VC_XQ_STORE(j, val)                                                                      \
+  if constexpr ((j) < XP) {                                                                      \
+    const int i_ = (j) * NT + tid;                                                               \
+    if (i_ < total) {                                                                            \
+      const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                        \
+      const int u_ = i_ - r_ * upr;                                                              \
+      *reinterpret_cast<uint4*>(xl + (size_t)r_ * xs + (size_t)u_ * 16) = val;                   \
+    }                                                                                            \
+  }
+  auto x_fetch = [&](int row0, int nr) {
+    if constexpr (PRO == PRO_PLAIN) {
+      const int total = nr * upr;
+      VC_XQ_LOAD(0, xq0) VC_XQ_LOAD(1, xq1) VC_XQ_LOAD(2, xq2) VC_XQ_LOAD(3, xq3)
+      VC_XQ_LOAD(4, xq4) VC_XQ_LOAD(5, xq5) VC_XQ_LOAD(6, xq6) VC_XQ_LOAD(7, xq7)
+    }
+  };
+  // ... -> LDS (plus whatever did not fit into the XP slots, copied directly)
+  auto x_park = [&](int row0, int nr) {
+    if constexpr (PRO == PRO_PLAIN) {
+      const int total = nr * upr;
+      VC_XQ_STORE(0, xq0) VC_XQ_STORE(1, xq1) VC_XQ_STORE(2, xq2) VC_XQ_STORE(3, xq3)
+      VC_XQ_STORE(4, xq4) VC_XQ_STORE(5, xq5) VC_XQ_STORE(6, xq6) VC_XQ_STORE(7, xq7)
+      for (int i = XP * NT + tid; i < total; i += NT) {
+        const int r = (sh >= 0) ? (i >> sh) : (i / upr);
+        const int u = i - r * upr;
+        *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) =
+            *reinterpret_cast<const uint4*>(xsrc + (long)(row0 + r) * rstride + (long)u * 16);
+      }
+    } else {   // PRO_ATT (short passes whose attention was split): merge the partials in place
+      const int q4 = kblk >> 2;
+      for (int idx = tid; idx < nr * q4; idx += NT) {
+        const int r = idx / q4, c = k0 + (idx - r * q4) * 4;
+        const int h = c / a.hd, e = c - h * a.hd;
+        const float2* ml = reinterpret_cast<const float2*>(a.att_ml) + (long)((row0 + r) * a.H + h) * a.nsplit;
+        const float* op = a.att_o + ((long)((row0 + r) * a.H + h) * a.nsplit) * a.hd + e;
+        float M = -INFINITY;
+        for (int sp = 0; sp < a.nsplit; ++sp) M = fmaxf(M, ml[sp].x);
+        float L = 0.f;
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < a.nsplit; ++sp) {
+          const float2 v = ml[sp];
+          const float w = (v.x == -INFINITY) ? 0.f : expf(v.x - M);
+          const float4 os = *reinterpret_cast<const float4*>(op + (long)sp * a.hd);
+          L += w * v.y;
+          o[0] += w * os.x; o[1] += w * os.y; o[2] += w * os.z; o[3] += w * os.w;
+        }
+        const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+        o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+        store4(reinterpret_cast<WT*>(xl + (size_t)r * xs) + (c - k0), o);
+      }
+    }
+  };
+
+  x_fetch(0, min(VC_ROWS, n_rows));
+  x_park(0, min(VC_ROWS, n_rows));
+  for (int row0 = 0; row0 < n_rows; row0 += VC_ROWS) {
+    const int nr = min(VC_ROWS, n_rows - row0);
+    const int row1 = row0 + VC_ROWS;
+    const int nr1 = min(VC_ROWS, n_rows - row1);
+    __syncthreads();                       // X(row0) is in LDS
+    if (nr1 > 0) x_fetch(row1, nr1);       // next tile on its way while this one is in the MFMAs
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int mrow = (m < nr) ? m : 0;
+    const char* xrow = xl + (size_t)mrow * xs + (size_t)(lane >> 4) * 16;
+    for (int c = 0; c < a.nchunk; ++c) {
+      if (a.nchunk > 1) {       // several chunks: the registers only ever hold one of them
+        const int kt = kt0 + (c * 4 + wave) * KTW;
+#pragma unroll
+        for (int i = 0; i < KTW; ++i) {
+          wf[i] = wp[(long)(kt + i) * SPT];
+          if (TH < 16 && !wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
+        }
+      }
+      const int ktl = (c * 4 + wave) * KTW;
+#pragma unroll
+      for (int i = 0; i < KTW; ++i) {
+        const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)(ktl + i) * 64);
+        acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);
+      }
+    }
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (wave == 0 && m < nr && nvalid && tile_ok) {
+      const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
+      acc = (acc + a1) + (a2 + a3);
+      float4 eb;
+      int epos, eseq;
+      epi_preload<WT, EPI>(a, row0 + m, n, grp, eb, epos, eseq);
+      gemm_epilogue<WT, EPI>(a, acc, row0 + m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
+    }
+    __syncthreads();            // x and red are rewritten for the next tile
+    if (nr1 > 0) x_park(row1, nr1);
+  }
+#undef VC_XQ_LOAD
+#undef VC_XQ_STORE
+}
+
 // ------------------------------------------------------------------ prefill: block GEMM, up to VC_MAX_ROWS rows per pass
 // out[M][N] = X[M][K] W'[N][K]^T on the MFMA for M >> 16 (prompt rows of one or several sequences).  The weights
 // keep the decode layout - they are already MFMA A fragments in HBM, so a wave loads them straight into
@@ -847,8 +1004,47 @@ static hipError_t launch_blk(const GemmArgs& a, int pro, int epi, int ksplit, hi
   return hipErrorInvalidValue;
 }
 
+template <typename WT, int KTW, int PRO, int EPI, int NTW>
+static hipError_t launch_mt_n(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  auto kern = rows_gemm_mt_k<WT, KTW, PRO, EPI, NTW>;
+  GemmArgs b = a;
+  b.r_lds = VC_ROWS;
+  {
+    const int esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
+    const int upr = (a.K / ksplit) * esz / 16;
+    b.x_upr_shift = -1;
+    for (int sft = 0; sft < 20; ++sft)
+      if ((1 << sft) == upr) b.x_upr_shift = sft;
+  }
+  const size_t lds = vc_gemm_lds_bytes(b, dtype, ksplit) + (size_t)(NTW - 1) * 4 * 64 * sizeof(f32x4);
+  if (lds > 64 * 1024) {
+    static size_t granted[16] = {0};   // per instantiation and device
+    int dev = 0;
+    hipGetDevice(&dev);
+    if (dev >= 0 && dev < 16 && lds > granted[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      granted[dev] = lds;
+    }
+  }
+  hipLaunchKernelGGL(kern, dim3((a.n_tiles + NTW - 1) / NTW, ksplit, groups), dim3(256 * NTW), lds, s, b);
+  return hipGetLastError();
+}
+
+template <typename WT, int KTW, int PRO, int EPI>
+static hipError_t launch_mt(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  if constexpr (PRO == PRO_LN) {
+    return hipErrorInvalidValue;       // multi-tile passes take their LayerNorm from ln_rows_k
+  } else {
+    // 4 weight tiles per workgroup when that still leaves >= 128 workgroups, else 2
+    if ((long)a.n_tiles * ksplit * groups >= 512) return launch_mt_n<WT, KTW, PRO, EPI, 4>(a, dtype, ksplit, groups, s);
+    return launch_mt_n<WT, KTW, PRO, EPI, 2>(a, dtype, ksplit, groups, s);
+  }
+}
+
 template <typename WT, int KTW, int PRO, int EPI>
 static hipError_t launch_one(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  if (a.mt == 2) return launch_mt<WT, KTW, PRO, EPI>(a, dtype, ksplit, groups, s);     // wide decode pass (17..64 rows)
   return launch_dec<WT, KTW, PRO, EPI>(a, dtype, ksplit, groups, s);
 }
 
@@ -883,7 +1079,7 @@ static hipError_t launch_wt(const GemmArgs& a, int dtype, int pro, int epi, int 
 
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s) {
-  if (a.mt) {     // prefill pass: block GEMM
+  if (a.mt == 1) {     // prefill pass: block GEMM
     if (groups != 1) return hipErrorInvalidValue;
     if (dtype == VC_DTYPE_BF16) return launch_blk<bf16_t>(a, pro, epi, ksplit, s);
     return launch_blk<float>(a, pro, epi, ksplit, s);
