@@ -262,17 +262,17 @@ __global__ __launch_bounds__(256) void tile_attn_k(const AttnArgs a) {
     const WT* kc = reinterpret_cast<const WT*>(a.kcache) + hbase;
     const WT* vc = reinterpret_cast<const WT*>(a.vcache) + hbase;
     const long own = (long)seq * a.cache_seq_stride;   // positions below `share` live in sequence 0's cache
-    // The K fragments and V items of the NEXT key tile of this wave are requested before the current tile is
-    // worked on (two register sets; positions past `last` are clamped, the tile itself is skipped).
-    uint4 kfA[NSUB][NKS], kfB[NSUB][NKS], vuA[VITEMS][NPK], vuB[VITEMS][NPK];
-    auto request = [&](uint4 (&kf)[NSUB][NKS], uint4 (&vu)[VITEMS][NPK], int kt0) {
+    for (int kt0 = wave * KW; kt0 <= last; kt0 += 4 * KW) {
+      // ---- requests: K fragments (B operand: lane = key kt0 + 16 sub + m, dims KW ks + EPL kg), V items
+      uint4 kf[NSUB][NKS];
 #pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {     // B operand: lane = key kt0 + 16 sub + m, dims KW ks + EPL kg
+      for (int sub = 0; sub < NSUB; ++sub) {
         const int kp = min(kt0 + sub * 16 + m, last);
         const WT* kr = kc + ((kp < share) ? 0 : own) + (long)kp * HD + EPL * kg;
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) kf[sub][ks] = *reinterpret_cast<const uint4*>(kr + KW * ks);
       }
+      uint4 vu[VITEMS][NPK];
 #pragma unroll
       for (int it = 0; it < VITEMS; ++it) {
         const int item = it * 64 + lane;
@@ -283,8 +283,6 @@ __global__ __launch_bounds__(256) void tile_attn_k(const AttnArgs a) {
           vu[it][q] = *reinterpret_cast<const uint4*>(vc + ((kp < share) ? 0 : own) + (long)kp * HD + dgrp * EPL);
         }
       }
-    };
-    auto work = [&](const uint4 (&kf)[NSUB][NKS], const uint4 (&vu)[VITEMS][NPK], int kt0) {
       // ---- S = Q K^T : D[row 4 kg + r][key 16 sub + m]
       f32x4 sc[NSUB];
 #pragma unroll
@@ -354,18 +352,6 @@ __global__ __launch_bounds__(256) void tile_attn_k(const AttnArgs a) {
       for (int dt = 0; dt < NDT; ++dt) {
         const uint4 vf = *reinterpret_cast<const uint4*>(vt + (dt * 16 + m) * VS + kg * 16);
         o[dt] = mfma_frag(pf, vf, o[dt], (WT*)nullptr);
-      }
-    };
-    int kt0 = wave * KW;
-    if (kt0 <= last) {
-      request(kfA, vuA, kt0);
-      for (;;) {
-        request(kfB, vuB, kt0 + 4 * KW);
-        work(kfA, vuA, kt0);
-        if ((kt0 += 4 * KW) > last) break;
-        request(kfA, vuA, kt0 + 4 * KW);
-        work(kfB, vuB, kt0);
-        if ((kt0 += 4 * KW) > last) break;
       }
     }
   }
