@@ -232,7 +232,7 @@ def main():
         esz = 2 if args.dtype == "bf16" else 4
         w_bytes = esz * (L * (12 * d * d + 13 * d) + 2 * d + K * (d * P + P + P * V + V))
         s_mean = args.lx + args.prompt_frames + 1 + Tg / 2
-        step_bytes = w_bytes + esz * 2 * L * d * (s_mean + 1)            # weights + KV read + KV write
+        step_bytes = w_bytes + B * esz * 2 * L * d * (s_mean + 1)        # weights (once per step) + KV read + KV write of each of the B sequences
         # dominant kernel: the FFN up-projection rows-GEMM (LayerNorm prologue, ReLU epilogue)
         mb_rows = min(B, 16)       # the kernel microbenchmarks drive the <=16-row decode kernels
         k_ms, k_bytes = eng.bench_kernel("ffn1", n_rows=mb_rows, iters=64)
