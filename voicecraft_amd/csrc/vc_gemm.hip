@@ -735,6 +735,9 @@ __global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
   const int kt0 = ks * kt_blk;
   const int nck = kt_blk / VC_BLK_KT;
   const bool wvalid = m < TH;
+  // diagnostic mask (VC_BLK_DBG, 0 in production): bit 0 = every chunk re-reads the weights of chunk 0, bit 1 = the X
+  // of chunk 0 (wrong results; tells a launch bound by the weight stream from one bound by the X traffic)
+  const int wlast = (a.att_q4_shift & 1) ? 0 : nck - 1, xlast = (a.att_q4_shift & 2) ? 0 : nck - 1;
   // weight fragments of the wave's 2 tiles: tile j is j * KT * SPT units further (n_tiles is a multiple of
   // VC_BLK_NT for every matrix of the path: d % 256 == 0)
   const uint4* wp0 = a.Wp + ((long)nt0 * a.KT + kt0) * SPT + (kg * TH + min(m, TH - 1));
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
   // (chunk indices past the end are clamped: a redundant load is cheaper than a branch around the burst)
 #define VC_BLK_LOADW(W, c_)                                                                      \
   {                                                                                              \
-    const long cw_ = (long)min((c_), nck - 1) * VC_BLK_KT * SPT;                                  \
+    const long cw_ = (long)min((c_), wlast) * VC_BLK_KT * SPT;                                    \
     _Pragma("unroll") for (int kt_ = 0; kt_ < VC_BLK_KT; ++kt_)                                   \
       _Pragma("unroll") for (int j_ = 0; j_ < NTW; ++j_) {                                        \
         W[kt_][j_] = wp0[j_ * wtile + cw_ + kt_ * SPT];                                          \
@@ -767,7 +770,7 @@ __global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
 #define VC_BLK_LX1(j_) xr##j_ = *reinterpret_cast<const uint4*>(xc_ + (long)j_ * RPJ * rstride);
 #define VC_BLK_LOADX(c_)                                                                         \
   {                                                                                              \
-    const char* xc_ = xg0 + (long)min((c_), nck - 1) * ROWB;                                      \
+    const char* xc_ = xg0 + (long)min((c_), xlast) * ROWB;                                        \
     VC_BLK_LX1(0) VC_BLK_LX1(1) VC_BLK_LX1(2) VC_BLK_LX1(3) VC_BLK_LX1(4) VC_BLK_LX1(5) VC_BLK_LX1(6) VC_BLK_LX1(7) \
   }
 #define VC_BLK_PX1(j_, buf_) *reinterpret_cast<uint4*>(smem + (buf_) * (VC_BLK_M * XS) + xl0 + j_ * RPJ * XS) = xr##j_;
@@ -776,20 +779,54 @@ __global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
     VC_BLK_PX1(0, buf_) VC_BLK_PX1(1, buf_) VC_BLK_PX1(2, buf_) VC_BLK_PX1(3, buf_)               \
     VC_BLK_PX1(4, buf_) VC_BLK_PX1(5, buf_) VC_BLK_PX1(6, buf_) VC_BLK_PX1(7, buf_)               \
   }
+  // A wave is alone on its SIMD and issues in order: whatever it issues back to back - 16 global loads (16 clocks of
+  // address path each), 32 ds_read_b128, 8 ds_write_b128 (13 clocks each), 64 MFMAs (16 clocks each) - runs back to
+  // back, and a chunk costs the SUM of the four (measured: 2 800 clocks per chunk with every load an L1/L2 hit, the
+  // MFMAs being 1 024 of them).  So the step is one scheduling region with an explicit interleave
+  // (sched_group_barrier): the first k-tile's X fragments; then per NTW MFMAs one ds_read of the NEXT k-tile's
+  // fragments (two register sets) and, during the first two k-tiles, the step's global loads (next chunk's X
+  // first, then the weights AHEAD chunks on); the last k-tile's MFMAs carry the ds_writes that park the next X.
+#define VC_BLK_LDX(dst_, kt_)                                                                    \
+  _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                               \
+    dst_[i_] = *reinterpret_cast<const uint4*>(xb_ + i_ * 16 * XS + (kt_) * 64);
+#define VC_BLK_MM(W, src_, kt_)                                                                  \
+  _Pragma("unroll") for (int j_ = 0; j_ < NTW; ++j_) {                                            \
+    uint4 w_ = W[kt_][j_];                                                                       \
+    if (TH < 16 && !wvalid) w_ = make_uint4(0u, 0u, 0u, 0u);                                     \
+    _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                             \
+      acc[i_][j_] = mfma_frag(w_, src_[i_], acc[i_][j_], (WT*)nullptr);                           \
+  }
 #define VC_BLK_COMPUTE(W, buf_)                                                                  \
   {                                                                                              \
+    static_assert(VC_BLK_KT == 4, "unrolled by hand for 4 k-tiles per chunk");                   \
     const char* xb_ = smem + (buf_) * (VC_BLK_M * XS) + (wm * (16 * MT) + m) * XS + kg * 16;      \
-    _Pragma("unroll") for (int kt_ = 0; kt_ < VC_BLK_KT; ++kt_) {                                 \
-      uint4 xf_[MT];                                                                             \
-      _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                           \
-        xf_[i_] = *reinterpret_cast<const uint4*>(xb_ + i_ * 16 * XS + kt_ * 64);                 \
-      _Pragma("unroll") for (int j_ = 0; j_ < NTW; ++j_) {                                        \
-        uint4 w_ = W[kt_][j_];                                                                   \
-        if (TH < 16 && !wvalid) w_ = make_uint4(0u, 0u, 0u, 0u);                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < MT; ++i_)                                         \
-          acc[i_][j_] = mfma_frag(w_, xf_[i_], acc[i_][j_], (WT*)nullptr);                        \
-      }                                                                                          \
-      __builtin_amdgcn_sched_barrier(0);   /* keep the B fragments of later k-tiles out of the register file */ \
+    uint4 xa_[MT], xd_[MT];                                                                      \
+    VC_BLK_LDX(xa_, 0)                                                                           \
+    VC_BLK_LDX(xd_, 1)                                                                           \
+    VC_BLK_MM(W, xa_, 0)                                                                         \
+    VC_BLK_LDX(xa_, 2)                                                                           \
+    VC_BLK_MM(W, xd_, 1)                                                                         \
+    VC_BLK_LDX(xd_, 3)                                                                           \
+    VC_BLK_MM(W, xa_, 2)                                                                         \
+    VC_BLK_MM(W, xd_, 3)                                                                         \
+  }
+  // instruction classes of sched_group_barrier: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write
+#define VC_BLK_SCHED()                                                                           \
+  {                                                                                              \
+    constexpr int VPS_ = (8 + VC_BLK_KT * NTW) / (2 * MT);   /* global loads per slot, first two k-tiles */ \
+    __builtin_amdgcn_sched_group_barrier(0x100, MT, 0);                                          \
+    _Pragma("unroll") for (int n_ = 0; n_ < 2 * MT; ++n_) {                                       \
+      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+      __builtin_amdgcn_sched_group_barrier(0x020, VPS_, 0);                                      \
+    }                                                                                            \
+    _Pragma("unroll") for (int n_ = 0; n_ < MT; ++n_) {                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                         \
+    }                                                                                            \
+    _Pragma("unroll") for (int n_ = 0; n_ < MT; ++n_) {                                           \
+      __builtin_amdgcn_sched_group_barrier(0x008, NTW, 0);                                       \
+      __builtin_amdgcn_sched_group_barrier(0x200, 8 / MT, 0);                                    \
     }                                                                                            \
   }
   // one pipeline step: chunk c is computed from ring slot WC / LDS buffer BUF, chunk c+1's X and chunk c+2's
@@ -800,6 +837,7 @@ __global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
     VC_BLK_LOADW(WN, (c_) + (AHEAD))                                                             \
     VC_BLK_COMPUTE(WC, BUF)                                                                      \
     VC_BLK_PARKX((c_) + 1, 1 - (BUF))                                                            \
+    VC_BLK_SCHED()                                                                               \
     __syncthreads();                                                                             \
   }
   if constexpr (RING3) {        // ring of three sets: weights two chunks ahead
@@ -839,6 +877,9 @@ __global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
 #undef VC_BLK_LX1
 #undef VC_BLK_PX1
 #undef VC_BLK_COMPUTE
+#undef VC_BLK_LDX
+#undef VC_BLK_MM
+#undef VC_BLK_SCHED
   // ---- epilogue: lane holds channels n..n+3 of row (row tile i, m) for weight tile j
   const bool nvalid = 4 * kg < TH;
 #pragma unroll
@@ -977,7 +1018,11 @@ static hipError_t launch_blk_n(const GemmArgs& a, int ksplit, hipStream_t s) {
   if ((a.KT / ksplit) % VC_BLK_KT != 0) return hipErrorInvalidValue;
   if (a.n_tiles % (WN * NTW) != 0) return hipErrorInvalidValue;
   dim3 grid(a.n_tiles / (WN * NTW), (a.n_rows + VC_BLK_M - 1) / VC_BLK_M, ksplit);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+  const char* dbg_env = getenv("VC_BLK_DBG");            // read per launch: tools/blk_probe.py flips it inside one process
+  const int dbg = dbg_env ? atoi(dbg_env) : 0;
+  GemmArgs b = a;
+  b.att_q4_shift = dbg;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
   return hipGetLastError();
 }
 template <typename WT, int EPI>
