@@ -17,8 +17,12 @@ for rep in range(2):
         eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, _seed=1)
     else:
         eng.inference_tts_multi([p[0][0].cuda() for p in prompts], [p[2][0].cuda() for p in prompts], top_k=40, _seed=1)
-    ts = eng.debug_read("kernel_ts", (32,), dtype=torch.int64).numpy()
+    ts = eng.debug_read("kernel_ts", (64,), dtype=torch.int64).numpy()
     blk = ts[16:32].reshape(8, 2)
+    wall = ts[32:48].reshape(8, 2)[:B]          # 100 MHz chip-wide counter: entry / exit of every block
+    w0 = wall[:, 0].min()
+    print("wall clock, us after the first block's entry: entries", [round((int(v) - int(w0)) / 100.0, 2) for v in wall[:, 0]],
+          "exits", [round((int(v) - int(w0)) / 100.0, 2) for v in wall[:, 1]], flush=True)
     print("per-block (entry -> TS0 of block 0 is", int(ts[0] - blk[0, 0]), "clk); in-kernel clocks per block:", [int(e - s) for s, e in blk[:B]], flush=True)
     idx = [0, 1, 2, 5, 6, 7, 8, 9]          # the stamps the kernel sets (vc_tokens.hip VC_TS)
     d = np.diff(ts[idx])

@@ -860,8 +860,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->samp, (size_t)e->NS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->amax, (size_t)e->NS))) return rc;
-  if ((rc = dalloc(e, &e->dbg_ts, (size_t)32))) return rc;
-  HIPCHK(e, hipMemset(e->dbg_ts, 0, 32 * 8));
+  if ((rc = dalloc(e, &e->dbg_ts, (size_t)64))) return rc;
+  HIPCHK(e, hipMemset(e->dbg_ts, 0, 64 * 8));
   e->gen_cap = e->S_max;
   if ((rc = dalloc(e, &e->gen, (size_t)e->B_max * e->gen_cap * K))) return rc;
   HIPCHK(e, hipMemset(e->err_flag, 0, 16));
@@ -1192,7 +1192,7 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "vcache0") { src = e->layers[0].vc; avail = (int64_t)e->B_max * e->H * e->S_max * e->hd * e->esz; }
   else if (n == "pe") { src = e->pe; avail = (int64_t)e->S_max * e->d * 4; }
   else if (n == "sampler_ts") { src = e->dbg_ts; avail = 16 * 8; }
-  else if (n == "kernel_ts") { src = e->dbg_ts; avail = 32 * 8; }
+  else if (n == "kernel_ts") { src = e->dbg_ts; avail = 64 * 8; }
   else if (n == "host_ms") { host_src = e->host_ms; avail = 8 * 8; }
   else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
   if (nbytes > avail) return fail(e, VC_ECAP, "debug buffer '%s' holds %lld bytes", n.c_str(), (long long)avail);

@@ -583,7 +583,10 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
   VC_TS(0);
-  if (dy.dbg_ts && b < 8 && threadIdx.x == 0) dy.dbg_ts[16 + 2 * b] = t_entry;   // diagnosis: entry / exit clock of every block
+  if (dy.dbg_ts && b < 8 && threadIdx.x == 0) {   // diagnosis: entry / exit clock of every block
+    dy.dbg_ts[16 + 2 * b] = t_entry;
+    dy.dbg_ts[32 + 2 * b] = wall_clock64();       // 100 MHz, one counter for the whole chip (clock64 is per XCD); read
+  }                                               // after the state fetch (~1.3 us in), only when stamps are requested
   park_state(&s_st, sw);
   sample_phase(a, dy, blockIdx.x, &s_st, s_xs, s_dyn, v0);
   __syncthreads();
@@ -592,7 +595,10 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   VC_TS(8);
   store_state(a, blockIdx.x, &s_st);
   VC_TS(9);
-  if (dy.dbg_ts && b < 8 && threadIdx.x == 0) dy.dbg_ts[17 + 2 * b] = clock64();
+  if (dy.dbg_ts && b < 8 && threadIdx.x == 0) {
+    dy.dbg_ts[17 + 2 * b] = clock64();
+    dy.dbg_ts[33 + 2 * b] = wall_clock64();
+  }
 }
 __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
