@@ -24,6 +24,11 @@ for rep in range(2):
     print("wall clock, us after the first block's entry: entries", [round((int(v) - int(w0)) / 100.0, 2) for v in wall[:, 0]],
           "exits", [round((int(v) - int(w0)) / 100.0, 2) for v in wall[:, 1]], flush=True)
     print("per-block (entry -> TS0 of block 0 is", int(ts[0] - blk[0, 0]), "clk); in-kernel clocks per block:", [int(e - s) for s, e in blk[:B]], flush=True)
+    acc = ts[48:59]
+    if acc[8] > 0:
+        nm = ["state parked + row in LDS", "edits + arg-max", "filter + draw", "cond + sync", "advance (thread 0)", "next-row embedding", "store state"]
+        print(f"MEAN over {int(acc[8])} steps of this and earlier calls, block 0 (shader clocks):", {n: int(v / acc[8]) for n, v in zip(nm, acc[:7])},
+              "entry->exit", int(acc[7] / acc[8]), "| last block entry->exit", int(acc[9] / max(1, acc[10])), flush=True)
     idx = [0, 1, 2, 5, 6, 7, 8, 9]          # the stamps the kernel sets (vc_tokens.hip VC_TS)
     d = np.diff(ts[idx])
     names = ["state parked + row in LDS", "edits + arg-max", "temperature/top-k/softmax/top-p/draw", "cond + sync", "advance (thread 0)",

@@ -596,8 +596,24 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   store_state(a, blockIdx.x, &s_st);
   VC_TS(9);
   if (dy.dbg_ts && b < 8 && threadIdx.x == 0) {
-    dy.dbg_ts[17 + 2 * b] = clock64();
+    const long long t_exit = clock64();
+    dy.dbg_ts[17 + 2 * b] = t_exit;
     dy.dbg_ts[33 + 2 * b] = wall_clock64();
+    // sums over ALL steps of a call (the stamps above keep the last step only): slots 48..54 = the seven phase
+    // deltas of block 0 (stamps 0,1,2,5,6,7,8,9), 55 = block 0 entry -> exit, 56 = steps summed, 57 = the same
+    // total for the last block, 58 = its steps.  Steps whose block took the early exits are left out.
+    long long* acc = dy.dbg_ts + 48;
+    if (b == 0) {
+      const int idx[8] = {0, 1, 2, 5, 6, 7, 8, 9};
+      bool ok = true;
+      for (int i = 0; i < 7; ++i) ok = ok && dy.dbg_ts[idx[i + 1]] >= dy.dbg_ts[idx[i]] && dy.dbg_ts[idx[i]] >= t_entry;
+      if (ok) {
+        for (int i = 0; i < 7; ++i) acc[i] += dy.dbg_ts[idx[i + 1]] - dy.dbg_ts[idx[i]];
+        acc[7] += t_exit - t_entry;
+        acc[8] += 1;
+      }
+    }
+    if (b == (int)gridDim.x - 1) { acc[9] += t_exit - t_entry; acc[10] += 1; }
   }
 }
 __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
