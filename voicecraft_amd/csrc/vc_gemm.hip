@@ -696,11 +696,14 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
 //                registers, so two workgroups share a CU (one in the MFMAs while the other waits for memory)
 //   wave       = 4 row tiles x 2 weight tiles: per k-tile 2 A fragments (global) + 4 B fragments (ds_read_b128)
 //                feed 8 MFMAs
-//   K pipeline = chunks of 4 k-tiles.  Weight fragments run through a ring of THREE register sets, i.e. they are
-//                requested two chunks (16 KB per wave) ahead of their MFMAs - at a few hundred rows the pass is as
-//                much a weight stream (HBM) as a GEMM.  X rows of the next chunk (8 x 16 B per thread) are requested
-//                BEFORE that chunk's weights (a wave's loads return in order: waiting for X must not drain the
-//                weight ring) and parked in the other LDS buffer behind the barrier.
+//   K pipeline = chunks of 4 k-tiles.  Weight fragments run through a ring of register sets (three on the 2 x 2 form:
+//                requested two chunks = 16 KB per wave ahead of their MFMAs; two on the side-by-side form, whose
+//                register file holds no third) - at a few hundred rows the pass is as much a weight stream (HBM) as
+//                a GEMM.  X rows of the next chunk (8 x 16 B per thread) are requested BEFORE that chunk's weights
+//                (a wave's loads return in order: waiting for X must not drain the weight ring) and parked in the
+//                other LDS buffer during the chunk's last k-tile.  Inside a chunk the four instruction classes are
+//                interleaved explicitly (VC_BLK_SCHED below): one wave per SIMD issues in order, so anything
+//                issued back to back also RUNS back to back.
 // LDS: 2 x 128 rows x (256 B + 16 B pad) = 68 KB; the pad rotates rows by 4 banks.  Epilogues are the decode ones
 // (bias/ReLU, split-K slab, QKV with the cache scatter), LayerNorm comes from ln_rows_k + the folded weights.
 // NTW = weight tiles per wave: 2 (64-channel workgroup tile, enough workgroups for one short prompt) or 4 (128
