@@ -778,7 +778,6 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
   float* seq[2] = {c->HS0, c->HS1};
   if (L.layers == 2 && H % 256 == 0 && H <= 1024 && !getenv("VC_LSTM_SEQUENTIAL")) {
     // two-layer wavefront: T + 1 launches (lstm_wave_k)
-    int Lo;
     int rc = run_conv1x1(c, L.Wih[0], x, T, c->G, s, B);                          // layer 0: G = x W_ih^T + b_ih + b_hh
     if (rc) return rc;
     CCHK(c, hipMemsetAsync(c->cstate, 0, (size_t)2 * B * H * 4, s));
@@ -851,14 +850,14 @@ extern "C" int vc_codec_create(const vc_codec_cfg* cfg, int hip_device, vc_codec
 
 extern "C" void vc_codec_destroy(vc_codec* c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  hipDeviceSynchronize();
-  for (auto& kv : c->raw) if (kv.second.second) hipFree(kv.second.second);
-  for (void* p : c->allocs) hipFree(p);
-  if (c->h_flag) hipHostFree(c->h_flag);
-  for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
-  for (auto& ev : c->ev_l) if (ev) hipEventDestroy(ev);
-  if (c->own_stream) hipStreamDestroy(c->own_stream);
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : c->raw) if (kv.second.second) (void)hipFree(kv.second.second);
+  for (void* p : c->allocs) (void)hipFree(p);
+  if (c->h_flag) (void)hipHostFree(c->h_flag);
+  for (auto& ev : c->ev) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : c->ev_l) if (ev) (void)hipEventDestroy(ev);
+  if (c->own_stream) (void)hipStreamDestroy(c->own_stream);
   delete c;
 }
 
@@ -872,7 +871,7 @@ extern "C" int vc_codec_load_tensor(vc_codec* c, const char* key, const void* da
   for (auto v : sh) n *= v;
   if (n <= 0) return cfail(c, VC_EINVAL, "empty tensor '%s'", key);
   auto it = c->raw.find(key);
-  if (it != c->raw.end()) { hipFree(it->second.second); c->raw.erase(it); }
+  if (it != c->raw.end()) { (void)hipFree(it->second.second); c->raw.erase(it); }
   float* d = nullptr;
   CCHK(c, hipMalloc((void**)&d, (size_t)n * 4));
   CCHK(c, hipMemcpy(d, data, (size_t)n * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
@@ -1081,7 +1080,7 @@ extern "C" int vc_codec_decode_batch(vc_codec* c, const int64_t* codes_dev, int 
   CCHK(c, hipStreamSynchronize(s));
   CCHK(c, hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
   if (*c->h_flag) {
-    hipMemset(c->err_flag, 0, 4);
+    (void)hipMemset(c->err_flag, 0, 4);   // already on the error path
     return cfail(c, VC_EINVAL, "code index outside [0, %d)", g.codebook_size);
   }
   return VC_OK;

@@ -352,6 +352,7 @@ hipError_t vc_launch_fold_vecs(const float* W, const float* gamma, const float* 
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s);
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
+extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);
 hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s);

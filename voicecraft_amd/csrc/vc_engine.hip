@@ -564,11 +564,11 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
       int rc = VC_OK;
       for (int i = 0; i < G && rc == VC_OK; ++i) rc = decode_step(e, sa, B, rps, grouped, s);
       hipError_t ce = hipStreamEndCapture(s, &graph);
-      if (rc) { if (graph) hipGraphDestroy(graph); return rc; }
+      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
       HIPCHK(e, ce);
       e->host_ms[1] = now_ms() - t0;
       hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      hipGraphDestroy(graph);
+      (void)hipGraphDestroy(graph);
       if (ie != hipSuccess) return fail(e, VC_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
       e->host_ms[2] = now_ms() - t0 - e->host_ms[1];
       e->graphs[key] = exec;
@@ -632,7 +632,7 @@ int check_err_flag(vc_engine* e, hipStream_t s) {
   HIPCHK(e, hipMemcpyAsync(e->h_flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
   if (*e->h_flag) {
-    hipMemsetAsync(e->err_flag, 0, sizeof(int), s);
+    (void)hipMemsetAsync(e->err_flag, 0, sizeof(int), s);   // already on the error path
     return fail(e, VC_EINVAL, "token id out of range in x or y (text rows %d, audio vocab %d)", e->cfg.text_rows, e->V);
   }
   return VC_OK;
@@ -679,17 +679,17 @@ extern "C" int vc_create(const vc_model_cfg* c, int hip_device, vc_engine** out)
 
 extern "C" void vc_destroy(vc_engine* e) {
   if (!e) return;
-  hipSetDevice(e->device);
-  hipDeviceSynchronize();
-  for (auto& kv : e->raw) if (kv.second.dev) hipFree(kv.second.dev);
-  for (void* p : e->allocs) hipFree(p);
-  if (e->h_st) hipHostFree(e->h_st);
-  if (e->h_flag) hipHostFree(e->h_flag);
-  if (e->h_dyn) hipHostFree(e->h_dyn);
-  for (auto& kv : e->graphs) if (kv.second) hipGraphExecDestroy(kv.second);
-  for (auto& ev : e->ev_pace) if (ev) hipEventDestroy(ev);
-  for (auto& ev : e->ev) if (ev) hipEventDestroy(ev);
-  if (e->own_stream) hipStreamDestroy(e->own_stream);
+  (void)hipSetDevice(e->device);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : e->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->h_st) (void)hipHostFree(e->h_st);
+  if (e->h_flag) (void)hipHostFree(e->h_flag);
+  if (e->h_dyn) (void)hipHostFree(e->h_dyn);
+  for (auto& kv : e->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
+  for (auto& ev : e->ev_pace) if (ev) (void)hipEventDestroy(ev);
+  for (auto& ev : e->ev) if (ev) (void)hipEventDestroy(ev);
+  if (e->own_stream) (void)hipStreamDestroy(e->own_stream);
   delete e;
 }
 
@@ -704,7 +704,7 @@ extern "C" int vc_load_tensor(vc_engine* e, const char* key, const void* data, i
   for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); t.numel *= shape[i]; }
   if (t.numel <= 0) return fail(e, VC_EINVAL, "empty tensor '%s'", key);
   auto it = e->raw.find(key);
-  if (it != e->raw.end()) { hipFree(it->second.dev); e->raw.erase(it); }
+  if (it != e->raw.end()) { (void)hipFree(it->second.dev); e->raw.erase(it); }
   HIPCHK(e, hipMalloc((void**)&t.dev, (size_t)t.numel * 4));
   HIPCHK(e, hipMemcpy(t.dev, data, (size_t)t.numel * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice));
   e->raw[key] = t;
@@ -777,7 +777,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     // free the staging copies of this layer right away (3.3 GB for the 830M shape otherwise)
     for (const char* k2 : {"self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"}) {
       auto it = e->raw.find(pre + k2);
-      if (it != e->raw.end()) { hipDeviceSynchronize(); hipFree(it->second.dev); e->raw.erase(it); }
+      if (it != e->raw.end()) { HIPCHK(e, hipDeviceSynchronize()); (void)hipFree(it->second.dev); e->raw.erase(it); }
     }
   }
   // ---- heads: first linears concatenated to one [K*P][d] matrix, second ones one group each
@@ -788,16 +788,16 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if ((rc = need(e, "decoder.norm.weight", {d}, &tg))) return rc;
     if ((rc = need(e, "decoder.norm.bias", {d}, &tbe))) return rc;
     HIPCHK(e, hipMalloc((void**)&cat, (size_t)K * P * d * 4));
-    if (hipMalloc((void**)&bcat, (size_t)K * P * 4) != hipSuccess) { hipFree(cat); return fail(e, VC_EHIP, "hipMalloc failed"); }
-    auto drop = [&]() { hipDeviceSynchronize(); hipFree(cat); hipFree(bcat); };
+    if (hipMalloc((void**)&bcat, (size_t)K * P * 4) != hipSuccess) { (void)hipFree(cat); return fail(e, VC_EHIP, "hipMalloc failed"); }
+    auto drop = [&]() { (void)hipDeviceSynchronize(); (void)hipFree(cat); (void)hipFree(bcat); };
     if ((rc = dalloc(e, &e->bh1, (size_t)K * P))) { drop(); return rc; }
     if ((rc = dalloc(e, &e->wg_h1, (size_t)K * P))) { drop(); return rc; }
     for (int k = 0; k < K; ++k) {
       const std::string pre = "predict_layer." + std::to_string(k) + ".";
       if ((rc = need(e, pre + "0.weight", {P, d}, &t))) { drop(); return rc; }
-      hipMemcpy(cat + (size_t)k * P * d, t->dev, (size_t)P * d * 4, hipMemcpyDeviceToDevice);
+      if (hipMemcpy(cat + (size_t)k * P * d, t->dev, (size_t)P * d * 4, hipMemcpyDeviceToDevice) != hipSuccess) { drop(); return fail(e, VC_EHIP, "hipMemcpy of %s0.weight failed", pre.c_str()); }
       if ((rc = need(e, pre + "0.bias", {P}, &t))) { drop(); return rc; }
-      hipMemcpy(bcat + (size_t)k * P, t->dev, (size_t)P * 4, hipMemcpyDeviceToDevice);
+      if (hipMemcpy(bcat + (size_t)k * P, t->dev, (size_t)P * 4, hipMemcpyDeviceToDevice) != hipSuccess) { drop(); return fail(e, VC_EHIP, "hipMemcpy of %s0.bias failed", pre.c_str()); }
     }
     const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
     const long units = (long)(K * P / 16) * (d / KW) * 64;
@@ -819,7 +819,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     }
   }
   HIPCHK(e, hipDeviceSynchronize());
-  for (auto& kv : e->raw) if (kv.second.dev) hipFree(kv.second.dev);
+  for (auto& kv : e->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
   e->raw.clear();
   // ---- launch plans
   e->p_qkv = make_plan(3 * d, d, e->dtype, false, nullptr, VC_TH_QKV);
@@ -1278,7 +1278,11 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     } else if (w == "pf_ffn1") {      // the prefill pass's FFN up-projection on the MFMA block GEMM (X = xn, n_rows rows)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = 1;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
+      const char* dbg_env = getenv("VC_BLK_DBG");        // tools/blk_probe.py: wrong results by design, timing only
+      vc_blk_dbg_mask = dbg_env ? atoi(dbg_env) : 0;
+      hipError_t le = vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s);
+      vc_blk_dbg_mask = 0;
+      HIPCHK(e, le);
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);
       if (r) return r;

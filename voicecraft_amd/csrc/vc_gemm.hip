@@ -709,6 +709,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
 // NTW = weight tiles per wave: 2 (64-channel workgroup tile, enough workgroups for one short prompt) or 4 (128
 // channels: each X byte staged in LDS feeds twice as many MFMAs - the L2->LDS traffic of X is what bounds the
 // 64-channel form once the grid is large enough).
+int vc_blk_dbg_mask = 0;     // diagnostic mask of the block GEMM (see the kernel); only the kernel microbenchmark sets it
 #define VC_BLK_M 128
 #define VC_BLK_KT 4          // k-tiles per pipeline chunk
 template <typename WT, int EPI, int NTW, int WM, int OCC>
@@ -981,7 +982,7 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   if (lds > 64 * 1024) {
     static size_t granted[16] = {0};   // per instantiation and device
     int dev = 0;
-    hipGetDevice(&dev);
+    if (hipError_t ge = hipGetDevice(&dev); ge != hipSuccess) return ge;
     if (dev >= 0 && dev < 16 && lds > granted[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1012,7 +1013,7 @@ static hipError_t launch_blk_n(const GemmArgs& a, int ksplit, hipStream_t s) {
   constexpr size_t lds = 2 * (size_t)VC_BLK_M * (VC_BLK_KT * WTr<WT>::KW * sizeof(WT) + 16);
   static size_t granted[16] = {0};                  // per instantiation and device
   int dev = 0;
-  hipGetDevice(&dev);
+  if (hipError_t ge = hipGetDevice(&dev); ge != hipSuccess) return ge;
   if (dev >= 0 && dev < 16 && granted[dev] < lds) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -1021,10 +1022,8 @@ static hipError_t launch_blk_n(const GemmArgs& a, int ksplit, hipStream_t s) {
   if ((a.KT / ksplit) % VC_BLK_KT != 0) return hipErrorInvalidValue;
   if (a.n_tiles % (WN * NTW) != 0) return hipErrorInvalidValue;
   dim3 grid(a.n_tiles / (WN * NTW), (a.n_rows + VC_BLK_M - 1) / VC_BLK_M, ksplit);
-  const char* dbg_env = getenv("VC_BLK_DBG");            // read per launch: tools/blk_probe.py flips it inside one process
-  const int dbg = dbg_env ? atoi(dbg_env) : 0;
   GemmArgs b = a;
-  b.att_q4_shift = dbg;
+  b.att_q4_shift = vc_blk_dbg_mask;                     // 0 except inside vc_bench_kernel("pf_ffn1") under VC_BLK_DBG
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
   return hipGetLastError();
 }
@@ -1068,7 +1067,7 @@ static hipError_t launch_mt_n(const GemmArgs& a, int dtype, int ksplit, int grou
   if (lds > 64 * 1024) {
     static size_t granted[16] = {0};   // per instantiation and device
     int dev = 0;
-    hipGetDevice(&dev);
+    if (hipError_t ge = hipGetDevice(&dev); ge != hipSuccess) return ge;
     if (dev >= 0 && dev < 16 && lds > granted[dev]) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
