@@ -1,0 +1,35 @@
+"""Validates and times the EXPERIMENTAL persistent LSTM (VC_LSTM_PERSIST=1, lstm_persist_k) against the default
+two-layer wavefront (lstm_wave_k): codes and waveform must be bit-identical (same arithmetic, same order).
+Run under a short `timeout`: every hand-off wait in the kernel is bounded, but this path has not seen hardware yet.
+usage: timeout 120 python tools/lstm_probe.py [batch]"""
+import os, sys
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from voicecraft_amd import synth
+from voicecraft_amd.codec import AudioTokenizer
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+sd = synth.make_codec_state_dict(0)
+tok = AudioTokenizer(sd, device="cuda:0", max_seconds=17.0, max_batch=B)
+torch.manual_seed(0)
+res = {}
+for secs in (1, 16):
+    wav = (torch.randn(B, 1, 16000 * secs) * 0.1).cuda()
+    for mode in ("wave", "persist"):
+        if mode == "persist":
+            os.environ["VC_LSTM_PERSIST"] = "1"
+        else:
+            os.environ.pop("VC_LSTM_PERSIST", None)
+        for _ in range(2):
+            codes = tok.encode(wav)[0][0]
+        enc_ms = tok.last_ms()
+        lstm_ms, _ = tok.last_lstm_ms()
+        for _ in range(2):
+            back = tok.decode([(codes, None)])
+        dec_ms = tok.last_ms()
+        res[(secs, mode)] = (codes.cpu(), back.cpu())
+        print(f"[lstm] {secs:2d} s x {B}: {mode:7s} encode {enc_ms:7.2f} ms (LSTM part {lstm_ms:6.2f} ms), decode {dec_ms:7.2f} ms", flush=True)
+    same_codes = bool((res[(secs, "wave")][0] == res[(secs, "persist")][0]).all())
+    same_wav = bool((res[(secs, "wave")][1] == res[(secs, "persist")][1]).all())
+    print(f"[lstm] {secs:2d} s x {B}: codes identical {same_codes}, waveform bit-identical {same_wav}", flush=True)
+os.environ.pop("VC_LSTM_PERSIST", None)

@@ -360,6 +360,144 @@ __global__ __launch_bounds__(256) void lstm_wave_k(const LstmWaveArgs a) {
   }
 }
 
+// ---- EXPERIMENTAL (VC_LSTM_PERSIST=1, off by default; not yet validated on hardware): the same recurrence as ONE
+// persistent cooperative launch.  Every wave keeps its unit's gate rows (16 KB of W_hh, layer 1 also 16 KB of W_ih) in
+// registers for the whole sequence instead of re-reading 48 MB of weights per step, and hidden values travel between
+// workgroups as 8-byte granules {h bits, epoch} written and read with ONE relaxed agent-scope atomic each (value and
+// tag cannot tear and need no fence; MI355X_MICROARCH "data-tagged hand-off").  A granule is valid when its tag equals
+// the call's epoch, so nothing is cleared between calls.  The arithmetic (order of every sum) is lstm_wave_k's: results
+// must be bit-identical.  Launched cooperatively (all 2 x H/4 workgroups resident: a wait can only be for a
+// workgroup that is running); every wait is bounded and raises err instead of hanging.
+struct LstmPersistArgs {
+  const float* Whh[2];
+  const float* Wih1;
+  const float* b1;
+  const float* G0;
+  unsigned long long* hg[2];   // [B][T][H] granules of the two hidden sequences
+  float* c[2];                 // [B][H] cell states (private to the wave that owns the unit)
+  const float* skip;
+  float* out_raw;
+  float* out_elu;
+  int H, T, B;
+  unsigned epoch;              // != 0, differs from call to call
+  int* err;
+};
+#define VC_LSTM_SPIN_LIMIT 400000
+template <int NQ>
+__device__ __forceinline__ bool lstm_poll(const unsigned long long* g, unsigned epoch, int lane, float4 (&hv)[NQ]) {
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+    const unsigned long long* p = g + 4 * (lane + 64 * j);
+    const unsigned long long a0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long a1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long a2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long a3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    ok = ok && (unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch && (unsigned)(a2 >> 32) == epoch &&
+         (unsigned)(a3 >> 32) == epoch;
+    hv[j] = make_float4(__uint_as_float((unsigned)a0), __uint_as_float((unsigned)a1), __uint_as_float((unsigned)a2),
+                        __uint_as_float((unsigned)a3));
+  }
+  return ok;
+}
+// waits (bounded) until every granule of one hidden vector carries the epoch; false = gave up
+template <int NQ>
+__device__ __forceinline__ bool lstm_wait(const unsigned long long* g, unsigned epoch, int lane, float4 (&hv)[NQ], int* err) {
+  for (int spins = 0; spins < VC_LSTM_SPIN_LIMIT; ++spins) {
+    const bool ok = lstm_poll<NQ>(g, epoch, lane, hv);
+    if (__all(ok)) return true;
+    __builtin_amdgcn_s_sleep(1);
+  }
+  if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return false;
+}
+template <int NQ>   // H = 256 * NQ
+__global__ __launch_bounds__(256, 2) void lstm_persist_k(const LstmPersistArgs a) {
+  const int n = blockIdx.y;
+  const int H = a.H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x * 4 + wave;                   // hidden unit (grid.x = H / 4)
+  const int nq = H >> 2;
+  const long TH = (long)a.T * H;
+  const float4* whh = reinterpret_cast<const float4*>(a.Whh[n] + (long)(4 * u) * H);
+  float4 w[4][NQ], wi[4][NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w[g][j] = whh[(long)g * nq + lane + 64 * j];
+  }
+  float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n == 1) {
+    const float4* wih = reinterpret_cast<const float4*>(a.Wih1 + (long)(4 * u) * H);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wi[g][j] = wih[(long)g * nq + lane + 64 * j];
+    }
+    gb = *reinterpret_cast<const float4*>(a.b1 + 4 * u);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wi[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  for (int t = 0; t < a.T; ++t) {
+    for (int b = 0; b < a.B; ++b) {
+      float4 hv[NQ], xv[NQ];
+      if (t) {
+        if (!lstm_wait<NQ>(a.hg[n] + b * TH + (long)(t - 1) * H, a.epoch, lane, hv, a.err)) return;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j) hv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float4 gi = gb;
+      if (n == 0) {
+        gi = *reinterpret_cast<const float4*>(a.G0 + (b * (long)a.T + t) * 4 * H + 4 * u);
+      } else {
+        if (!lstm_wait<NQ>(a.hg[0] + b * TH + (long)t * H, a.epoch, lane, xv, a.err)) return;
+      }
+      const float c_prev = t ? a.c[n][(long)b * H + u] : 0.f;
+      const float sk = (n == 1 && a.skip) ? a.skip[b * TH + (long)t * H + u] : 0.f;
+      float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+          g4[g] += (w[g][j].x * hv[j].x + w[g][j].y * hv[j].y) + (w[g][j].z * hv[j].z + w[g][j].w * hv[j].w);
+      }
+      if (n == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < NQ; ++j)
+            acc += (wi[g][j].x * xv[j].x + wi[g][j].y * xv[j].y) + (wi[g][j].z * xv[j].z + wi[g][j].w * xv[j].w);
+          g4[g] += acc;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
+      if (lane == 0) {
+        const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
+        const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
+        const float gg = tanhf(g4[2] + gi.z);
+        const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
+        const float c = fg * c_prev + ig * gg;
+        const float h = og * tanhf(c);
+        a.c[n][(long)b * H + u] = c;
+        __hip_atomic_store(a.hg[n] + b * TH + (long)t * H + u, ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(h),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == 1 && a.skip) {
+          const float y = h + sk;
+          if (a.out_raw) a.out_raw[b * TH + (long)t * H + u] = y;
+          if (a.out_elu) a.out_elu[b * TH + (long)t * H + u] = elu1(y);
+        }
+      }
+    }
+  }
+}
+
 // ---- residual VQ (EncodecResidualVectorQuantizer.encode/.decode).  One block per frame.
 // dist = -(|r|^2 - 2 r.e + |e|^2), arg-max with the lowest index on ties (torch.max), residual update.
 __global__ __launch_bounds__(256) void rvq_encode_k(const float* __restrict__ z, const float* __restrict__ Et,
@@ -575,6 +713,9 @@ struct vc_codec {
   float *A_raw = nullptr, *C_raw = nullptr, *S_raw = nullptr, *A_elu = nullptr, *B_elu = nullptr, *H_elu = nullptr, *latent = nullptr;
   int B_max = 1;
   float *G = nullptr, *HS0 = nullptr, *HS1 = nullptr, *cstate = nullptr, *hzero = nullptr;
+  unsigned long long* hgran = nullptr;   // experimental persistent LSTM: 2 x [B_max][T_max][H] granules, allocated on first use
+  unsigned lstm_epoch = 0;
+  int persist_ok = -1;                   // -1 not probed, 0 the cooperative grid does not fit, 1 usable
   int* err_flag = nullptr;
   int* h_flag = nullptr;
   int T_max = 0;
@@ -771,6 +912,17 @@ int run_conv1x1(vc_codec* c, const Conv& cv, const float* x, int T, float* out_r
   return VC_OK;
 }
 
+// experimental persistent LSTM: after a synchronise, report a wait that gave up (word 1 of err_flag)
+int check_lstm_flag(vc_codec* c) {
+  if (!getenv("VC_LSTM_PERSIST")) return VC_OK;
+  int w = 0;
+  CCHK(c, hipMemcpy(&w, c->err_flag + 1, 4, hipMemcpyDeviceToHost));
+  if (w) {
+    (void)hipMemset(c->err_flag + 1, 0, 4);
+    return cfail(c, VC_EHIP, "persistent LSTM: a hand-off wait exceeded its bound (workgroups not co-resident?)");
+  }
+  return VC_OK;
+}
 // EncodecLSTM: y = lstm(x) + x over [B][T][H]; x is raw, the block output is written raw and/or ELU'd
 int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, float* out_elu, hipStream_t s, int B = 1) {
   const int H = L.H;
@@ -780,6 +932,37 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
     // two-layer wavefront: T + 1 launches (lstm_wave_k)
     int rc = run_conv1x1(c, L.Wih[0], x, T, c->G, s, B);                          // layer 0: G = x W_ih^T + b_ih + b_hh
     if (rc) return rc;
+    if (getenv("VC_LSTM_PERSIST")) {      // EXPERIMENTAL: one persistent cooperative launch (lstm_persist_k)
+      const void* kern = H == 256 ? (const void*)lstm_persist_k<1> : H == 512 ? (const void*)lstm_persist_k<2>
+                       : H == 768 ? (const void*)lstm_persist_k<3> : (const void*)lstm_persist_k<4>;
+      if (c->persist_ok < 0) {
+        int per_cu = 0, coop = 0;
+        hipDeviceProp_t prop;
+        CCHK(c, hipGetDeviceProperties(&prop, c->device));
+        CCHK(c, hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device));
+        CCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
+        c->persist_ok = (coop && (long)per_cu * prop.multiProcessorCount >= 2L * (H / 4)) ? 1 : 0;
+      }
+      if (!c->persist_ok) return cfail(c, VC_EINVAL, "VC_LSTM_PERSIST: the cooperative grid of %d workgroups does not fit this device", 2 * (H / 4));
+      if (!c->hgran) {
+        int rc2 = calloc_dev(c, &c->hgran, (size_t)2 * c->B_max * c->T_max * H);
+        if (rc2) return rc2;
+        CCHK(c, hipMemsetAsync(c->hgran, 0, (size_t)2 * c->B_max * c->T_max * H * 8, s));
+      }
+      if (++c->lstm_epoch == 0) c->lstm_epoch = 1;
+      LstmPersistArgs pa;
+      memset(&pa, 0, sizeof pa);
+      pa.Whh[0] = L.Whh[0]; pa.Whh[1] = L.Whh[1]; pa.Wih1 = L.WihP[1]; pa.b1 = L.bP[1]; pa.G0 = c->G;
+      pa.hg[0] = c->hgran; pa.hg[1] = c->hgran + (size_t)c->B_max * c->T_max * H;
+      pa.c[0] = c->cstate; pa.c[1] = c->cstate + (size_t)B * H;
+      pa.skip = x; pa.out_raw = out_raw; pa.out_elu = out_elu; pa.H = H; pa.T = T; pa.B = B;
+      pa.epoch = c->lstm_epoch; pa.err = c->err_flag + 1;      // word 1: a bounded wait of the persistent LSTM gave up
+      void* kargs[] = {&pa};
+      CCHK(c, hipEventRecord(c->ev_l[0], s));
+      CCHK(c, hipLaunchCooperativeKernel(kern, dim3(H / 4, 2), dim3(256), kargs, 0, s));
+      CCHK(c, hipEventRecord(c->ev_l[1], s));
+      return VC_OK;
+    }
     CCHK(c, hipMemsetAsync(c->cstate, 0, (size_t)2 * B * H * 4, s));
     LstmWaveArgs a;
     memset(&a, 0, sizeof a);
@@ -1030,6 +1213,7 @@ extern "C" int vc_codec_encode_batch(vc_codec* c, const float* wav_dev, int B, i
   CCHK(c, hipEventRecord(c->ev[1], s));
   CCHK(c, hipStreamSynchronize(s));
   CCHK(c, hipEventElapsedTime(&c->last_ms, c->ev[0], c->ev[1]));
+  if ((rc = check_lstm_flag(c))) return rc;
   c->last_T = T;
   *n_frames = T;
   return VC_OK;
@@ -1083,7 +1267,7 @@ extern "C" int vc_codec_decode_batch(vc_codec* c, const int64_t* codes_dev, int 
     (void)hipMemset(c->err_flag, 0, 4);   // already on the error path
     return cfail(c, VC_EINVAL, "code index outside [0, %d)", g.codebook_size);
   }
-  return VC_OK;
+  return check_lstm_flag(c);
 }
 extern "C" int vc_codec_decode(vc_codec* c, const int64_t* codes_dev, int T, float* wav_dev, int wav_cap, void* stream) {
   return vc_codec_decode_batch(c, codes_dev, 1, T, wav_dev, wav_cap, stream);
