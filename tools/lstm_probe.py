@@ -1,5 +1,6 @@
 """Validates and times the EXPERIMENTAL persistent LSTM (VC_LSTM_PERSIST=1, lstm_persist_k) against the default
-two-layer wavefront (lstm_wave_k): codes and waveform must be bit-identical (same arithmetic, same order).
+two-layer wavefront (lstm_wave_k): codes must be identical (the waveform may differ in the last bits: the two kernels
+contract their multiply-adds differently).
 Run under a short `timeout`: every hand-off wait in the kernel is bounded, but this path has not seen hardware yet.
 usage: timeout 120 python tools/lstm_probe.py [batch]"""
 import os, sys
