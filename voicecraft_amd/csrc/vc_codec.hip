@@ -360,13 +360,14 @@ __global__ __launch_bounds__(256) void lstm_wave_k(const LstmWaveArgs a) {
   }
 }
 
-// ---- EXPERIMENTAL (VC_LSTM_PERSIST=1, off by default; not yet validated on hardware): the same recurrence as ONE
+// ---- EXPERIMENTAL (VC_LSTM_PERSIST=1, off by default: correct but 14.0 us per step against the wavefront's 10.4 us,
+// profiles/r02_lstm_persist_probe.log - every wave polling the whole hidden vector costs more than the weights): the same recurrence as ONE
 // persistent cooperative launch.  Every wave keeps its unit's gate rows (16 KB of W_hh, layer 1 also 16 KB of W_ih) in
 // registers for the whole sequence instead of re-reading 48 MB of weights per step, and hidden values travel between
 // workgroups as 8-byte granules {h bits, epoch} written and read with ONE relaxed agent-scope atomic each (value and
 // tag cannot tear and need no fence; MI355X_MICROARCH "data-tagged hand-off").  A granule is valid when its tag equals
-// the call's epoch, so nothing is cleared between calls.  The arithmetic (order of every sum) is lstm_wave_k's: results
-// must be bit-identical.  Launched cooperatively (all 2 x H/4 workgroups resident: a wait can only be for a
+// the call's epoch, so nothing is cleared between calls.  The arithmetic (order of every sum) is lstm_wave_k's (codes
+// identical; the compiler contracts the multiply-adds of the two kernels differently, so the waveform differs in the last bits).  Launched cooperatively (all 2 x H/4 workgroups resident: a wait can only be for a
 // workgroup that is running); every wait is bounded and raises err instead of hanging.
 struct LstmPersistArgs {
   const float* Whh[2];
