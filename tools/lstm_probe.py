@@ -16,11 +16,11 @@ torch.manual_seed(0)
 res = {}
 for secs in (1, 16):
     wav = (torch.randn(B, 1, 16000 * secs) * 0.1).cuda()
-    for mode in ("wave", "persist"):
-        if mode == "persist":
-            os.environ["VC_LSTM_PERSIST"] = "1"
-        else:
+    for mode in ("wave", "persist", "persist2"):
+        if mode == "wave":
             os.environ.pop("VC_LSTM_PERSIST", None)
+        else:
+            os.environ["VC_LSTM_PERSIST"] = "2" if mode == "persist2" else "1"   # 2: LDS-staged form (lstm_persist2_k)
         for _ in range(2):
             codes = tok.encode(wav)[0][0]
         enc_ms = tok.last_ms()
@@ -29,8 +29,9 @@ for secs in (1, 16):
             back = tok.decode([(codes, None)])
         dec_ms = tok.last_ms()
         res[(secs, mode)] = (codes.cpu(), back.cpu())
-        print(f"[lstm] {secs:2d} s x {B}: {mode:7s} encode {enc_ms:7.2f} ms (LSTM part {lstm_ms:6.2f} ms), decode {dec_ms:7.2f} ms", flush=True)
-    same_codes = bool((res[(secs, "wave")][0] == res[(secs, "persist")][0]).all())
-    same_wav = bool((res[(secs, "wave")][1] == res[(secs, "persist")][1]).all())
-    print(f"[lstm] {secs:2d} s x {B}: codes identical {same_codes}, waveform bit-identical {same_wav}", flush=True)
+        print(f"[lstm] {secs:2d} s x {B}: {mode:8s} encode {enc_ms:7.2f} ms (LSTM part {lstm_ms:6.2f} ms), decode {dec_ms:7.2f} ms", flush=True)
+    for mode in ("persist", "persist2"):
+        same_codes = bool((res[(secs, "wave")][0] == res[(secs, mode)][0]).all())
+        err = float((res[(secs, "wave")][1] - res[(secs, mode)][1]).abs().max())
+        print(f"[lstm] {secs:2d} s x {B}: {mode}: codes identical {same_codes}, waveform max |diff| {err:.3g}", flush=True)
 os.environ.pop("VC_LSTM_PERSIST", None)

@@ -499,6 +499,135 @@ __global__ __launch_bounds__(256, 2) void lstm_persist_k(const LstmPersistArgs a
   }
 }
 
+// ---- second form of the persistent LSTM (VC_LSTM_PERSIST=2; written after the first form's measurement, NOT yet run on
+// hardware): the polling traffic is what cost 14 us per step, so a workgroup is now 8 waves = 8 units (one per CU:
+// 2 x H/8 workgroups), its waves poll ONE EIGHTH of the hidden vector each (H/8 granules, two per lane), park the values
+// in LDS and meet at one block barrier per step; every wave then reads the whole vector from LDS.  L2 traffic per
+// poll round: 2 MB instead of 24 MB.  The LDS vector is double-buffered by step parity, so one barrier per step is
+// enough; a wait that gives up raises an LDS flag BEFORE the barrier and the whole workgroup leaves together.
+template <int NQ>   // H = 256 * NQ
+__global__ __launch_bounds__(512) void lstm_persist2_k(const LstmPersistArgs a) {
+  __shared__ __attribute__((aligned(16))) float s_h[2][2][256 * NQ];     // [parity][h_prev | x][H]
+  __shared__ int s_abort;
+  const int H = a.H;
+  const int per_layer = H >> 3;                          // workgroups per layer
+  const int n = blockIdx.x / per_layer;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = (blockIdx.x - n * per_layer) * 8 + wave;  // hidden unit
+  const int nq = H >> 2;
+  const long TH = (long)a.T * H;
+  if (threadIdx.x == 0) s_abort = 0;
+  const float4* whh = reinterpret_cast<const float4*>(a.Whh[n] + (long)(4 * u) * H);
+  float4 w[4][NQ], wi[4][NQ];
+#pragma unroll
+  for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) w[g][j] = whh[(long)g * nq + lane + 64 * j];
+  }
+  float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (n == 1) {
+    const float4* wih = reinterpret_cast<const float4*>(a.Wih1 + (long)(4 * u) * H);
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wi[g][j] = wih[(long)g * nq + lane + 64 * j];
+    }
+    gb = *reinterpret_cast<const float4*>(a.b1 + 4 * u);
+  } else {
+#pragma unroll
+    for (int j = 0; j < NQ; ++j) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) wi[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  }
+  __syncthreads();
+  // this wave's slice of a hidden vector: granules [wave * H/8, (wave + 1) * H/8) = GPL consecutive granules per lane
+  // (this form accepts H = 512 or 1024: one or two per lane)
+  constexpr int GPL = NQ / 2;
+  static_assert(NQ == 2 || NQ == 4, "lstm_persist2_k: hidden 512 or 1024");
+  const int s0 = wave * (H >> 3) + GPL * lane;
+  auto fetch = [&](const unsigned long long* g, float* dst) -> bool {      // bounded wait for the slice, parked in LDS
+    for (int spins = 0; spins < VC_LSTM_SPIN_LIMIT; ++spins) {
+      bool ok = true;
+      float v[GPL];
+#pragma unroll
+      for (int q = 0; q < GPL; ++q) {
+        const unsigned long long a0 = __hip_atomic_load(g + s0 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        ok = ok && (unsigned)(a0 >> 32) == a.epoch;
+        v[q] = __uint_as_float((unsigned)a0);
+      }
+      if (__all(ok)) {
+#pragma unroll
+        for (int q = 0; q < GPL; ++q) dst[s0 + q] = v[q];
+        return true;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+    return false;
+  };
+  int it = 0;
+  for (int t = 0; t < a.T; ++t) {
+    for (int b = 0; b < a.B; ++b, ++it) {
+      float* sh = s_h[it & 1][0];
+      float* sx = s_h[it & 1][1];
+      bool ok = true;
+      if (t) ok = fetch(a.hg[n] + b * TH + (long)(t - 1) * H, sh);
+      if (n == 1 && ok) ok = fetch(a.hg[0] + b * TH + (long)t * H, sx);
+      if (!ok && lane == 0) {
+        s_abort = 1;
+        __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      __syncthreads();
+      if (s_abort) return;                               // every wave sees the flag behind the same barrier
+      float4 hv[NQ], xv[NQ];
+#pragma unroll
+      for (int j = 0; j < NQ; ++j) {
+        hv[j] = t ? reinterpret_cast<const float4*>(sh)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        xv[j] = (n == 1) ? reinterpret_cast<const float4*>(sx)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      float4 gi = gb;
+      if (n == 0) gi = *reinterpret_cast<const float4*>(a.G0 + (b * (long)a.T + t) * 4 * H + 4 * u);
+      const float c_prev = t ? a.c[n][(long)b * H + u] : 0.f;
+      const float sk = (n == 1 && a.skip) ? a.skip[b * TH + (long)t * H + u] : 0.f;
+      float g4[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+#pragma unroll
+        for (int j = 0; j < NQ; ++j)
+          g4[g] += (w[g][j].x * hv[j].x + w[g][j].y * hv[j].y) + (w[g][j].z * hv[j].z + w[g][j].w * hv[j].w);
+      }
+      if (n == 1) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float acc = 0.f;
+#pragma unroll
+          for (int j = 0; j < NQ; ++j)
+            acc += (wi[g][j].x * xv[j].x + wi[g][j].y * xv[j].y) + (wi[g][j].z * xv[j].z + wi[g][j].w * xv[j].w);
+          g4[g] += acc;
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
+      if (lane == 0) {
+        const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
+        const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
+        const float gg = tanhf(g4[2] + gi.z);
+        const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
+        const float c = fg * c_prev + ig * gg;
+        const float h = og * tanhf(c);
+        a.c[n][(long)b * H + u] = c;
+        __hip_atomic_store(a.hg[n] + b * TH + (long)t * H + u, ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(h),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (n == 1 && a.skip) {
+          const float y = h + sk;
+          if (a.out_raw) a.out_raw[b * TH + (long)t * H + u] = y;
+          if (a.out_elu) a.out_elu[b * TH + (long)t * H + u] = elu1(y);
+        }
+      }
+    }
+  }
+}
+
 // ---- residual VQ (EncodecResidualVectorQuantizer.encode/.decode).  One block per frame.
 // dist = -(|r|^2 - 2 r.e + |e|^2), arg-max with the lowest index on ties (torch.max), residual update.
 __global__ __launch_bounds__(256) void rvq_encode_k(const float* __restrict__ z, const float* __restrict__ Et,
@@ -717,6 +846,7 @@ struct vc_codec {
   unsigned long long* hgran = nullptr;   // experimental persistent LSTM: 2 x [B_max][T_max][H] granules, allocated on first use
   unsigned lstm_epoch = 0;
   int persist_ok = -1;                   // -1 not probed, 0 the cooperative grid does not fit, 1 usable
+  int persist_form = 0;
   int* err_flag = nullptr;
   int* h_flag = nullptr;
   int T_max = 0;
@@ -934,17 +1064,24 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
     int rc = run_conv1x1(c, L.Wih[0], x, T, c->G, s, B);                          // layer 0: G = x W_ih^T + b_ih + b_hh
     if (rc) return rc;
     if (getenv("VC_LSTM_PERSIST")) {      // EXPERIMENTAL: one persistent cooperative launch (lstm_persist_k)
-      const void* kern = H == 256 ? (const void*)lstm_persist_k<1> : H == 512 ? (const void*)lstm_persist_k<2>
+      const int form = atoi(getenv("VC_LSTM_PERSIST"));          // 1: every wave polls the whole vector; 2: LDS-staged (8 units per workgroup)
+      if (form == 2 && H != 512 && H != 1024) return cfail(c, VC_EINVAL, "VC_LSTM_PERSIST=2 needs hidden 512 or 1024");
+      const void* kern = form == 2 ? (H == 512 ? (const void*)lstm_persist2_k<2> : (const void*)lstm_persist2_k<4>)
+                       : H == 256 ? (const void*)lstm_persist_k<1> : H == 512 ? (const void*)lstm_persist_k<2>
                        : H == 768 ? (const void*)lstm_persist_k<3> : (const void*)lstm_persist_k<4>;
-      if (c->persist_ok < 0) {
+      const dim3 pgrid = form == 2 ? dim3(2 * (H / 8)) : dim3(H / 4, 2);
+      const int pthreads = form == 2 ? 512 : 256;
+      const long n_wg = form == 2 ? 2L * (H / 8) : 2L * (H / 4);
+      if (c->persist_ok < 0 || c->persist_form != form) {
+        c->persist_form = form;
         int per_cu = 0, coop = 0;
         hipDeviceProp_t prop;
         CCHK(c, hipGetDeviceProperties(&prop, c->device));
         CCHK(c, hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device));
-        CCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 256, 0));
-        c->persist_ok = (coop && (long)per_cu * prop.multiProcessorCount >= 2L * (H / 4)) ? 1 : 0;
+        CCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, pthreads, 0));
+        c->persist_ok = (coop && (long)per_cu * prop.multiProcessorCount >= n_wg) ? 1 : 0;
       }
-      if (!c->persist_ok) return cfail(c, VC_EINVAL, "VC_LSTM_PERSIST: the cooperative grid of %d workgroups does not fit this device", 2 * (H / 4));
+      if (!c->persist_ok) return cfail(c, VC_EINVAL, "VC_LSTM_PERSIST: the cooperative grid of %ld workgroups does not fit this device", n_wg);
       if (!c->hgran) {
         int rc2 = calloc_dev(c, &c->hgran, (size_t)2 * c->B_max * c->T_max * H);
         if (rc2) return rc2;
@@ -960,7 +1097,7 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
       pa.epoch = c->lstm_epoch; pa.err = c->err_flag + 1;      // word 1: a bounded wait of the persistent LSTM gave up
       void* kargs[] = {&pa};
       CCHK(c, hipEventRecord(c->ev_l[0], s));
-      CCHK(c, hipLaunchCooperativeKernel(kern, dim3(H / 4, 2), dim3(256), kargs, 0, s));
+      CCHK(c, hipLaunchCooperativeKernel(kern, pgrid, dim3(pthreads), kargs, 0, s));
       CCHK(c, hipEventRecord(c->ev_l[1], s));
       return VC_OK;
     }
