@@ -157,3 +157,21 @@ def test_wrong_architecture_switch_is_rejected_at_load():
         AudioTokenizer(sd, device="cuda:0", max_seconds=1.0)              # shortcut tensors present, switch off
     with pytest.raises(AssertionError):
         AudioTokenizer(synth.make_codec_state_dict(2), device="cuda:0", max_seconds=1.0, cfg=dict(num_residual_layers=2))
+
+
+@pytest.mark.skipif(not __import__("os").environ.get("VC_TEST_EXPERIMENTAL"), reason="experimental path: set VC_TEST_EXPERIMENTAL=1")
+@pytest.mark.parametrize("form", ["1", "2"])
+def test_experimental_persistent_lstm_gives_the_wavefront_codes(setup, form, monkeypatch):
+    """VC_LSTM_PERSIST: the persistent cooperative LSTM must reproduce the default path's codes and,
+    to fp32 rounding, its waveform.  Off by default, so this test is opt-in."""
+    tok, _ = setup
+    torch.manual_seed(3)
+    wav = (torch.randn(1, 1, 16000 * 2 + 77) * 0.1).cuda()
+    monkeypatch.delenv("VC_LSTM_PERSIST", raising=False)
+    codes = tok.encode(wav)[0][0]
+    back = tok.decode([(codes, None)])
+    monkeypatch.setenv("VC_LSTM_PERSIST", form)
+    codes_p = tok.encode(wav)[0][0]
+    back_p = tok.decode([(codes_p, None)])
+    assert torch.equal(codes, codes_p)
+    assert float((back - back_p).abs().max()) <= 1e-4 * float(back.abs().max()) + 1e-6
