@@ -103,6 +103,69 @@ MODEL_CASES = {
 }
 
 
+# Training objective, teacher-forced (VoiceCraft.forward, models/voicecraft.py:472-559).  The reference draws
+# its mask intervals at random (:198-237); the fixtures fix them by replacing `prepare_mask_intervals` on the live model.
+# `samples` = (Lx, T, seed) per utterance of the batch, `spans` = its mask intervals (frame indices).
+# The audio tokens of these batches are folded into [0, 16) and twelve of those ids get a bias boost on every head, so
+# that the target is among the ten largest logits for roughly half of the positions: the top-10 metric is exercised with
+# hits AND misses (with flat random logits it would be 0 almost everywhere).
+_BOOST12 = [(-1, t, 4.0) for t in range(12)]
+FORWARD_CASES = {
+    "fwd_b1_1span": dict(preset="tiny", arg_kw={}, wseed=11, sd_kw=dict(mute_eos=False, boost=_BOOST12),
+                         samples=[(9, 48, 21)], spans=[[(12, 25)]], codebook_weight=None),
+    "fwd_b3_ragged": dict(preset="tiny", arg_kw={}, wseed=12, sd_kw=dict(mute_eos=False, boost=_BOOST12),
+                          samples=[(12, 60, 22), (7, 41, 23), (10, 33, 24)],
+                          spans=[[(10, 20), (35, 40)], [(5, 17)], [(3, 8), (12, 19), (25, 30)]],
+                          codebook_weight="[5,1,0.5,0.1]"),        # the released models' weights (z_scripts/e830M.sh)
+    "fwd_oldscheme": dict(preset="tiny", arg_kw=dict(eos=-1, n_special=3, reduced_eog=0), wseed=13,
+                          sd_kw=dict(mute_eos=False, boost=_BOOST12),
+                          samples=[(8, 50, 25), (11, 37, 26)], spans=[[(20, 31)], [(4, 9), (20, 28)]], codebook_weight=None),
+    "fwd_hd128": dict(preset="tiny128", arg_kw={}, wseed=14, sd_kw=dict(mute_eos=False, boost=_BOOST12),
+                      samples=[(10, 70, 27), (6, 52, 28)], spans=[[(1, 6), (30, 44)], [(26, 51)]],
+                      codebook_weight="[5,1,0.5,0.1]"),
+}
+
+
+def forward_inputs(spec, args):
+    """Padded batch of a FORWARD case (shared with the tests)."""
+    parts = [synth.random_prompt(args, Lx, T, seed=sd) for (Lx, T, sd) in spec["samples"]]
+    B, K = len(parts), args.n_codebooks
+    x_lens = torch.tensor([p[0].shape[1] for p in parts], dtype=torch.int64)
+    y_lens = torch.tensor([p[2].shape[1] for p in parts], dtype=torch.int64)
+    x = torch.full((B, int(x_lens.max())), args.text_pad_token, dtype=torch.int64)
+    y = torch.full((B, K, int(y_lens.max())), args.audio_pad_token, dtype=torch.int64)
+    for i, (xi, _, yi) in enumerate(parts):
+        x[i, : xi.shape[1]] = xi[0]
+        y[i, :, : yi.shape[1]] = yi[0].transpose(0, 1) % 16
+    return dict(x=x, x_lens=x_lens, y=y, y_lens=y_lens)
+
+
+def run_reference_forward(spec):
+    args = synth.make_args(spec["preset"], **spec["arg_kw"])
+    args.codebook_weight = spec["codebook_weight"]
+    sd = case_state_dict(spec, args)
+    model = ref_loader.build_reference_model(args, sd)
+    batch = forward_inputs(spec, args)
+    spans = spec["spans"]
+
+    def fixed_intervals(y_lens):               # what prepare_mask_intervals (:198-237) returns, for the chosen spans
+        mi = [list(v) for v in spans]
+        nmi = []
+        for i, v in enumerate(spans):
+            T = int(y_lens[i])
+            nmi.append(list(zip([0] + [e for _, e in v], [s for s, _ in v] + [T])))
+        return mi, nmi
+    model.prepare_mask_intervals = fixed_intervals
+    with torch.no_grad():
+        ref = model.forward(batch)
+    out = {k: v.numpy() for k, v in batch.items()}
+    out["loss"] = np.float64(float(ref["loss"]))
+    out["top10acc"] = np.float64(float(ref["top10acc"]))
+    out["top10acc_by_codebook"] = np.array([float(t) for t in ref["top10acc_by_codebook"]], dtype=np.float64)
+    out["effective_ntoken"] = np.int64(int(ref["effective_ntoken"]))
+    return out
+
+
 def case_state_dict(spec, args):
     """The synthetic checkpoint of a golden case (shared with tests/_util.py)."""
     kw = dict(mute_eos=True)
@@ -205,12 +268,22 @@ def gen_sampler():
 def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
+    if "--forward-only" in sys.argv:            # the training-objective fixtures only (the others are unchanged)
+        for name, spec in FORWARD_CASES.items():
+            out = run_reference_forward(spec)
+            np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **out)
+            print(f"{name}.npz: loss={float(out['loss']):.4f} top10={out['top10acc_by_codebook']} ntoken={int(out['effective_ntoken'])}")
+        return
     gen_pattern()
     gen_sampler()
     for name, spec in MODEL_CASES.items():
         out = run_reference_case(spec)
         np.savez_compressed(os.path.join(GOLDEN, f"model_{name}.npz"), **out)
         print(f"model_{name}.npz: steps={int(out['n_steps'])} res={out['res'].shape}")
+    for name, spec in FORWARD_CASES.items():
+        out = run_reference_forward(spec)
+        np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **out)
+        print(f"{name}.npz: loss={float(out['loss']):.4f} top10={out['top10acc_by_codebook']} ntoken={int(out['effective_ntoken'])}")
 
 
 if __name__ == "__main__":

@@ -5,7 +5,8 @@ the `-m gpu` tests, smoke() or bench.py may import this module.  It is used by g
 produce tests/golden/*.npz and by the container-only cross-check test.
 
 `torchmetrics` is absent from the image and only feeds a training metric
-(models/voicecraft.py:10, :187-195), so a no-op stand-in is put on sys.modules first.
+(models/voicecraft.py:10, :187-195), so a stand-in that restates the one metric the reference uses is put on
+sys.modules first.
 """
 from __future__ import annotations
 
@@ -29,8 +30,18 @@ def _stub_torchmetrics() -> None:
     cl = types.ModuleType("torchmetrics.classification")
 
     class MulticlassAccuracy(torch.nn.Module):
-        def __init__(self, *a, **k):
+        """Stand-in for torchmetrics 0.11.1 (README.md:113) `MulticlassAccuracy(num_classes, top_k, average="micro",
+        multidim_average="global", ignore_index=None)` as the reference constructs it (models/voicecraft.py:187-195):
+        the fraction of samples whose target is among the top_k logits (`select_topk` = `Tensor.topk`)."""
+
+        def __init__(self, num_classes=None, top_k=1, average="micro", multidim_average="global", ignore_index=None, **k):
             super().__init__()
+            assert average == "micro" and multidim_average == "global" and ignore_index is None
+            self.top_k = int(top_k)
+
+        def forward(self, preds, target):
+            hit = (preds.topk(self.top_k, dim=1).indices == target[:, None]).any(dim=1)
+            return hit.float().mean()
 
     cl.MulticlassAccuracy = MulticlassAccuracy
     tm.classification = cl

@@ -9,6 +9,10 @@ A functional restatement of the reference's inference path over a plain state_di
   sequence rearrangement  <- models/voicecraft.py:239-320 (rearrange/shift/insert_mask/cat_y/embed_y)
   generation loops        <- models/voicecraft.py:561-906 (inference), :908-1153 (inference_tts),
                              :1156-1439 (inference_tts_batch)
+  training objective      <- models/voicecraft.py:472-559 (forward) with the mask intervals given instead of drawn
+                             (:198-237), :322-404 (prepare_input_target / remove_mask / revert_pattern),
+                             codebooks_patterns.py:178-266 (revert_pattern_logits); top-10 accuracy restates
+                             torchmetrics 0.11.1 MulticlassAccuracy(top_k=10, average="micro") (README.md:113)
 
 The three public generation methods of the reference share one loop here (`_run`); the ATen ops,
 their order and their operand shapes are kept identical to the reference, including the per-step
@@ -404,6 +408,121 @@ class VoiceCraftOracle:
         if self.special_first:
             res = res - self.n_special
         return res
+
+
+    # ---- the training objective, teacher-forced
+    def train_layout(self, T: int, intervals: list[tuple[int, int]], mask_value: list[int]):
+        """Pieces of one sample's training sequence (voicecraft.py:239-288): every non-masked piece, then every
+        masked piece (each + `eog`), a mask placeholder after each piece but the last.  Returns a list of
+        ('piece', s, e, term) / ('mask', value)."""
+        M = len(intervals)
+        assert 1 <= M <= self.max_n_spans and len(mask_value) == M
+        starts = [iv[0] for iv in intervals] + [T]
+        ends = [0] + [iv[1] for iv in intervals]
+        pieces = []
+        for i, (s, e) in enumerate(zip(ends, starts)):                      # non-masked pieces (:243-250)
+            if self.eos > 0:
+                assert self.reduced_eog
+                term = self.eos if i == M else -1
+            elif self.reduced_eog:
+                term = self.eog if i == M else -1
+            else:
+                term = self.eog
+            pieces.append((s, e, term))
+        for (s, e) in intervals:                                            # masked pieces, always + eog
+            pieces.append((s, e, self.eog))
+        values = list(mask_value) + list(mask_value)                        # emb_inds_use + emb_inds_use (:274)
+        desc: list[tuple] = []
+        for j, (s, e, term) in enumerate(pieces):
+            desc.append(("piece", s, e, term))
+            if j < len(pieces) - 1:
+                desc.append(("mask", values[j]))
+        return desc
+
+    @torch.no_grad()
+    def forward(self, batch: dict, mask_intervals: list[list[tuple[int, int]]], mask_values: list[list[int]] | None = None,
+                codebook_weight: list[float] | None = None):
+        """VoiceCraft.forward (voicecraft.py:472-559) with `prepare_mask_intervals` (:198-237, random) replaced by the
+        given intervals (frame indices into each sample's y) and `mask_values[i]` = the sample's `emb_inds_use`
+        (:270-273; default 0..M-1, i.e. shuffle_mask_embedding = 0).  Batched and padded exactly as the reference:
+        pad tokens + key-padding masks.  Returns the reference's dict."""
+        x, x_lens, y, y_lens = batch["x"], batch["x_lens"], batch["y"], batch["y_lens"]
+        B, K = x.shape[0], self.K
+        x = x[:, : int(x_lens.max())]
+        y = y[:, :, : int(y_lens.max())]
+        assert y.ndim == 3 and y.shape[1] == K
+        if mask_values is None:
+            mask_values = [list(range(len(iv))) for iv in mask_intervals]
+        # ---- text side (:497-500)
+        x_input = self._pos(F.embedding(x, self.sd["text_embedding.word_embeddings.weight"]), "text")
+        # ---- audio side: rearrange, shift, insert placeholders, concatenate, pad (:322-372)
+        cols, targets, mask_pos = [], [], []
+        for i in range(B):
+            T = int(y_lens[i])
+            desc = self.train_layout(T, mask_intervals[i], mask_values[i])
+            yi = y[i, :, :T].numpy()
+            cur, tg, mp, n = [], [], {}, 0
+            for item in desc:
+                if item[0] == "piece":
+                    _, s0, e0, term = item
+                    z = yi[:, s0:e0]
+                    if term >= 0:
+                        z = np.concatenate([z, np.full((K, 1), term, dtype=z.dtype)], axis=1)
+                    assert z.shape[1] > 0, "empty piece (the reference raises inside get_pattern)"
+                    tg.append(torch.from_numpy(np.ascontiguousarray(z)))
+                    sh = delayed_shift(z[None], self.empty)[0]               # [K, n+K]
+                    cur.append(sh); n += sh.shape[1]
+                else:
+                    mp[n] = item[1]                                           # placeholder column -> mask_embedding row
+                    cur.append(np.full((K, 1), self.eog, dtype=yi.dtype)); n += 1
+            cols.append(torch.from_numpy(np.concatenate(cur, axis=1)))       # [K, S_i]
+            targets.append(tg); mask_pos.append(mp)
+        new_y_lens = torch.tensor([c.shape[1] for c in cols])
+        S = int(new_y_lens.max())
+        cated = torch.full((K, S, B), self.pad, dtype=torch.int64)          # pad_sequence(..., audio_pad_token) (:305)
+        for i, c in enumerate(cols):
+            cated[:, : c.shape[1], i] = c
+        emb = self._embed_cols(cated)                                        # [B,S,d]
+        for i in range(B):
+            for col, val in mask_pos[i].items():
+                emb[i, col] = self.sd["mask_embedding"][val]                 # (:318-319)
+        y_input = self._pos(emb, "audio")
+        # ---- masks (:416-444): causal over the concatenation (x rows see no y), padded keys removed
+        Lx = x.shape[1]
+        tri = torch.triu(torch.ones(Lx + S, Lx + S), diagonal=1).bool()
+        tri[:Lx, Lx:] = True
+        pad = torch.cat([torch.arange(Lx)[None] >= x_lens[:, None], torch.arange(S)[None] >= new_y_lens[:, None]], dim=1)
+        m = tri[None] | pad[:, None, :]
+        mask = torch.zeros(B, Lx + S, Lx + S).masked_fill_(m, float("-inf"))[:, None].expand(B, self.H, Lx + S, Lx + S).contiguous()
+        out, _ = self._stack(torch.cat([x_input, y_input], dim=1), mask, None)
+        y_out = out[:, Lx:]
+        logits = torch.stack([F.linear(F.gelu(F.linear(y_out, self.sd[f"predict_layer.{k}.0.weight"], self.sd[f"predict_layer.{k}.0.bias"])),
+                                       self.sd[f"predict_layer.{k}.2.weight"], self.sd[f"predict_layer.{k}.2.bias"])
+                              for k in range(K)], dim=1)                      # [B,K,S,V] (:516)
+        # ---- drop the placeholders, revert the delay pattern per piece (:374-404): piece logits [K, n+K, V] ->
+        #      [K, n, V] with out[q,t] = logits[q, t+q] (codebooks_patterns.py:209-215 with is_model_output)
+        lg_all, tg_all = [], []
+        for i in range(B):
+            bounds = [-1] + sorted(mask_pos[i].keys()) + [int(new_y_lens[i])]
+            for j in range(len(bounds) - 1):
+                seg = logits[i, :, bounds[j] + 1: bounds[j + 1]]              # [K, n+K, V]
+                n = seg.shape[1] - K
+                assert n == targets[i][j].shape[1]
+                lg_all.append(torch.stack([seg[q, q: q + n] for q in range(K)], dim=0))
+                tg_all.append(targets[i][j])
+        lg = torch.cat(lg_all, dim=1)                                        # [K, N, V]
+        tg = torch.cat(tg_all, dim=1)                                        # [K, N]
+        cw = codebook_weight if codebook_weight is not None else [1.0] * K
+        loss, top10, ntok = [], [], []
+        for k in range(K):
+            loss.append(F.cross_entropy(lg[k], tg[k], reduction="mean"))
+            hit = (lg[k].topk(10, dim=1).indices == tg[k][:, None]).any(dim=1)   # torchmetrics 0.11.1 select_topk, micro
+            top10.append(hit.float().mean())
+            ntok.append(lg[k].shape[0])
+        by_cb = [t * n for t, n in zip(top10, ntok)]
+        return {"loss": sum(l * n * c for l, n, c in zip(loss, ntok, cw)), "top10acc": sum(by_cb),
+                "top10acc_by_codebook": by_cb, "effective_ntoken": torch.tensor(sum(ntok)),
+                "_per_token_logits": lg, "_targets": tg}
 
 
 def prompt_columns_tts(y_TK: np.ndarray, empty: int) -> np.ndarray:

@@ -41,3 +41,13 @@ def run_oracle_case(name: str, trace=None):
         return res, gen
     mi = torch.tensor([spec["spans"]], dtype=torch.int64)
     return orc.inference(x, x_lens, y, mi, trace=trace, **kn), None
+
+
+def build_forward_case(name: str):
+    """(spec, args, state_dict, batch dict) of a training-objective golden case (oracle/gen_golden.py FORWARD_CASES)."""
+    from oracle.gen_golden import FORWARD_CASES, forward_inputs
+    spec = FORWARD_CASES[name]
+    args = synth.make_args(spec["preset"], **spec["arg_kw"])
+    args.codebook_weight = spec["codebook_weight"]
+    sd = case_state_dict(spec, args)
+    return spec, args, sd, forward_inputs(spec, args)
