@@ -148,6 +148,27 @@ int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, in
             int64_t* res_dev, int res_cap, int* res_len, float* logits_dev, int logit_steps,
             int* n_steps, void* stream);
 
+/* ---- the training objective, teacher-forced: VoiceCraft.forward (models/voicecraft.py:472-559) for B utterances
+ * whose mask intervals are GIVEN (the reference draws them at random, :198-237): rearrange / delay-shift / mask
+ * placeholders (:239-320), one non-cached decoder pass over [text ; rearranged audio] of every utterance (:501-512;
+ * the reference pads the batch and masks the padding, the engine runs the rows unpadded), the K heads on every audio
+ * position (:516), the placeholders dropped and the delay pattern reverted per piece (:374-404,
+ * codebooks_patterns.py:247-266), then per codebook the cross-entropy SUM and the number of targets among the ten
+ * largest logits (torchmetrics MulticlassAccuracy(top_k=10), :187-195, :540-541).  EXPERIMENTAL: not yet validated
+ * on hardware.
+ *   x_dev int64 (all texts back to back), x_off host int32 [B+1]; y_dev int64 [frames][K] time-major (all utterances
+ *   back to back), y_off host int32 [B+1] in frames
+ *   spans host int32 [sum M_i][2] frame intervals, span_off host int32 [B+1]; mask_values host int32 [sum M_i]
+ *   (the utterance's emb_inds_use, :270-273)
+ *   out (host): nll_sum double [K] = sum of -log softmax(logits)[target]; hits int64 [K]; n_targets int64 (per codebook)
+ *   nll_dev optional device float [nll_cap][K]: the per-row terms in the engine's row order (parity hook), with
+ *   tgt_dev int32 [nll_cap][K] (>= 0 index into y_dev, -1 none, <= -2 constant token -(v+2)); n_rows_out = rows written */
+int vc_eval_forward(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_off,
+                    const int64_t* y_dev, const int32_t* y_off,
+                    const int32_t* spans, const int32_t* span_off, const int32_t* mask_values,
+                    double* nll_sum, int64_t* hits, int64_t* n_targets,
+                    float* nll_dev, int32_t* tgt_dev, int64_t nll_cap, int64_t* n_rows_out, void* stream);
+
 /* ---- delayed-codebook pattern (models/codebooks_patterns.py:151-176, :222-245 and
  * the un-shift at models/voicecraft.py:1125-1139).  Integer, bit-exact.  No engine needed.
  *   shift : z [B][K][T]  -> out [B][K][T+K]   out[q][s] = z[q][s-1-q] or `special`

@@ -359,6 +359,30 @@ hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s);
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s);
 hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s);
+
+// ---- training objective, teacher-forced (vc_eval_forward; VoiceCraft.forward, models/voicecraft.py:472-559)
+struct CeArgs {            // cross-entropy and top-10 membership of up to VC_ROWS logits rows against their targets
+  const float* logits;     // [n_rows][K][V] raw head outputs
+  const int64_t* y;        // the call's audio tokens, [frames][K] (all utterances back to back)
+  const int* tgt;          // [n_rows][K]: >= 0 = index into y; -1 = no target here; <= -2 = the constant token -(v + 2)
+  float* nll;              // [n_rows][K]: -log softmax(logits)[target]; 0 where there is no target
+  int* hit;                // [n_rows][K]: 1 when fewer than 10 logits exceed the target's (torchmetrics top_k = 10)
+  int n_rows, K, V;
+  int* err;                // raised on a target id outside [0, V)
+};
+hipError_t vc_launch_ce(const CeArgs& a, hipStream_t s);
+struct CeReduceArgs {      // per codebook: acc[k] += sum over rows, in a fixed order, in double
+  const float* nll;
+  const int* hit;
+  const int* tgt;
+  long n_rows;
+  int K;
+  double* nll_sum;         // [K]
+  long long* hits;         // [K]
+  long long* count;        // [K] number of targets
+};
+hipError_t vc_launch_ce_reduce(const CeReduceArgs& a, hipStream_t s);
+
 hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStream_t s);
 hipError_t vc_launch_copy_kv(void* cache, long seq_stride, int H, int S_max, int hd, int len,
                              int src_seq, int dst_seq0, int n_dst, int dtype, hipStream_t s);

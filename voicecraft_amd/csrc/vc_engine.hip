@@ -93,6 +93,11 @@ struct vc_engine {
   float ms[3]{0, 0, 0};
   double host_ms[8]{};                  // host wall clock of the last call's phases (vc_debug_read "host_ms")
   double bytes_total = 0;               // HBM bytes owned by the engine
+  // training objective (vc_eval_forward), allocated on first use
+  int *ce_tgt = nullptr, *ce_hit = nullptr;
+  float *ce_nll = nullptr;
+  double *ce_sum = nullptr;
+  long long *ce_hits = nullptr, *ce_cnt = nullptr;
 };
 
 namespace {
@@ -1168,6 +1173,172 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   HIPCHK(e, vc_launch_assemble(a, s));
   HIPCHK(e, hipStreamSynchronize(s));
   *res_len = dst;
+  return VC_OK;
+}
+
+// ------------------------------------------------------------------------------------- training objective
+// VoiceCraft.forward (voicecraft.py:472-559) with given mask intervals.  EXPERIMENTAL (not yet run on hardware).
+// The decoder pass is the prefill's (row stream over all utterances, block GEMM + tile attention); after every pass the
+// heads run over its rows 16 at a time and ce_rows_k turns each group's logits into per-row terms straight away, so the
+// [rows][K][V] logits of the whole batch never exist.
+extern "C" int vc_eval_forward(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_off,
+                               const int64_t* y_dev, const int32_t* y_off,
+                               const int32_t* spans, const int32_t* span_off, const int32_t* mask_values,
+                               double* nll_sum, int64_t* hits, int64_t* n_targets,
+                               float* nll_dev, int32_t* tgt_dev, int64_t nll_cap, int64_t* n_rows_out, void* stream) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (B < 1 || !x_dev || !x_off || !y_dev || !y_off || !spans || !span_off || !mask_values || !nll_sum || !hits || !n_targets)
+    return fail(e, VC_EINVAL, "null/invalid argument to vc_eval_forward");
+  if (B > e->B_max) return fail(e, VC_ECAP, "%d utterances, the engine was created for max_seqs %d", B, e->B_max);
+  hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
+  const int K = e->K;
+  const vc_model_cfg& c = e->cfg;
+  if (c.eos > 0 && !c.reduced_eog) return fail(e, VC_EINVAL, "eos > 0 requires reduced_eog (voicecraft.py:244)");
+  if (!e->ce_tgt) {
+    if ((rc = dalloc(e, &e->ce_tgt, (size_t)e->emb_cap * K))) return rc;
+    if ((rc = dalloc(e, &e->ce_hit, (size_t)e->emb_cap * K))) return rc;
+    if ((rc = dalloc(e, &e->ce_nll, (size_t)e->emb_cap * K))) return rc;
+    if ((rc = dalloc(e, &e->ce_sum, (size_t)VC_MAX_CODEBOOKS))) return rc;
+    if ((rc = dalloc(e, &e->ce_hits, (size_t)VC_MAX_CODEBOOKS))) return rc;
+    if ((rc = dalloc(e, &e->ce_cnt, (size_t)VC_MAX_CODEBOOKS))) return rc;
+  }
+  // ---- per utterance: the segment table of its training sequence (rearrange :239-252, shift :254-262, insert_mask
+  //      :264-288) and the target of every (row, codebook): piece column s, codebook q predicts piece token t = s - q
+  //      (revert_pattern_logits with is_model_output, codebooks_patterns.py:209-215, :247-266)
+  std::vector<PromptArgs> pas(B);
+  std::vector<std::vector<int>> tgts(B);          // [rows_i][K]
+  for (int i = 0; i < B; ++i) {
+    const int Lx = x_off[i + 1] - x_off[i], T = y_off[i + 1] - y_off[i], M = span_off[i + 1] - span_off[i];
+    if (Lx < 1 || T < 1) return fail(e, VC_EINVAL, "utterance %d: empty text or audio", i);
+    if (M < 1 || M > c.max_n_spans) return fail(e, VC_EINVAL, "utterance %d: %d spans outside [1,%d]", i, M, c.max_n_spans);
+    const int32_t* iv = spans + 2 * (size_t)span_off[i];
+    const int32_t* mv = mask_values + span_off[i];
+    for (int j = 0; j < M; ++j) {
+      if (mv[j] < 0 || mv[j] >= c.max_n_spans) return fail(e, VC_EINVAL, "utterance %d: mask value out of range", i);
+      const int lo = j ? iv[2 * (j - 1) + 1] : 0;
+      if (iv[2 * j] < lo || iv[2 * j + 1] < iv[2 * j] || iv[2 * j + 1] > T)
+        return fail(e, VC_EINVAL, "utterance %d: mask intervals must be ordered, disjoint and inside [0,%d]", i, T);
+    }
+    PromptArgs& pa = pas[i];
+    fill_prompt_common(e, pa, x_dev + x_off[i], Lx, y_dev + (size_t)y_off[i] * K, T);
+    struct Piece { int s, e, term; };
+    std::vector<Piece> pieces;
+    for (int j = 0; j <= M; ++j) {                 // non-masked pieces, the terminator as rearrange() places it
+      const int ps = j ? iv[2 * (j - 1) + 1] : 0, pe = (j == M) ? T : iv[2 * j];
+      int term;
+      if (c.eos > 0) term = (j == M) ? c.eos : -1;
+      else if (c.reduced_eog) term = (j == M) ? c.eog : -1;
+      else term = c.eog;
+      pieces.push_back(Piece{ps, pe, term});
+    }
+    for (int j = 0; j < M; ++j) pieces.push_back(Piece{iv[2 * j], iv[2 * j + 1], c.eog});   // masked pieces, always + eog
+    if ((int)(2 * pieces.size()) > VC_MAX_SEG) return fail(e, VC_EINVAL, "too many segments");
+    int col = 0, nseg = 0;
+    const int rows_text = Lx;
+    std::vector<int>& tg = tgts[i];
+    tg.assign((size_t)rows_text * K, -1);
+    for (size_t j = 0; j < pieces.size(); ++j) {
+      const Piece& p = pieces[j];
+      const int n = (p.e - p.s) + (p.term >= 0 ? 1 : 0);
+      if (n <= 0) return fail(e, VC_EINVAL, "utterance %d: piece %d is empty (the reference raises inside get_pattern)", i, (int)j);
+      pa.seg[nseg++] = Segment{col, n + K, p.s, p.e - p.s, p.term, -1};
+      for (int sidx = 0; sidx < n + K; ++sidx)
+        for (int q = 0; q < K; ++q) {
+          const int t = sidx - q;
+          int v = -1;
+          if (t >= 0 && t < n) v = (t < p.e - p.s) ? (int)(((long)y_off[i] + p.s + t) * K + q) : -(p.term + 2);
+          tg.push_back(v);
+        }
+      col += n + K;
+      if (j + 1 < pieces.size()) {                 // placeholder: values = emb_inds_use + emb_inds_use (:274)
+        pa.seg[nseg++] = Segment{col, 1, 0, 0, -1, mv[j % M]};
+        for (int q = 0; q < K; ++q) tg.push_back(-1);
+        col += 1;
+      }
+    }
+    pa.n_seg = nseg; pa.n_cols = col;
+    if (Lx + col > e->S_max) return fail(e, VC_ECAP, "utterance %d: %d positions, max_positions is %d", i, Lx + col, e->S_max);
+  }
+  HIPCHK(e, hipMemsetAsync(e->ce_sum, 0, sizeof(double) * VC_MAX_CODEBOOKS, s));
+  HIPCHK(e, hipMemsetAsync(e->ce_hits, 0, sizeof(long long) * VC_MAX_CODEBOOKS, s));
+  HIPCHK(e, hipMemsetAsync(e->ce_cnt, 0, sizeof(long long) * VC_MAX_CODEBOOKS, s));
+  HIPCHK(e, hipEventRecord(e->ev[0], s));
+  const int chunk = e->prefill_rows_per_pass;
+  int64_t rows_out = 0;
+  size_t i0 = 0;
+  std::vector<int> tg_host;
+  while (i0 < (size_t)B) {                         // groups of utterances that fit the row arena (as prefill_batch)
+    size_t i1 = i0;
+    int R = 0;
+    auto rows_of = [](const PromptArgs& pa) { return ((pa.Lx + pa.n_cols) + 15) & ~15; };
+    while (i1 < (size_t)B && (i1 == i0 || R + rows_of(pas[i1]) <= e->emb_cap)) { R += rows_of(pas[i1]); ++i1; }
+    if (R > e->emb_cap) return fail(e, VC_ECAP, "an utterance of %d rows does not fit the row arena of %d rows", R, e->emb_cap);
+    HIPCHK(e, hipMemsetAsync(e->pre_row_pos, 0xFF, (size_t)R * sizeof(int), s));
+    HIPCHK(e, hipMemsetAsync(e->pre_row_seq, 0, (size_t)R * sizeof(int), s));
+    HIPCHK(e, hipMemsetAsync(e->emb, 0, (size_t)R * e->d * sizeof(float), s));
+    tg_host.assign((size_t)R * K, -1);
+    int row0 = 0;
+    for (size_t i = i0; i < i1; ++i) {
+      PromptArgs& pa = pas[i];
+      const int rows = pa.Lx + pa.n_cols;
+      pa.seq = (int)(i - i0); pa.row0 = row0;     // a cache slot per utterance of the group
+      pa.emb = e->emb; pa.row_seq = e->pre_row_seq; pa.row_pos = e->pre_row_pos; pa.err = e->err_flag;
+      pa.logit_row = nullptr;
+      HIPCHK(e, vc_launch_prompt(pa, s));
+      if ((size_t)rows * K != tgts[i].size()) return fail(e, VC_ESTATE, "internal: target table of utterance %d", (int)i);
+      std::copy(tgts[i].begin(), tgts[i].end(), tg_host.begin() + (size_t)row0 * K);
+      row0 += (rows + 15) & ~15;
+    }
+    // the host table must outlive the copy: synchronous copy (a few hundred KB, once per group)
+    HIPCHK(e, hipStreamSynchronize(s));
+    HIPCHK(e, hipMemcpy(e->ce_tgt, tg_host.data(), (size_t)R * K * sizeof(int), hipMemcpyHostToDevice));
+    for (int r0 = 0; r0 < R; r0 += chunk) {
+      RowSrc rs{};
+      rs.h_in = e->emb + (size_t)r0 * e->d;
+      rs.row_seq = e->pre_row_seq + r0; rs.row_pos = e->pre_row_pos + r0;
+      rs.n_rows = std::min(chunk, R - r0);
+      if (rs.n_rows > VC_ROWS) { rs.nsplit = 1; rs.tiled = getenv("VC_NO_TILE_ATTN") ? 0 : 1; rc = prefill_rows(e, rs, s); }
+      else { rs.nsplit = attn_nsplit(e, rs.n_rows); rc = forward_rows(e, rs, s); }
+      if (rc) return rc;
+      for (int g0 = 0; g0 < rs.n_rows; g0 += VC_ROWS) {
+        const int n = std::min(VC_ROWS, rs.n_rows - g0);
+        if ((rc = run_heads16(e, nullptr, n, g0, 0, nullptr, s))) return rc;
+        CeArgs ca;
+        memset(&ca, 0, sizeof ca);
+        ca.logits = e->logits; ca.y = y_dev; ca.tgt = e->ce_tgt + (size_t)(r0 + g0) * K;
+        ca.nll = e->ce_nll + (size_t)(r0 + g0) * K; ca.hit = e->ce_hit + (size_t)(r0 + g0) * K;
+        ca.n_rows = n; ca.K = K; ca.V = e->V; ca.err = e->err_flag;
+        HIPCHK(e, vc_launch_ce(ca, s));
+      }
+    }
+    CeReduceArgs ra;
+    memset(&ra, 0, sizeof ra);
+    ra.nll = e->ce_nll; ra.hit = e->ce_hit; ra.tgt = e->ce_tgt; ra.n_rows = R; ra.K = K;
+    ra.nll_sum = e->ce_sum; ra.hits = e->ce_hits; ra.count = e->ce_cnt;
+    HIPCHK(e, vc_launch_ce_reduce(ra, s));
+    if (nll_dev && tgt_dev) {                      // parity hook: the per-row terms of this group, appended
+      if (rows_out + R > nll_cap) return fail(e, VC_ECAP, "nll capacity %lld < %lld rows", (long long)nll_cap, (long long)(rows_out + R));
+      HIPCHK(e, hipMemcpyAsync(nll_dev + rows_out * K, e->ce_nll, (size_t)R * K * sizeof(float), hipMemcpyDeviceToDevice, s));
+      HIPCHK(e, hipMemcpyAsync(tgt_dev + rows_out * K, e->ce_tgt, (size_t)R * K * sizeof(int), hipMemcpyDeviceToDevice, s));
+    }
+    rows_out += R;
+    HIPCHK(e, hipStreamSynchronize(s));          // the next group reuses the arena, the target table and the cache slots
+    i0 = i1;
+  }
+  HIPCHK(e, hipEventRecord(e->ev[1], s));
+  rc = check_err_flag(e, s);
+  if (rc) return rc;
+  double h_sum[VC_MAX_CODEBOOKS];
+  long long h_hits[VC_MAX_CODEBOOKS], h_cnt[VC_MAX_CODEBOOKS];
+  HIPCHK(e, hipMemcpy(h_sum, e->ce_sum, sizeof h_sum, hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(h_hits, e->ce_hits, sizeof h_hits, hipMemcpyDeviceToHost));
+  HIPCHK(e, hipMemcpy(h_cnt, e->ce_cnt, sizeof h_cnt, hipMemcpyDeviceToHost));
+  for (int k = 0; k < K; ++k) { nll_sum[k] = h_sum[k]; hits[k] = h_hits[k]; }
+  *n_targets = h_cnt[0];
+  if (n_rows_out) *n_rows_out = rows_out;
+  HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
+  e->ms[1] = 0.f; e->ms[2] = e->ms[0];
   return VC_OK;
 }
 

@@ -698,6 +698,78 @@ __global__ void assemble_k(const AssembleArgs a) {
     a.res[(long)j * a.res_cap + a.dst0[p] + t] = v;
   }
 }
+// ---- training objective (VoiceCraft.forward, models/voicecraft.py:535-543): F.cross_entropy term and top-10 membership
+// of one logits row per block.  Two passes over the V logits of the row (maximum; sum of exponentials + number of
+// logits above the target's), fp32 like torch's log_softmax.  A target tied with the 10th value counts as a hit
+// (torch.topk picks ten indices among equals arbitrarily).
+__global__ __launch_bounds__(256) void ce_rows_k(const CeArgs a) {
+  __shared__ float s_f[4];
+  __shared__ int s_i[4];
+  const int r = blockIdx.x, k = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long o = (long)r * a.K + k;
+  const int t = a.tgt[o];
+  if (t == -1) {
+    if (tid == 0) { a.nll[o] = 0.f; a.hit[o] = 0; }
+    return;
+  }
+  long tok = t >= 0 ? a.y[t] : (long)(-(t + 2));
+  if (tok < 0 || tok >= a.V) { if (tid == 0) *a.err = 1; tok = 0; }
+  const float* row = a.logits + o * a.V;
+  float m = -INFINITY;
+  for (int i = tid; i < a.V; i += 256) m = fmaxf(m, row[i]);
+  m = wave_max(m);
+  if (lane == 0) s_f[wave] = m;
+  __syncthreads();
+  m = fmaxf(fmaxf(s_f[0], s_f[1]), fmaxf(s_f[2], s_f[3]));
+  __syncthreads();
+  const float tl = row[tok];
+  float se = 0.f;
+  int gt = 0;
+  for (int i = tid; i < a.V; i += 256) {
+    const float v = row[i];
+    se += expf(v - m);
+    gt += (v > tl) ? 1 : 0;
+  }
+  se = wave_sum(se);
+  gt = wave_sum_i(gt);
+  if (lane == 0) { s_f[wave] = se; s_i[wave] = gt; }
+  __syncthreads();
+  if (tid == 0) {
+    const float tot = (s_f[0] + s_f[1]) + (s_f[2] + s_f[3]);
+    const int above = (s_i[0] + s_i[1]) + (s_i[2] + s_i[3]);
+    a.nll[o] = (logf(tot) + m) - tl;
+    a.hit[o] = above < 10 ? 1 : 0;
+  }
+}
+hipError_t vc_launch_ce(const CeArgs& a, hipStream_t s) {
+  if (a.n_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ce_rows_k, dim3(a.n_rows, a.K), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+// one block per codebook; thread i adds rows i, i + 256, ... in order, then a fixed tree: the same sum on every run
+__global__ __launch_bounds__(256) void ce_reduce_k(const CeReduceArgs a) {
+  __shared__ double s_d[256];
+  __shared__ long long s_h[256], s_c[256];
+  const int k = blockIdx.x, tid = threadIdx.x;
+  double acc = 0.0;
+  long long h = 0, c = 0;
+  for (long r = tid; r < a.n_rows; r += 256) {
+    const long o = r * a.K + k;
+    if (a.tgt[o] != -1) { acc += (double)a.nll[o]; h += a.hit[o]; c += 1; }
+  }
+  s_d[tid] = acc; s_h[tid] = h; s_c[tid] = c;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) { s_d[tid] += s_d[tid + w]; s_h[tid] += s_h[tid + w]; s_c[tid] += s_c[tid + w]; }
+    __syncthreads();
+  }
+  if (tid == 0) { a.nll_sum[k] += s_d[0]; a.hits[k] += s_h[0]; a.count[k] += s_c[0]; }
+}
+hipError_t vc_launch_ce_reduce(const CeReduceArgs& a, hipStream_t s) {
+  if (a.n_rows <= 0) return hipSuccess;
+  hipLaunchKernelGGL(ce_reduce_k, dim3(a.K), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
 hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s) {
   if (a.n_piece <= 0) return hipSuccess;
   hipLaunchKernelGGL(assemble_k, dim3(8, a.n_piece), dim3(256), 0, s, a);

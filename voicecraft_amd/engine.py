@@ -37,6 +37,41 @@ def _sine_table(n: int, d: int) -> torch.Tensor:
     return pe.contiguous()
 
 
+def draw_mask_intervals(args, y_lens):
+    """`VoiceCraft.prepare_mask_intervals` (models/voicecraft.py:198-237), call for call on Python's `random` (and
+    torch's generator for the Poisson option), so that `random.seed(n)` gives the reference's intervals.  Needs the
+    training fields of `args` (mask_sample_dist, mask_len_min, mask_len_max, min_gap, max_n_spans).
+    Returns (mask_intervals, non_mask_intervals) as the reference does."""
+    import random
+    a = args
+    mask_intervals, non_mask_intervals = [], []
+    for y_len in [int(v) for v in y_lens]:
+        if a.mask_sample_dist == "uniform":
+            n_spans = random.choice(range(1, a.max_n_spans + 1))
+        elif "poisson" in a.mask_sample_dist.lower():
+            param = float(a.mask_sample_dist[len("poisson"):])
+            n_spans = int(torch.poisson(torch.tensor([param])).clamp(1, a.max_n_spans).item())
+        else:
+            raise AssertionError(f"mask_sample_dist {a.mask_sample_dist!r}")
+        starts = sorted(random.sample(range(1, y_len - 1 - a.mask_len_min), n_spans))
+        for j in range(len(starts) - 1, 0, -1):
+            if starts[j] - starts[j - 1] < a.min_gap:
+                del starts[j]
+        assert len(starts) > 0, f"there is no masked span left, y_len: {y_len}, sampled n_spans: {n_spans}"
+        temp = starts + [y_len]
+        gaps = [temp[j + 1] - temp[j] for j in range(len(temp) - 1)]
+        ends = []
+        for start, gap in zip(starts, gaps):
+            mask_len = random.randint(a.mask_len_min, a.mask_len_max)
+            if mask_len > gap - 1:
+                mask_len = random.randint(1, gap - 1)
+            ends.append(start + mask_len)
+        mask_intervals.append([(s, e) for s, e in zip(starts, ends)])
+        non_mask_intervals.append([(ns, ne) for ns, ne in zip([0] + ends, starts + [y_len])])
+    return mask_intervals, non_mask_intervals
+
+
+
 class VoiceCraftEngine:
     """Drop-in for `VoiceCraft(args)` + `load_state_dict` + `.to(device).eval()` on the inference path.
 
@@ -267,6 +302,92 @@ class VoiceCraftEngine:
         if logits is not None:
             return outs, logits
         return outs
+
+    # ---- the training objective, teacher-forced.  EXPERIMENTAL: not yet validated on hardware.
+    def draw_mask_intervals(self, y_lens):
+        """`VoiceCraft.prepare_mask_intervals` (models/voicecraft.py:198-237): see the module-level function."""
+        return draw_mask_intervals(self.args, y_lens)
+
+    @torch.no_grad()
+    def forward(self, batch, mask_intervals=None, mask_values=None, _per_row: bool = False):
+        """`VoiceCraft.forward` (models/voicecraft.py:472-559) as an evaluation pass: batch = {"x" [B,Lx], "x_lens" [B],
+        "y" [B,K,T], "y_lens" [B]} exactly as the reference's collate gives it; returns the reference's dict
+        (`loss` = sum over codebooks of weight * summed cross-entropy, `top10acc`, `top10acc_by_codebook`,
+        `effective_ntoken`).  The reference draws the mask intervals inside (`prepare_mask_intervals`); pass them as
+        `mask_intervals` (list per utterance of (start, end) frames) to evaluate fixed spans, otherwise they are drawn
+        by the restated procedure.  `mask_values[i]` = the utterance's `emb_inds_use` (default 0..M-1; the reference
+        shuffles them when `shuffle_mask_embedding` is set).  No gradients: this engine does not train."""
+        import ast
+        import random
+        x, x_lens, y, y_lens = batch["x"], batch["x_lens"], batch["y"], batch["y_lens"]
+        if len(x) == 0:
+            return None
+        K = self.args.n_codebooks
+        assert x.ndim == 2, x.shape
+        assert x_lens.ndim == 1, x_lens.shape
+        assert y.ndim == 3 and y.shape[1] == K, y.shape
+        assert y_lens.ndim == 1, y_lens.shape
+        B = int(x.shape[0])
+        assert B <= self.max_seqs, (B, self.max_seqs)
+        if mask_intervals is None:
+            mask_intervals, _ = self.draw_mask_intervals(y_lens)
+        if mask_values is None:
+            mask_values = []
+            for iv in mask_intervals:
+                inds = list(range(self.args.max_n_spans))
+                if getattr(self.args, "shuffle_mask_embedding", 0):
+                    random.shuffle(inds)                                   # insert_mask, :270-272
+                mask_values.append(inds[: len(iv)])
+        xs = [x[i, : int(x_lens[i])].to(torch.int64).reshape(-1) for i in range(B)]
+        ys = [y[i, :, : int(y_lens[i])].to(torch.int64).transpose(0, 1).reshape(-1, K) for i in range(B)]     # time-major
+        xcat = torch.cat(xs).to(self.device).contiguous()
+        ycat = torch.cat(ys).to(self.device).contiguous()
+        if self.args.special_first:
+            ycat = ycat + int(self.args.n_special)
+        xo, yo, so = [0], [0], [0]
+        flat_iv, flat_mv = [], []
+        rows_cap = 0
+        for i in range(B):
+            xo.append(xo[-1] + int(xs[i].numel()))
+            yo.append(yo[-1] + int(ys[i].shape[0]))
+            M = len(mask_intervals[i])
+            assert M == len(mask_values[i]) and M >= 1, (M, mask_values[i])
+            so.append(so[-1] + M)
+            for (s0, e0) in mask_intervals[i]:
+                flat_iv += [int(s0), int(e0)]
+            flat_mv += [int(v) for v in mask_values[i]]
+            rows_cap += ((int(xs[i].numel()) + int(ys[i].shape[0]) + (2 * M + 1) * (K + 1) + 2 * M) + 15) // 16 * 16
+        c32 = C.c_int32
+        nll_sum = (C.c_double * K)()
+        hits = (C.c_int64 * K)()
+        n_targets = C.c_int64(0)
+        n_rows = C.c_int64(0)
+        nll = tgt = None
+        if _per_row:
+            nll = torch.zeros((rows_cap, K), dtype=torch.float32, device=self.device)
+            tgt = torch.full((rows_cap, K), -1, dtype=torch.int32, device=self.device)
+        rc = self.lib.vc_eval_forward(self._h, B, C.c_void_p(xcat.data_ptr()), (c32 * (B + 1))(*xo),
+                                      C.c_void_p(ycat.data_ptr()), (c32 * (B + 1))(*yo),
+                                      (c32 * len(flat_iv))(*flat_iv), (c32 * (B + 1))(*so), (c32 * len(flat_mv))(*flat_mv),
+                                      nll_sum, hits, C.byref(n_targets),
+                                      C.c_void_p(nll.data_ptr()) if nll is not None else None,
+                                      C.c_void_p(tgt.data_ptr()) if tgt is not None else None,
+                                      rows_cap if _per_row else 0, C.byref(n_rows), self._stream())
+        check(rc, self._h, "vc_eval_forward")
+        cw = getattr(self.args, "codebook_weight", None)
+        cw = [float(w) for w in ast.literal_eval(cw)] if cw else [1.0] * K
+        dev = self.device
+        by_cb = [torch.tensor(float(hits[k]), device=dev) for k in range(K)]
+        out = {
+            "loss": torch.tensor(sum(nll_sum[k] * cw[k] for k in range(K)), dtype=torch.float32, device=dev),
+            "top10acc": torch.tensor(float(sum(hits[k] for k in range(K))), device=dev),
+            "top10acc_by_codebook": by_cb,
+            "effective_ntoken": torch.tensor(int(n_targets.value) * K).to(dev),
+        }
+        if _per_row:
+            out["_nll_rows"], out["_tgt_rows"] = nll[: n_rows.value], tgt[: n_rows.value]
+            out["_nll_sum"] = [float(nll_sum[k]) for k in range(K)]
+        return out
 
     @torch.no_grad()
     def inference_tts_long(self, x_prompt, x_sentences, y, top_k: int = -100, top_p: float = 1.0, temperature: float = 1.0,
