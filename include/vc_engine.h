@@ -169,6 +169,13 @@ int vc_eval_forward(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_
                     double* nll_sum, int64_t* hits, int64_t* n_targets,
                     float* nll_dev, int32_t* tgt_dev, int64_t nll_cap, int64_t* n_rows_out, void* stream);
 
+/* Host-only half of vc_eval_forward for ONE utterance (no engine, no GPU: checked against the oracle in the CPU tests):
+ * the segment table of its training sequence, seg_out int32 [n_seg][6] = {first column, columns, first source frame,
+ * source frames, appended terminator or -1, mask_embedding row or -1}, the number of audio columns, and the target
+ * table tgt_out int32 [Lx + n_cols][K] as described above (y_frame_off = the utterance's first frame inside y_dev). */
+int vc_eval_layout(const vc_model_cfg* cfg, int Lx, int T, const int32_t* spans, int M, const int32_t* mask_values,
+                   int y_frame_off, int32_t* seg_out, int* n_seg, int* n_cols, int32_t* tgt_out, int64_t tgt_cap);
+
 /* ---- delayed-codebook pattern (models/codebooks_patterns.py:151-176, :222-245 and
  * the un-shift at models/voicecraft.py:1125-1139).  Integer, bit-exact.  No engine needed.
  *   shift : z [B][K][T]  -> out [B][K][T+K]   out[q][s] = z[q][s-1-q] or `special`

@@ -522,7 +522,10 @@ class VoiceCraftOracle:
         by_cb = [t * n for t, n in zip(top10, ntok)]
         return {"loss": sum(l * n * c for l, n, c in zip(loss, ntok, cw)), "top10acc": sum(by_cb),
                 "top10acc_by_codebook": by_cb, "effective_ntoken": torch.tensor(sum(ntok)),
-                "_per_token_logits": lg, "_targets": tg}
+                "_per_token_logits": lg, "_targets": tg,
+                # test hooks: per sample, the concatenated columns [K,S_i], {placeholder column: mask_embedding row} and
+                # the per-piece targets
+                "_cols": cols, "_mask_pos": mask_pos, "_targets_per_sample": targets}
 
 
 def prompt_columns_tts(y_TK: np.ndarray, empty: int) -> np.ndarray:

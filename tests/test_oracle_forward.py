@@ -67,3 +67,62 @@ def test_interval_sampler_reproduces_the_reference_under_the_same_seed():
         got_n = np.array([[i, s0, e0] for i, v in enumerate(nmi) for (s0, e0) in v], dtype=np.int64)
         assert np.array_equal(got_m, g[f"mask_{ci}"]), (ci, got_m, g[f"mask_{ci}"])
         assert np.array_equal(got_n, g[f"nonmask_{ci}"]), ci
+
+
+def test_engine_host_layout_equals_the_oracle_layout():
+    """vc_eval_layout (the host half of vc_eval_forward: segment table + target table of one utterance) against the oracle's
+    rearranged columns, placeholder positions and targets - no GPU involved, the library is only loaded."""
+    import ctypes as C
+    from voicecraft_amd import _lib
+    lib = _lib.load()
+    for name in sorted(FORWARD_CASES):
+        spec, args, sd, batch = build_forward_case(name)
+        K = args.n_codebooks
+        orc = VoiceCraftOracle(args, sd)
+        ref = orc.forward(batch, spec["spans"])
+        cfg = _lib.ModelCfg(d_model=args.d_model, nhead=args.nhead, num_layers=args.num_decoder_layers, n_codebooks=K,
+                            audio_vocab_size=args.audio_vocab_size, n_special=int(args.n_special), text_rows=args.text_vocab_size + 1,
+                            head_hidden=args.audio_vocab_size // 2, empty_token=args.empty_token, eog=args.eog,
+                            audio_pad_token=args.audio_pad_token, eos=args.eos if args.eos > 0 else -1,
+                            reduced_eog=int(args.reduced_eog or 0), encodec_sr=50, max_n_spans=args.max_n_spans, max_seqs=4, max_positions=512)
+        y_off = 0
+        for i, spans in enumerate(spec["spans"]):
+            Lx, T, M = int(batch["x_lens"][i]), int(batch["y_lens"][i]), len(spans)
+            yi = batch["y"][i, :, :T].numpy()                                   # [K,T]
+            flat = (C.c_int32 * (2 * M))(*[v for se in spans for v in se])
+            mv = (C.c_int32 * M)(*range(M))
+            seg = (C.c_int32 * (32 * 6))()
+            n_seg, n_cols = C.c_int(0), C.c_int(0)
+            cap = (Lx + T + 64) * K * 2
+            tgt = (C.c_int32 * cap)()
+            rc = lib.vc_eval_layout(C.byref(cfg), Lx, T, flat, M, mv, y_off, seg, C.byref(n_seg), C.byref(n_cols), tgt, cap)
+            assert rc == 0, (name, i, rc)
+            want_cols = ref["_cols"][i].numpy()                                  # [K,S]
+            S = want_cols.shape[1]
+            assert n_cols.value == S, (name, i, n_cols.value, S)
+            segs = np.array(seg[: 6 * n_seg.value]).reshape(-1, 6)
+            # what prompt_k puts into every audio column (vc_tokens.hip: token s-1-q of the piece, else `empty`)
+            got_cols = np.full((K, S), -7, dtype=np.int64)
+            got_mask = {}
+            for col0, ncols, src0, src_len, term, mval in segs:
+                for s in range(ncols):
+                    if mval >= 0:
+                        got_mask[col0 + s] = int(mval)
+                        got_cols[:, col0 + s] = args.eog                          # the reference's placeholder token (:283)
+                        continue
+                    n = src_len + (1 if term >= 0 else 0)
+                    for q in range(K):
+                        j = s - 1 - q
+                        got_cols[q, col0 + s] = (yi[q, src0 + j] if j < src_len else term) if 0 <= j < n else args.empty_token
+            assert got_mask == ref["_mask_pos"][i], (name, i)
+            assert np.array_equal(got_cols, want_cols), (name, i)
+            # targets, codebook by codebook in row order == the oracle's per-piece targets concatenated
+            t = np.array(tgt[: (Lx + S) * K]).reshape(Lx + S, K)
+            assert (t[:Lx] == -1).all()
+            want_t = torch.cat(ref["_targets_per_sample"][i], dim=1).numpy()     # [K, N_i]
+            flat_y = batch["y"][i, :, :T].numpy().T.reshape(-1)                  # this utterance's [frames][K], frames from y_off
+            for q in range(K):
+                col = t[Lx:, q]
+                vals = [int(flat_y[v - y_off * K]) if v >= 0 else -(v + 2) for v in col if v != -1]
+                assert vals == [int(v) for v in want_t[q]], (name, i, q)
+            y_off += T

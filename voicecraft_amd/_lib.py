@@ -47,6 +47,8 @@ PROTOTYPES = {
                                   C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64),
                                   C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.c_void_p]),
+    "vc_eval_layout": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32), C.c_int, C.POINTER(C.c_int32), C.c_int,
+                                 C.POINTER(C.c_int32), C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int32), C.c_int64]),
     "vc_debug_sample": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(SampleCfg), C.c_int, C.c_void_p, C.c_void_p]),
     "vc_edit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_int32), C.c_int,
                           C.POINTER(C.c_int32), C.POINTER(SampleCfg), C.c_void_p, C.c_int, C.c_void_p, C.c_int,

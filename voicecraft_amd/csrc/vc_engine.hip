@@ -1176,6 +1176,61 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   return VC_OK;
 }
 
+// Layout of one utterance's training sequence (host only; also exported as vc_eval_layout so that it can be checked
+// against the oracle without a GPU): the segment table prompt_k consumes (rearrange :239-252, shift :254-262,
+// insert_mask :264-288: every non-masked piece, then every masked piece + eog, a placeholder after each piece but the
+// last) and, per row of [text ; audio columns] and codebook, the target: piece column s, codebook q predicts piece token
+// t = s - q (revert_pattern_logits with is_model_output, codebooks_patterns.py:209-215, :247-266).
+// tgt: >= 0 index into the call's y ([frames][K], y_frame_off = first frame of this utterance); -1 none; <= -2 constant.
+int eval_layout(const vc_model_cfg& c, int K, int Lx, int T, const int32_t* iv, int M, const int32_t* mv, int y_frame_off,
+                Segment* seg, int* n_seg, int* n_cols, std::vector<int>* tgt, std::string* why) {
+  char buf[160];
+  if (Lx < 1 || T < 1) { *why = "empty text or audio"; return 1; }
+  if (M < 1 || M > c.max_n_spans) { snprintf(buf, sizeof buf, "%d spans outside [1,%d]", M, c.max_n_spans); *why = buf; return 1; }
+  for (int j = 0; j < M; ++j) {
+    if (mv[j] < 0 || mv[j] >= c.max_n_spans) { *why = "mask value out of range"; return 1; }
+    const int lo = j ? iv[2 * (j - 1) + 1] : 0;
+    if (iv[2 * j] < lo || iv[2 * j + 1] < iv[2 * j] || iv[2 * j + 1] > T) {
+      snprintf(buf, sizeof buf, "mask intervals must be ordered, disjoint and inside [0,%d]", T); *why = buf; return 1;
+    }
+  }
+  struct Piece { int s, e, term; };
+  std::vector<Piece> pieces;
+  for (int j = 0; j <= M; ++j) {                   // non-masked pieces, the terminator as rearrange() places it
+    const int ps = j ? iv[2 * (j - 1) + 1] : 0, pe = (j == M) ? T : iv[2 * j];
+    int term;
+    if (c.eos > 0) term = (j == M) ? c.eos : -1;
+    else if (c.reduced_eog) term = (j == M) ? c.eog : -1;
+    else term = c.eog;
+    pieces.push_back(Piece{ps, pe, term});
+  }
+  for (int j = 0; j < M; ++j) pieces.push_back(Piece{iv[2 * j], iv[2 * j + 1], c.eog});     // masked pieces, always + eog
+  if ((int)(2 * pieces.size()) > VC_MAX_SEG) { *why = "too many segments"; return 1; }
+  int col = 0, ns = 0;
+  tgt->assign((size_t)Lx * K, -1);                 // text rows carry no target
+  for (size_t j = 0; j < pieces.size(); ++j) {
+    const Piece& p = pieces[j];
+    const int n = (p.e - p.s) + (p.term >= 0 ? 1 : 0);
+    if (n <= 0) { snprintf(buf, sizeof buf, "piece %d is empty (the reference raises inside get_pattern)", (int)j); *why = buf; return 1; }
+    seg[ns++] = Segment{col, n + K, p.s, p.e - p.s, p.term, -1};
+    for (int sidx = 0; sidx < n + K; ++sidx)
+      for (int q = 0; q < K; ++q) {
+        const int t = sidx - q;
+        int v = -1;
+        if (t >= 0 && t < n) v = (t < p.e - p.s) ? (int)(((long)y_frame_off + p.s + t) * K + q) : -(p.term + 2);
+        tgt->push_back(v);
+      }
+    col += n + K;
+    if (j + 1 < pieces.size()) {                   // placeholder: values = emb_inds_use + emb_inds_use (:274)
+      seg[ns++] = Segment{col, 1, 0, 0, -1, mv[j % M]};
+      for (int q = 0; q < K; ++q) tgt->push_back(-1);
+      col += 1;
+    }
+  }
+  *n_seg = ns; *n_cols = col;
+  return 0;
+}
+
 // ------------------------------------------------------------------------------------- training objective
 // VoiceCraft.forward (voicecraft.py:472-559) with given mask intervals.  EXPERIMENTAL (not yet run on hardware).
 // The decoder pass is the prefill's (row stream over all utterances, block GEMM + tile attention); after every pass the
@@ -1203,62 +1258,18 @@ extern "C" int vc_eval_forward(vc_engine* e, int B, const int64_t* x_dev, const 
     if ((rc = dalloc(e, &e->ce_hits, (size_t)VC_MAX_CODEBOOKS))) return rc;
     if ((rc = dalloc(e, &e->ce_cnt, (size_t)VC_MAX_CODEBOOKS))) return rc;
   }
-  // ---- per utterance: the segment table of its training sequence (rearrange :239-252, shift :254-262, insert_mask
-  //      :264-288) and the target of every (row, codebook): piece column s, codebook q predicts piece token t = s - q
-  //      (revert_pattern_logits with is_model_output, codebooks_patterns.py:209-215, :247-266)
+  // ---- per utterance: the segment table of its training sequence and the target of every (row, codebook)
   std::vector<PromptArgs> pas(B);
   std::vector<std::vector<int>> tgts(B);          // [rows_i][K]
   for (int i = 0; i < B; ++i) {
     const int Lx = x_off[i + 1] - x_off[i], T = y_off[i + 1] - y_off[i], M = span_off[i + 1] - span_off[i];
-    if (Lx < 1 || T < 1) return fail(e, VC_EINVAL, "utterance %d: empty text or audio", i);
-    if (M < 1 || M > c.max_n_spans) return fail(e, VC_EINVAL, "utterance %d: %d spans outside [1,%d]", i, M, c.max_n_spans);
-    const int32_t* iv = spans + 2 * (size_t)span_off[i];
-    const int32_t* mv = mask_values + span_off[i];
-    for (int j = 0; j < M; ++j) {
-      if (mv[j] < 0 || mv[j] >= c.max_n_spans) return fail(e, VC_EINVAL, "utterance %d: mask value out of range", i);
-      const int lo = j ? iv[2 * (j - 1) + 1] : 0;
-      if (iv[2 * j] < lo || iv[2 * j + 1] < iv[2 * j] || iv[2 * j + 1] > T)
-        return fail(e, VC_EINVAL, "utterance %d: mask intervals must be ordered, disjoint and inside [0,%d]", i, T);
-    }
     PromptArgs& pa = pas[i];
-    fill_prompt_common(e, pa, x_dev + x_off[i], Lx, y_dev + (size_t)y_off[i] * K, T);
-    struct Piece { int s, e, term; };
-    std::vector<Piece> pieces;
-    for (int j = 0; j <= M; ++j) {                 // non-masked pieces, the terminator as rearrange() places it
-      const int ps = j ? iv[2 * (j - 1) + 1] : 0, pe = (j == M) ? T : iv[2 * j];
-      int term;
-      if (c.eos > 0) term = (j == M) ? c.eos : -1;
-      else if (c.reduced_eog) term = (j == M) ? c.eog : -1;
-      else term = c.eog;
-      pieces.push_back(Piece{ps, pe, term});
-    }
-    for (int j = 0; j < M; ++j) pieces.push_back(Piece{iv[2 * j], iv[2 * j + 1], c.eog});   // masked pieces, always + eog
-    if ((int)(2 * pieces.size()) > VC_MAX_SEG) return fail(e, VC_EINVAL, "too many segments");
-    int col = 0, nseg = 0;
-    const int rows_text = Lx;
-    std::vector<int>& tg = tgts[i];
-    tg.assign((size_t)rows_text * K, -1);
-    for (size_t j = 0; j < pieces.size(); ++j) {
-      const Piece& p = pieces[j];
-      const int n = (p.e - p.s) + (p.term >= 0 ? 1 : 0);
-      if (n <= 0) return fail(e, VC_EINVAL, "utterance %d: piece %d is empty (the reference raises inside get_pattern)", i, (int)j);
-      pa.seg[nseg++] = Segment{col, n + K, p.s, p.e - p.s, p.term, -1};
-      for (int sidx = 0; sidx < n + K; ++sidx)
-        for (int q = 0; q < K; ++q) {
-          const int t = sidx - q;
-          int v = -1;
-          if (t >= 0 && t < n) v = (t < p.e - p.s) ? (int)(((long)y_off[i] + p.s + t) * K + q) : -(p.term + 2);
-          tg.push_back(v);
-        }
-      col += n + K;
-      if (j + 1 < pieces.size()) {                 // placeholder: values = emb_inds_use + emb_inds_use (:274)
-        pa.seg[nseg++] = Segment{col, 1, 0, 0, -1, mv[j % M]};
-        for (int q = 0; q < K; ++q) tg.push_back(-1);
-        col += 1;
-      }
-    }
-    pa.n_seg = nseg; pa.n_cols = col;
-    if (Lx + col > e->S_max) return fail(e, VC_ECAP, "utterance %d: %d positions, max_positions is %d", i, Lx + col, e->S_max);
+    fill_prompt_common(e, pa, x_dev + x_off[i], std::max(Lx, 0), y_dev + (size_t)y_off[i] * K, std::max(T, 0));
+    std::string why;
+    if (eval_layout(c, K, Lx, T, spans + 2 * (size_t)span_off[i], M, mask_values + span_off[i], y_off[i], pa.seg, &pa.n_seg,
+                    &pa.n_cols, &tgts[i], &why))
+      return fail(e, VC_EINVAL, "utterance %d: %s", i, why.c_str());
+    if (Lx + pa.n_cols > e->S_max) return fail(e, VC_ECAP, "utterance %d: %d positions, max_positions is %d", i, Lx + pa.n_cols, e->S_max);
   }
   HIPCHK(e, hipMemsetAsync(e->ce_sum, 0, sizeof(double) * VC_MAX_CODEBOOKS, s));
   HIPCHK(e, hipMemsetAsync(e->ce_hits, 0, sizeof(long long) * VC_MAX_CODEBOOKS, s));
@@ -1339,6 +1350,22 @@ extern "C" int vc_eval_forward(vc_engine* e, int B, const int64_t* x_dev, const 
   if (n_rows_out) *n_rows_out = rows_out;
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   e->ms[1] = 0.f; e->ms[2] = e->ms[0];
+  return VC_OK;
+}
+
+extern "C" int vc_eval_layout(const vc_model_cfg* cfg, int Lx, int T, const int32_t* spans, int M, const int32_t* mask_values,
+                              int y_frame_off, int32_t* seg_out, int* n_seg, int* n_cols, int32_t* tgt_out, int64_t tgt_cap) {
+  if (!cfg || !spans || !mask_values || !seg_out || !n_seg || !n_cols || !tgt_out) return VC_EINVAL;
+  Segment seg[VC_MAX_SEG];
+  std::vector<int> tgt;
+  std::string why;
+  if (eval_layout(*cfg, cfg->n_codebooks, Lx, T, spans, M, mask_values, y_frame_off, seg, n_seg, n_cols, &tgt, &why)) return VC_EINVAL;
+  if ((int64_t)tgt.size() > tgt_cap) return VC_ECAP;
+  for (int i = 0; i < *n_seg; ++i) {
+    int32_t* o = seg_out + 6 * i;
+    o[0] = seg[i].col0; o[1] = seg[i].ncols; o[2] = seg[i].src0; o[3] = seg[i].src_len; o[4] = seg[i].term; o[5] = seg[i].mask_value;
+  }
+  std::copy(tgt.begin(), tgt.end(), tgt_out);
   return VC_OK;
 }
 
