@@ -126,3 +126,23 @@ def test_engine_host_layout_equals_the_oracle_layout():
                 vals = [int(flat_y[v - y_off * K]) if v >= 0 else -(v + 2) for v in col if v != -1]
                 assert vals == [int(v) for v in want_t[q]], (name, i, q)
             y_off += T
+
+
+def test_the_kernel_definitions_of_loss_and_hit_agree_with_the_reference():
+    """ce_rows_k's arithmetic, restated in numpy on the oracle's logits: nll = log(sum exp(v - max)) + max - v[target];
+    hit = fewer than ten logits above the target's.  Summed per codebook this must give the fixture's loss and hits."""
+    for name in sorted(FORWARD_CASES):
+        spec, args, sd, batch = build_forward_case(name)
+        g = np.load(os.path.join(GOLDEN, f"{name}.npz"))
+        ref = VoiceCraftOracle(args, sd).forward(batch, spec["spans"])
+        lg, tg = ref["_per_token_logits"].numpy().astype(np.float32), ref["_targets"].numpy()
+        cw = weights_of(spec, args.n_codebooks)
+        loss, hits = 0.0, []
+        for k in range(lg.shape[0]):
+            m = lg[k].max(axis=1, keepdims=True)
+            tl = np.take_along_axis(lg[k], tg[k][:, None], axis=1)
+            nll = np.log(np.exp(lg[k] - m).sum(axis=1, dtype=np.float32)) + m[:, 0] - tl[:, 0]
+            loss += float(nll.astype(np.float64).sum()) * cw[k]
+            hits.append(int(((lg[k] > tl).sum(axis=1) < 10).sum()))
+        assert abs(loss - float(g["loss"])) <= 2e-5 * abs(float(g["loss"])), (name, loss, float(g["loss"]))
+        assert hits == [int(round(v)) for v in g["top10acc_by_codebook"]], (name, hits, g["top10acc_by_codebook"])
