@@ -251,7 +251,8 @@ int attn_nsplit(vc_engine* e, int rows) {
   // 8-wave blocks: one decode row is covered by ~256 of them; several rows get ~512 (two per CU), which
   // halves the positions each block walks while the merge in the out-projection stays <= 4 partials
   static const int blocks_multi = getenv("VC_ATTN_BLOCKS") ? atoi(getenv("VC_ATTN_BLOCKS")) : 512;
-  int ns = (rows > 1 ? blocks_multi : 256) / std::max(1, rows * e->H);
+  static const int blocks_one = getenv("VC_ATTN_BLOCKS1") ? atoi(getenv("VC_ATTN_BLOCKS1")) : 256;   // sweep knob: fewer splits = a cheaper merge in the out-projection
+  int ns = (rows > 1 ? blocks_multi : blocks_one) / std::max(1, rows * e->H);
   return std::max(1, std::min(ns, VC_MAX_NSPLIT));
 }
 
