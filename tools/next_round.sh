@@ -9,7 +9,7 @@ VC_TEST_EXPERIMENTAL=1 timeout 150 python -m pytest tests/test_gpu_forward.py -x
 echo "== persistent LSTM, both forms, against the wavefront path"
 timeout 90 python tools/lstm_probe.py 1 2>&1 | tail -10
 VC_TEST_EXPERIMENTAL=1 timeout 60 python -m pytest tests/test_gpu_codec.py -x -q -k experimental 2>&1 | tail -3
-echo "== attention split count of a single-row decode step (VC_ATTN_BLOCKS1: blocks per row; default 256 = 16 splits cap 8)"
-for b in 64 128 256 512; do
+echo "== attention split count of a single-row decode step (VC_ATTN_BLOCKS1 = blocks per row)"
+for b in 16 32 64 128; do   # = 1, 2, 4, 8 splits at 16 heads (VC_MAX_NSPLIT caps at 8)
   VC_ATTN_BLOCKS1=$b timeout 60 python tools/variant_sweep.py 1 2>&1 | tail -1 | sed "s/^/blocks1=$b  /"
 done
