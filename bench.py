@@ -53,88 +53,199 @@ def parse():
     return p.parse_args()
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in its own
-    run, x2-corrected for gfx950 as the microarchitecture guide prescribes); None when no pass is on file
-    or the preset/dtype differs from the one profiled."""
+def pmc_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in its own run of THIS
+    command, x2-corrected for gfx950 as the microarchitecture guide prescribes).  None unless the pass on file was taken
+    on the same preset / dtype / batch / Lx / prompt length as this run (profiles/pmc_traffic.json "config")."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return int(json.load(f)["kernels"][kernel]["fetch_bytes_per_launch"])
+            j = json.load(f)
+        want = {"preset": args.preset, "dtype": args.dtype, "batch": args.batch, "lx": args.lx,
+                "prompt_frames": args.prompt_frames, "mode": args.mode}
+        if j.get("config") != want:
+            return None
+        return int(j["kernels"][kernel]["fetch_bytes_per_launch"])
     except Exception:
         return None
 
 
 def cpu_baseline(args, sd, a, x, x_lens, y):
     """The oracle (a port of the reference's CPU path: same ATen ops incl. the per-step KV torch.cat) timed on this
-    box's host cores over a bounded sample of the same workload.  The reference's cost per step GROWS with the
-    context (O(S) cache copies, BASELINE.md §2: 43 -> 27 tok/s), so both ends of the run are sampled: the prefill and the
-    first n steps of the real run, and n steps at the END of the run's context (a second call whose prompt is as long
-    as the real run's context n steps before its end); the whole run is priced with the mean of the two per-step costs."""
+    box's host cores over a bounded sample of the same workload.  The reference's cost per step GROWS with the context
+    (O(S) cache copies, BASELINE.md §2: 43 -> 27 tok/s), so THREE windows of the run are sampled - its start, its middle
+    and its end (each a call whose prompt is as long as the real run's context at that point) - and the whole run is
+    priced by Simpson's rule over the three per-step costs.  When the unmodified reference tree is reachable
+    (VC_REFERENCE_ROOT; never on the GPU box) the same windows are timed on it too and both numbers are printed."""
     from oracle.voicecraft_oracle import VoiceCraftOracle
     from voicecraft_amd import synth
-    orc = VoiceCraftOracle(a, sd)
     torch.manual_seed(0)
     torch.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count() or 1)))
     K = a.n_codebooks
-    n = max(8, args.cpu_steps // 2)
+    n = max(4, args.cpu_steps // 3)
     total_steps = 10 * args.lx - args.prompt_frames + K
     kn = dict(top_k=args.top_k, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1)
-    t0 = time.perf_counter()
-    orc.inference_tts(x, x_lens, y, max_steps=1, **kn)
-    t_prefill = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.inference_tts(x, x_lens, y, max_steps=n + 1, **kn)
-    t_head = (time.perf_counter() - t0 - t_prefill) / n
-    # the last n steps: same text, a prompt of (prompt + generated - n) frames -> context = the real run's, n steps early
-    late_T = args.prompt_frames + max(0, total_steps - K - n)
-    _, _, y_late = synth.random_prompt(a, args.lx, late_T, seed=7)
-    t0 = time.perf_counter()
-    orc.inference_tts(x, x_lens, y_late, max_steps=1, **kn)
-    t_pre_late = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    orc.inference_tts(x, x_lens, y_late, max_steps=n + 1, **kn)
-    t_tail = (time.perf_counter() - t0 - t_pre_late) / n
-    est = t_prefill + total_steps * 0.5 * (t_head + t_tail)
+    windows = [0, max(0, (total_steps - K - n) // 2), max(0, total_steps - K - n)]      # generated frames before each window
+
+    def sample(run):      # run(x, x_lens, y, max_steps, stamps): appends time.perf_counter() to `stamps` once per decode step, where
+        per, t_prefill = [], None       # the step's logits exist (so the prompt pass is the time up to the first stamp)
+        for w0 in windows:
+            yy = y if w0 == 0 else synth.random_prompt(a, args.lx, args.prompt_frames + w0, seed=7)[2]
+            stamps = []
+            t0 = time.perf_counter()
+            run(x, x_lens, yy, n + 1, stamps)
+            per.append((stamps[-1] - stamps[0]) / max(1, len(stamps) - 1))
+            if w0 == 0:
+                t_prefill = stamps[0] - t0
+        est = t_prefill + total_steps * (per[0] + 4 * per[1] + per[2]) / 6.0
+        return t_prefill, per, est
+
+    class _Stamped(list):     # the oracle appends one trace entry per step, right after the heads
+        def __init__(self, stamps):
+            super().__init__()
+            self.stamps = stamps
+
+        def append(self, item):
+            self.stamps.append(time.perf_counter())
+            super().append(item)
+
+    orc = VoiceCraftOracle(a, sd)
+    t_prefill, per, est = sample(lambda xx, xl, yy, ms, st: orc.inference_tts(xx, xl, yy, max_steps=ms, trace=_Stamped(st), **kn))
     tokens = K * (10 * args.lx - args.prompt_frames)
-    return {
+    out = {
         "value": round(tokens / est, 2), "unit": "codec-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-        "sample": (f"{args.preset} fp32, Lx={args.lx}, {args.prompt_frames} prompt frames: prefill {t_prefill:.2f} s, first {n} decode steps "
-                   f"{t_head * 1e3:.0f} ms/step, {n} steps at the end of the run's context ({args.lx + late_T + 1} positions) "
-                   f"{t_tail * 1e3:.0f} ms/step; whole run of {total_steps} steps priced at their mean = {est:.1f} s. "
-                   "The oracle is a port (1.3-1.5x faster than the unmodified reference on the build box, VERDICT r01); "
+        "sample": (f"{args.preset} fp32, Lx={args.lx}, {args.prompt_frames} prompt frames: prefill {t_prefill:.2f} s; {n} decode steps at the "
+                   f"start / middle / end of the run's context ({', '.join(str(args.lx + args.prompt_frames + 1 + w) for w in windows)} positions): "
+                   f"{per[0] * 1e3:.0f} / {per[1] * 1e3:.0f} / {per[2] * 1e3:.0f} ms per step (stamped inside one call each); whole run of {total_steps} steps by Simpson's rule = {est:.1f} s. "
+                   "The oracle is a port of the reference's CPU path (1.3-1.5x faster than the unmodified reference on the build box); "
                    "the reference itself measured 27.1 tok/s on 8 cores (BASELINE.md §2)"),
     }
+    ref_root = os.environ.get("VC_REFERENCE_ROOT", "")
+    if ref_root and os.path.isfile(os.path.join(ref_root, "models", "voicecraft.py")):
+        try:       # the unmodified reference on the same windows (a bounded run: its loop is cut by a step-counting sampler hook)
+            from oracle import ref_loader
+            model = ref_loader.build_reference_model(a, sd)
+            vc, _ = ref_loader.import_reference()
+
+            class _Stop(Exception):
+                pass
+
+            def run_ref(xx, xl, yy, max_steps, stamps):
+                calls, orig = [0], vc.topk_sampling
+
+                def counted(*aa, **kk):
+                    stamps.append(time.perf_counter())
+                    calls[0] += 1
+                    if calls[0] >= max_steps:
+                        raise _Stop()
+                    return orig(*aa, **kk)
+                vc.topk_sampling = counted
+                try:
+                    with torch.no_grad():
+                        model.inference_tts(xx, xl, yy, silence_tokens=[1388, 1898, 131], **kn)
+                except _Stop:
+                    pass
+                finally:
+                    vc.topk_sampling = orig
+            _, rper, rest = sample(run_ref)
+            out["reference"] = {"value": round(tokens / rest, 2), "kind": "reference", "ms_per_step": [round(v * 1e3) for v in rper]}
+        except Exception as e:      # reporting only
+            out["reference"] = {"error": str(e)}
+    return out
+
+
+def conv_flops_encode(n_samples, F=64, ratios=(8, 5, 4, 2), hidden=128, k=7, rk=3):
+    """FLOPs (2 per multiply-add) of the SEANet encoder's convolutions for one clip at the VoiceCraft codec shape
+    (the restatement's layer list: first conv, per stage one residual unit [k=3 conv to dim/2, 1x1 conv back] and the
+    strided down-sampling conv (kernel 2 x stride), final conv; the LSTM is priced separately)."""
+    L, ch, fl = n_samples, F, 0.0
+    fl += 2.0 * L * 1 * F * k
+    for r in reversed(ratios):
+        fl += 2.0 * L * ch * (ch // 2) * rk + 2.0 * L * (ch // 2) * ch
+        Lo = -(-L // r)
+        fl += 2.0 * Lo * ch * (2 * ch) * (2 * r)
+        L, ch = Lo, 2 * ch
+    fl += 2.0 * L * ch * hidden * k
+    return fl, L, ch
 
 
 def codec_block(dev):
     """EnCodec encode / decode of 16 s of audio (synthetic weights at the VoiceCraft codec shape, fp32 MFMA), SURVEY §8d
-    'report codec encode/decode separately'.  The dominant kernel is the LSTM wavefront step, which re-reads the 50 MB of
-    fp32 recurrence weights per step out of L2 / Infinity Cache."""
+    'report codec encode/decode separately'.  Two roofline objects: the LSTM recurrence (persistent launch: the weights
+    live in registers, a step is one hand-off round - priced against the bytes a launch-per-step form would stream) and
+    the implicit-GEMM convolutions (conv_gemm_k, fp32 MFMA) taken together."""
     from voicecraft_amd import synth
     from voicecraft_amd.codec import AudioTokenizer
     tok = AudioTokenizer(synth.make_codec_state_dict(0), device=dev, max_seconds=16.5, max_batch=1)
     torch.manual_seed(0)
-    wav = (torch.randn(1, 1, 16 * 16000) * 0.1).to(dev)
+    n = 16 * 16000
+    wav = (torch.randn(1, 1, n) * 0.1).to(dev)
     codes = tok.encode(wav)[0][0]
-    enc = []
+    enc, lst = [], []
     for _ in range(3):
         tok.encode(wav)
         enc.append(tok.last_ms())
-    lstm_ms, lstm_bytes = tok.last_lstm_ms()
+        lst.append(tok.last_lstm_ms())
+    i = min(range(3), key=lambda j: enc[j])
+    lstm_ms, lstm_bytes = lst[i]
     T = int(codes.shape[2])
     dec = []
     for _ in range(3):
         tok.decode([(codes, None)])
         dec.append(tok.last_ms())
-    e_ms, d_ms = min(enc), min(dec)
-    step_us = lstm_ms * 1e3 / (T + 1)
+    e_ms, d_ms = enc[i], min(dec)
+    step_us = lstm_ms * 1e3 / max(1, T)
+    persistent = os.environ.get("VC_LSTM_WAVE") is None
+    conv_fl, _, ch = conv_flops_encode(n)
+    conv_fl += 2.0 * T * ch * 4 * ch            # the LSTM's layer-0 input projection runs on conv_gemm_k as a 1x1 convolution
+    conv_ms = max(1e-6, e_ms - lstm_ms)
     return {"audio_s": 16.0, "frames": T, "encode_ms": round(e_ms, 2), "decode_ms": round(d_ms, 2),
             "rtf_encode": round(e_ms / 16e3, 6), "rtf_decode": round(d_ms / 16e3, 6), "dtype": "f32", "parity": "unpinned (audiocraft not vendored)",
-            "roofline": {"bound": "hbm", "kernel": "lstm_wave_k (one recurrence step of both LSTM layers)",
+            "roofline": {"bound": "hbm", "kernel": ("lstm_persist_k (ONE persistent launch; per recurrence step of both layers)" if persistent
+                                                    else "lstm_wave_k (one launch per recurrence step of both LSTM layers)"),
                          "achieved": round(lstm_bytes / (step_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(lstm_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
                          "bytes_per_launch": lstm_bytes, "avg_launch_us": round(step_us, 2),
-                         "note": "weights are cache-resident (50 MB < 256 MB Infinity Cache): priced against HBM as the conservative bound"}}
+                         "note": ("the recurrence weights (50 MB fp32) are register-resident for the whole sequence: 'achieved' is the rate a launch-per-step "
+                                  "form would need to match this step time, not bytes moved" if persistent else
+                                  "weights are cache-resident (50 MB < 256 MB Infinity Cache): priced against HBM as the conservative bound")},
+            "conv_roofline": {"bound": "mfma", "kernel": "conv_gemm_k (every implicit-GEMM convolution of one encode, fp32 MFMA)",
+                              "achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TF["fp32"], "unit": "TFLOP/s",
+                              "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / MFMA_PEAK_TF["fp32"], 4), "traffic": None,
+                              "flops": conv_fl, "ms": round(conv_ms, 2),
+                              "note": "encode wall minus the LSTM launch; includes the first conv, the RVQ search and ~30 launch boundaries"}}
+
+
+def one_sample_block(eng, a, dev, args):
+    """The whole `inference_one_sample` chain (inference_tts_scale.py:42-105) on the bench's model: encode a 3 s synthetic
+    voice prompt, generate to the reference's length cap, decode the concatenation and the generated part.  The model's
+    special-token logits are NOT muted here (the bench checkpoint only mutes the terminator), so generated frames may
+    hold a special id once in a while; they are mapped to code 0 before the codec, which times the same work."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.codec import AudioTokenizer
+    from voicecraft_amd.pipeline import inference_one_sample
+
+    class _Codes0(AudioTokenizer):
+        def decode(self, frames):
+            return super().decode([(frames[0][0].clamp(max=2047), None)])
+
+    tok = _Codes0(synth.make_codec_state_dict(0), device=dev, max_seconds=17.0, max_batch=1)
+    torch.manual_seed(0)
+    wav = torch.randn(args.prompt_frames * 320) * 0.1
+    text = synth.random_prompt(a, args.lx, 1, seed=1)[0][0]
+    cfg = dict(top_k=args.top_k, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1, codec_sr=50,
+               silence_tokens=[1388, 1898, 131], sample_batch_size=1)
+    best = None
+    for _ in range(3):
+        tm = {}
+        concat, gen = inference_one_sample(eng, a, text, tok, wav, dev, cfg, -1, timings=tm)
+        if best is None or tm["total_s"] < best["total_s"]:
+            best = tm
+    gen_s = best["gen_frames"] / 50.0
+    return {"prompt_frames": best["prompt_frames"], "gen_frames": best["gen_frames"], "encode_ms": round(best["encode_s"] * 1e3, 2),
+            "model_ms": round(best["model_s"] * 1e3, 2), "decode_concat_and_gen_ms": round(best["decode_s"] * 1e3, 2),
+            "total_ms": round(best["total_s"] * 1e3, 2), "rtf_end_to_end": round(best["total_s"] / gen_s, 4),
+            "rtf_model_only": round(best["model_s"] / gen_s, 4),
+            "codec_tokens_per_sec_end_to_end": round(4 * best["gen_frames"] / best["total_s"], 1)}
 
 
 def main():
@@ -164,8 +275,10 @@ def main():
     if edit:       # 16 s utterance (10 frames per phoneme), the middle quarter masked: generation runs to the
         assert args.batch == 1, "editing is single-utterance (models/voicecraft.py:607)"   # reference's length cap y_len > 10*Lx
         args.prompt_frames = 10 * args.lx
-        span = (args.prompt_frames * 3 // 8, args.prompt_frames * 5 // 8)
-    Tg = 10 * args.lx - args.prompt_frames if not edit else span[1] - span[0]
+        span = (args.prompt_frames * 3 // 8, args.prompt_frames * 4 // 8)        # [300,400) of 800 frames
+    # generated frames: TTS 10 Lx - T (the length cap); editing: the cap minus the rearranged prompt's columns
+    # (two shifted pieces of K extra columns each, two mask placeholders, the end token and the start column)
+    Tg = 10 * args.lx - args.prompt_frames if not edit else 10 * args.lx - (args.prompt_frames - (span[1] - span[0]) + 2 * K + 4) + 1
     eng = VoiceCraftEngine(a, sd, device=dev, dtype=args.dtype, max_seqs=max(1, args.batch),
                            max_positions=max(1024, args.lx + args.prompt_frames + Tg + 64), use_graph=not args.no_graph)
     # utterance u of this rank = global utterance (u * world + rank); seed = 1 + global index
@@ -189,10 +302,13 @@ def main():
             gens = [o[1] for o in outs]
         n_tok = sum(int(g.shape[2]) * K for g in gens)
         if dist is not None or args.dump:   # the single collective of the job: gather every rank's token block
+            tg0 = time.perf_counter()
             gathered[:] = vdist.gather_token_blocks([g[0] for g in gens], Tg + 8, n_slots=B, K=K, device=dev)
+            gather_s[0] += time.perf_counter() - tg0      # host wall incl. the .to(int32) staging and the unpacking (it synchronises)
         return n_tok
 
     gathered = []
+    gather_s = [0.0]
 
     for w in range(args.warmup):
         one_step(100 + w)
@@ -202,11 +318,13 @@ def main():
     t0 = time.perf_counter()
     tokens = 0
     dec_ms = pre_ms = 0.0
-    steps_run = 0
+    steps_run = steps_launched = 0
+    gather_s[0] = 0.0
     for s in range(args.steps):
         tokens += one_step(1000 + s)
         tm = eng.last_timing_ms()
         dec_ms += tm["decode_ms"]; pre_ms += tm["prefill_ms"]; steps_run += eng.last_steps
+        steps_launched += int(eng.debug_read("host_ms", (8,), torch.float64)[5])
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -243,17 +361,21 @@ def main():
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
         roof = {"bound": "hbm", "kernel": "rows_gemm_k<LN,ReLU> (FFN up-projection)",
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn1") if (args.preset == "giga830M" and args.dtype == "bf16") else None,
+                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn1", args),
                 "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
-        mfma = None
-        if edit:       # the prefill of the editing call is GEMM-shaped: the MFMA roofline of its widest block GEMM
-            pf_rows = 512
-            pf_ms, pf_flops = eng.bench_kernel("pf_ffn1", n_rows=pf_rows, iters=32)
-            mfma = {"bound": "mfma", "kernel": f"rows_gemm_blk_k<ReLU> (prefill FFN up-projection, {pf_rows} rows)",
-                    "achieved": round(pf_flops / (pf_ms * 1e-3) / 1e12, 1), "peak": MFMA_PEAK_TF[args.dtype], "unit": "TFLOP/s",
-                    "frac": round(pf_flops / (pf_ms * 1e-3) / 1e12 / MFMA_PEAK_TF[args.dtype], 4), "traffic": None,
-                    "flops_per_launch": pf_flops, "avg_launch_us": round(pf_ms * 1e3, 2)}
-        dec_step_ms = dec_ms / max(1, steps_run)
+        # the prefill is GEMM-shaped: MFMA rooflines of its widest block GEMM (FFN up-projection) at the run's own pass
+        # size and at a full 512-row pass, and of the MFMA tile attention
+        own_rows = min(512, B * ((args.lx + (args.prompt_frames + 1 if not edit else args.prompt_frames - (span[1] - span[0]) + 2 * K + 4) + 15) // 16 * 16))
+        pk = MFMA_PEAK_TF[args.dtype]
+
+        def mfma_obj(which, rows, label):
+            ms_, fl_ = eng.bench_kernel(which, n_rows=rows, iters=32)
+            return {"bound": "mfma", "kernel": label, "achieved": round(fl_ / (ms_ * 1e-3) / 1e12, 1), "peak": pk, "unit": "TFLOP/s",
+                    "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / pk, 4), "traffic": None, "flops_per_launch": fl_, "avg_launch_us": round(ms_ * 1e3, 2)}
+        mfma = mfma_obj("pf_ffn1", 512, "rows_gemm_blk_k<ReLU> (prefill FFN up-projection, 512 rows)")
+        mfma["at_run_rows"] = mfma_obj("pf_ffn1", own_rows, f"rows_gemm_blk_k<ReLU> (prefill FFN up-projection, this run's {own_rows}-row pass)")
+        mfma["attention"] = mfma_obj("pf_attn", 512, "tile_attn_k (prefill attention, 512 causal rows of one sequence, all heads)")
+        dec_step_ms = dec_ms / max(1, steps_launched or steps_run)     # the timed region covers every LAUNCHED step (graph-rounded)
         out = {
             "metric": "codec_tokens_per_sec", "value": round(value, 1), "unit": "codec-tokens/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -266,12 +388,20 @@ def main():
                        "utterances_per_step": B * n_gpus, "parallelism": f"dp{n_gpus} (utterance-sharded, one all_gather)"},
             "rtf": round(dt / (frames / 50.0), 4),
             "decode_ms_per_token_step": round(dec_step_ms, 4), "prefill_ms": round(pre_ms / args.steps, 2),
+            "decode_steps": {"taken": steps_run // max(1, args.steps), "launched": steps_launched // max(1, args.steps)},
             "decode_step": {"alg_bytes": int(step_bytes), "isolated_step_ms": round(step_ms, 4),
                             "hbm_frac_in_loop": round(step_bytes / (dec_step_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dec_step_ms > 0 else None},
             "roofline": roof, "kernels": kernels,
         }
-        if mfma is not None:
-            out["prefill_roofline"] = mfma
+        out["prefill_roofline"] = mfma
+        if dist is not None:
+            out["collective"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "op": "all_gather of int32 [B,K,T+1] token blocks",
+                                 "gather_ms": round(gather_s[0] / args.steps * 1e3, 3)}
+        if n_gpus == 1 and B == 1 and not edit and not args.no_codec:
+            try:
+                out["one_sample"] = one_sample_block(eng, a, dev, args)
+            except Exception as e:   # reporting only
+                out["one_sample"] = {"error": str(e)}
         if n_gpus == 1 and not args.no_codec:
             try:
                 out["codec"] = codec_block(dev)

@@ -131,7 +131,8 @@ int vc_tts(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, int
  *     sequence and attention is causal, so the K/V of those P positions do not depend on what follows: they
  *     are computed once (sequence 0) and every sequence's attention reads them there - exact, no copy.
  *     (The audio prompt's K/V DO depend on the whole text and cannot be shared.)  0 = nothing shared;
- *     the caller guarantees the equality. */
+ *     the equality is verified on the device while the prompts are built: a text that differs from sequence 0's
+ *     inside the prefix makes the call fail with VC_EINVAL before anything is decoded. */
 int vc_tts_multi(vc_engine* e, int B, const int64_t* x_dev, const int32_t* x_off,
                  const int64_t* y_dev, const int32_t* y_off, const vc_sample_cfg* sc,
                  int shared_text_prefix,
@@ -154,8 +155,7 @@ int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t* y_dev, in
  * the reference pads the batch and masks the padding, the engine runs the rows unpadded), the K heads on every audio
  * position (:516), the placeholders dropped and the delay pattern reverted per piece (:374-404,
  * codebooks_patterns.py:247-266), then per codebook the cross-entropy SUM and the number of targets among the ten
- * largest logits (torchmetrics MulticlassAccuracy(top_k=10), :187-195, :540-541).  EXPERIMENTAL: not yet validated
- * on hardware.
+ * largest logits (torchmetrics MulticlassAccuracy(top_k=10), :187-195, :540-541).
  *   x_dev int64 (all texts back to back), x_off host int32 [B+1]; y_dev int64 [frames][K] time-major (all utterances
  *   back to back), y_off host int32 [B+1] in frames
  *   spans host int32 [sum M_i][2] frame intervals, span_off host int32 [B+1]; mask_values host int32 [sum M_i]

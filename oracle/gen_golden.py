@@ -166,37 +166,6 @@ def run_reference_forward(spec):
     return out
 
 
-# prepare_mask_intervals (models/voicecraft.py:198-237) under fixed seeds: (mask_sample_dist, mask_len_min, mask_len_max,
-# min_gap, max_n_spans, y_lens, seed)
-INTERVAL_CASES = [
-    ("uniform", 1, 600, 5, 3, [60, 41, 200, 333], 3),
-    ("uniform", 5, 40, 10, 3, [120, 500, 77], 4),
-    ("poisson1", 1, 600, 5, 3, [60, 41, 200, 333, 150, 150], 5),      # the released models' setting (z_scripts/e830M.sh)
-    ("poisson2.5", 2, 30, 3, 3, [90, 64, 1000], 6),
-]
-
-
-def interval_args(case):
-    dist, lmin, lmax, gap, nsp, _, _ = case
-    args = synth.make_args("tiny", max_n_spans=nsp)
-    args.mask_sample_dist, args.mask_len_min, args.mask_len_max, args.min_gap = dist, lmin, lmax, gap
-    return args
-
-
-def gen_intervals():
-    import random
-    out = {}
-    for ci, case in enumerate(INTERVAL_CASES):
-        args = interval_args(case)
-        model = ref_loader.build_reference_model(args, synth.make_state_dict(args, seed=0))
-        random.seed(case[6]); torch.manual_seed(case[6])
-        mi, nmi = model.prepare_mask_intervals(torch.tensor(case[5]))
-        out[f"mask_{ci}"] = np.array([[i, int(s0), int(e0)] for i, v in enumerate(mi) for (s0, e0) in v], dtype=np.int64)
-        out[f"nonmask_{ci}"] = np.array([[i, int(s0), int(e0)] for i, v in enumerate(nmi) for (s0, e0) in v], dtype=np.int64)
-    np.savez_compressed(os.path.join(GOLDEN, "mask_intervals.npz"), **out)
-    print("mask_intervals.npz:", {k: v.shape for k, v in out.items()})
-
-
 def case_state_dict(spec, args):
     """The synthetic checkpoint of a golden case (shared with tests/_util.py)."""
     kw = dict(mute_eos=True)
@@ -300,7 +269,6 @@ def main():
     os.makedirs(GOLDEN, exist_ok=True)
     torch.set_num_threads(8)
     if "--forward-only" in sys.argv:            # the training-objective fixtures only (the others are unchanged)
-        gen_intervals()
         for name, spec in FORWARD_CASES.items():
             out = run_reference_forward(spec)
             np.savez_compressed(os.path.join(GOLDEN, f"{name}.npz"), **out)
@@ -308,7 +276,6 @@ def main():
         return
     gen_pattern()
     gen_sampler()
-    gen_intervals()
     for name, spec in MODEL_CASES.items():
         out = run_reference_case(spec)
         np.savez_compressed(os.path.join(GOLDEN, f"model_{name}.npz"), **out)

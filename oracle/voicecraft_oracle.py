@@ -361,21 +361,10 @@ class VoiceCraftOracle:
         desc.append(("empty",))
         return non_mask, desc
 
-    @torch.no_grad()
-    def inference(self, x, x_lens, y, mask_interval, top_k=-100, top_p=1.0, temperature=1.0,
-                  stop_repetition=-1, kvcache=1, silence_tokens=(1388, 1898, 131), trace=None,
-                  mask_value=None, forced=None, forced_draws=None):
-        assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3
-        if self.special_first:
-            y = y + self.n_special
-        yk = y.transpose(2, 1)
-        assert yk.shape[0] == 1 and yk.shape[1] == self.K
-        assert mask_interval.shape == torch.Size((1, mask_interval.shape[1], 2))
+    def _edit_cols(self, yk, ivs, mask_value):
+        """Prompt columns of an editing call (rearrange / shift / insert_mask / cat_y, voicecraft.py:618-679):
+        (non_mask intervals, cols int64 [K,S0], {column: mask_embedding row})."""
         T = yk.shape[2]
-        ivs = [(int(a), int(b)) for a, b in mask_interval[0].tolist()]
-        M = len(ivs)
-        if mask_value is None:
-            mask_value = list(range(self.max_n_spans))[:M] * 2                 # insert_mask, shuffle off
         non_mask, desc = self.edit_layout(T, ivs, mask_value)
         ynp = yk[0].numpy()
         chunks, mask_cols, col = [], {}, 0
@@ -395,6 +384,50 @@ class VoiceCraftOracle:
             col += sh.shape[1]
         cols = torch.from_numpy(np.ascontiguousarray(np.concatenate(chunks, axis=1)))
         assert not (cols == self.pad).any()
+        return non_mask, cols, mask_cols
+
+    @torch.no_grad()
+    def edit_logits_for_trajectory(self, x, y, mask_interval, tokens, steps=None):
+        """The editing twin of tts_logits_for_trajectory for ONE masked span: raw head logits [len(steps),K,V] that
+        `inference` sees at the given decode steps of that span when the emitted tokens are forced to `tokens` [N,K],
+        computed in ONE full causal pass over [x ; rearranged prompt columns ; tokens] (voicecraft.py:449-453 without a
+        cache).  Step s reads the hidden state of audio column S0 - 1 + s (S0 = prompt columns)."""
+        if self.special_first:
+            y = y + self.n_special
+        yk = y.transpose(2, 1)
+        ivs = [(int(a), int(b)) for a, b in mask_interval[0].tolist()]
+        assert len(ivs) == 1, "one span: a span switch feeds three rows at once (covered by the free-running tests)"
+        _, cols, mask_cols = self._edit_cols(yk, ivs, list(range(self.max_n_spans))[:1] * 2)
+        S0 = cols.shape[1]
+        tok = torch.as_tensor(np.asarray(tokens), dtype=torch.long).reshape(-1, self.K)
+        steps = list(range(tok.shape[0] + 1)) if steps is None else list(steps)
+        n_tok = max(steps)
+        allc = torch.cat([cols, tok[:n_tok].t().contiguous()], dim=1)
+        y_emb = self._embed_cols(allc.unsqueeze(-1))
+        pos = sorted(mask_cols)
+        y_emb[0, pos] = self.sd["mask_embedding"][[mask_cols[c] for c in pos]]
+        x_in = self._pos(F.embedding(x, self.sd["text_embedding.word_embeddings.weight"]), "text")
+        y_in = self._pos(y_emb, "audio")
+        Lx, S = x.size(1), x.size(1) + y_in.size(1)
+        out, _ = self._stack(torch.cat([x_in, y_in], dim=1), self._causal_rows(1, S, S), None)
+        rows = out[:, [Lx + S0 - 1 + s for s in steps]]
+        return torch.stack([self._heads(rows[:, i:i + 1])[0] for i in range(rows.size(1))], dim=0)
+
+    @torch.no_grad()
+    def inference(self, x, x_lens, y, mask_interval, top_k=-100, top_p=1.0, temperature=1.0,
+                  stop_repetition=-1, kvcache=1, silence_tokens=(1388, 1898, 131), trace=None,
+                  mask_value=None, forced=None, forced_draws=None):
+        assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3
+        if self.special_first:
+            y = y + self.n_special
+        yk = y.transpose(2, 1)
+        assert yk.shape[0] == 1 and yk.shape[1] == self.K
+        assert mask_interval.shape == torch.Size((1, mask_interval.shape[1], 2))
+        ivs = [(int(a), int(b)) for a, b in mask_interval[0].tolist()]
+        M = len(ivs)
+        if mask_value is None:
+            mask_value = list(range(self.max_n_spans))[:M] * 2                 # insert_mask, shuffle off
+        non_mask, cols, mask_cols = self._edit_cols(yk, ivs, mask_value)
         spans, _ = self._run(x, cols, mask_cols, mode="edit", more_mask=mask_value[M + 1:], n_spans=M, B=1,
                              top_k=top_k, top_p=top_p, temperature=temperature, stop_repetition=stop_repetition,
                              kvcache=kvcache, silence_tokens=list(silence_tokens), trace=trace, forced=forced,

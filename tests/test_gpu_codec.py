@@ -24,7 +24,7 @@ def setup():
     return tok, eo.build(sd)
 
 
-@pytest.mark.parametrize("T", [4, 50, 150, 173])
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 50, 150, 173])
 def test_decode_matches_oracle(setup, T):
     tok, m = setup
     codes = torch.from_numpy(np.random.RandomState(T).randint(0, 2048, size=(4, T)).astype(np.int64))
@@ -36,7 +36,7 @@ def test_decode_matches_oracle(setup, T):
     assert np.abs(got - want).max() <= 2e-4 * rms + 1e-5, (np.abs(got - want).max(), rms)
 
 
-@pytest.mark.parametrize("n", [16000, 48000, 16001, 320 * 9 + 17])
+@pytest.mark.parametrize("n", [16000, 48000, 16001, 320 * 9 + 17, 1, 100, 320, 321, 960])   # the last five: clips of 1-3 frames, shorter than a
 def test_encode_matches_oracle(setup, n):
     tok, m = setup
     torch.manual_seed(n)
@@ -48,9 +48,9 @@ def test_encode_matches_oracle(setup, n):
     assert codes.shape == (4, T) and out[0][1] is None
     z = tok.last_latent(T)
     rel = float((z - z_o).norm() / z_o.norm())
-    assert rel <= 1e-3, rel
+    assert rel <= 1e-3, rel                                # layer's reflect padding: zero-extended first (EncodecConv1d._pad1d)
     agree = float((codes == codes_o).float().mean())
-    assert agree >= 0.99, agree
+    assert agree >= (0.99 if T >= 9 else 0.75), agree
     # every disagreement must sit on a near-tie of the oracle's own arg-min, at the first stage where they differ
     err = float((z - z_o).abs().max())
     E = [m.quantizer.layers[q].codebook.embed for q in range(4)]
@@ -159,19 +159,21 @@ def test_wrong_architecture_switch_is_rejected_at_load():
         AudioTokenizer(synth.make_codec_state_dict(2), device="cuda:0", max_seconds=1.0, cfg=dict(num_residual_layers=2))
 
 
-@pytest.mark.skipif(not __import__("os").environ.get("VC_TEST_EXPERIMENTAL"), reason="experimental path: set VC_TEST_EXPERIMENTAL=1")
-@pytest.mark.parametrize("form", ["1", "2"])
-def test_experimental_persistent_lstm_gives_the_wavefront_codes(setup, form, monkeypatch):
-    """VC_LSTM_PERSIST: the persistent cooperative LSTM must reproduce the default path's codes and,
-    to fp32 rounding, its waveform.  Off by default, so this test is opt-in."""
-    tok, _ = setup
+@pytest.mark.parametrize("batch", [1, 3])
+def test_persistent_lstm_equals_the_launch_per_step_wavefront(batch, monkeypatch):
+    """The LSTM runs as ONE persistent cooperative launch by default (lstm_persist_k: weights resident in registers,
+    hidden vector handed between workgroups as tagged granules); VC_LSTM_WAVE=1 selects the launch-per-step wavefront
+    (lstm_wave_k).  Same order of every sum: codes AND waveform must be bit-identical, single clips and batches (a batch
+    advances all its clips per hand-off round)."""
+    from voicecraft_amd.codec import AudioTokenizer
+    tok = AudioTokenizer(synth.make_codec_state_dict(0), device="cuda:0", max_seconds=3.0, max_batch=batch)
     torch.manual_seed(3)
-    wav = (torch.randn(1, 1, 16000 * 2 + 77) * 0.1).cuda()
-    monkeypatch.delenv("VC_LSTM_PERSIST", raising=False)
+    wav = (torch.randn(batch, 1, 16000 * 2 + 77) * 0.1).cuda()
+    monkeypatch.setenv("VC_LSTM_WAVE", "1")
     codes = tok.encode(wav)[0][0]
     back = tok.decode([(codes, None)])
-    monkeypatch.setenv("VC_LSTM_PERSIST", form)
+    monkeypatch.delenv("VC_LSTM_WAVE")
     codes_p = tok.encode(wav)[0][0]
     back_p = tok.decode([(codes_p, None)])
     assert torch.equal(codes, codes_p)
-    assert float((back - back_p).abs().max()) <= 1e-4 * float(back.abs().max()) + 1e-6
+    assert torch.equal(back, back_p)

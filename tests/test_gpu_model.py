@@ -485,3 +485,55 @@ def test_long_tts_sentences_with_shared_prefix_equal_independent_calls(dtype):
     x = torch.cat([x_prompt, sents[1]]).unsqueeze(0)
     res = eng.inference_tts(x.cuda(), torch.tensor([x.shape[1]]).cuda(), y.cuda(), top_k=1, stop_repetition=3)[0]
     assert np.array_equal(res.cpu().numpy(), want[1])
+
+
+def test_bf16_residual_stream_with_a_large_common_offset():
+    """Trained pre-LN stacks carry channels-wide offsets and outlier channels in the residual stream.  The decode GEMMs
+    fold the LayerNorm into the weights and multiply the row itself, so the row is CENTRED before it is rounded to
+    bf16 (vc_gemm.hip, LN prologue): with |mean| / sigma ~ 10 and a few 10x outlier channels the teacher-forced bf16
+    logits must still sit within the 2e-2 bar (un-centred rounding amplifies the error by |mean| / sigma)."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("tiny128")
+    sd = synth.make_state_dict(a, seed=14)
+    rs = np.random.RandomState(5)
+    outl = torch.from_numpy(rs.choice(a.d_model, size=6, replace=False))
+    sd["text_embedding.word_embeddings.weight"] += 20.0                 # sigma of a text row ~ 1, of an audio row (4 tables) ~ 2
+    sd["text_embedding.word_embeddings.weight"][:, outl] *= 10.0
+    for k in range(a.n_codebooks):
+        sd[f"audio_embedding.{k}.word_embeddings.weight"] += 5.0
+        sd[f"audio_embedding.{k}.word_embeddings.weight"][:, outl] *= 10.0
+    x, xl, y = synth.random_prompt(a, 9, 30, seed=8)
+    trace = []
+    res_o, _ = VoiceCraftOracle(a, sd).inference_tts(x, xl, y, top_k=1, stop_repetition=3, trace=trace)
+    want = torch.stack([t["logits"][0] for t in trace]).numpy()
+    forced = torch.stack([t["tokens"] for t in trace]).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=256)
+    res, gen, lg = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3, _forced=forced, _logit_steps=len(trace))
+    rel = rel_l2(lg.cpu().numpy(), want)
+    assert rel.max() <= 2e-2, float(rel.max())
+
+
+def test_shared_prefix_is_verified_and_does_not_leak_into_later_calls():
+    """vc_tts_multi(shared_text_prefix): texts that differ inside the claimed prefix are refused (device check while the
+    prompts are built), and the device word that redirects positions below the prefix to sequence 0's cache is cleared
+    on that error path too: a teacher-forced evaluation pass (vc_eval_forward, B > 1) right after the failed call gives
+    the same loss as on a fresh engine."""
+    from _util import build_forward_case
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    spec, args, sd, batch = build_forward_case("fwd_b3_ragged")
+    cu = {k: v.cuda() for k, v in batch.items()}
+    fresh = VoiceCraftEngine(args, sd, device="cuda:0", dtype="fp32", max_seqs=4, max_positions=512)
+    want = float(fresh.forward(cu, spec["spans"])["loss"])
+    del fresh
+    eng = VoiceCraftEngine(args, sd, device="cuda:0", dtype="fp32", max_seqs=4, max_positions=512)
+    xs = [torch.tensor([1, 2, 3, 4, 5, 6]), torch.tensor([1, 2, 9, 4, 7, 8, 9])]          # differ at index 2 < 4
+    _, _, y = synth.random_prompt(args, 1, 12, seed=2)
+    with pytest.raises(AssertionError, match="shared_text_prefix"):
+        eng.inference_tts_multi(xs, [y[0], y[0]], top_k=1, _shared_text_prefix=4)
+    assert float(eng.forward(cu, spec["spans"])["loss"]) == want
+    # and the same texts with an honest prefix run
+    outs = eng.inference_tts_multi(xs, [y[0], y[0]], top_k=1, _shared_text_prefix=2)
+    assert len(outs) == 2

@@ -1,0 +1,130 @@
+"""-m gpu: parity AT THE BENCHMARKED SHAPES of giga830M, for the kernel forms those shapes really launch.
+
+The tiny presets never reach the 128-channel side-by-side block GEMM (it needs >= 240 workgroups: a giga-size matrix
+and a pass of >= 385 rows), the MFMA prefill attention at head_dim 128 over several passes, or the weight-stationary
+wide-decode kernel at d = 2048.  Here BASELINE configs 4 and 5 (C4 = Lx 80, 800-frame utterance, span
+[300,400) -> a 792-row prefill; C5 = 8 utterances per GPU, Lx 80, 150 prompt frames -> one 1 848-row prefill stream and
+8-row decode steps) and a 32-sequence decode are teacher-forced on random trajectories and compared with the oracle's
+ONE-PASS evaluation of the same trajectory (fp32, CPU).  Every test also reads the engine's launch census
+(`launch_counts`) and asserts that the intended kernel form ran.
+
+Tolerances: bf16 per-step relative L2 <= 2e-2; fp32 |delta| <= 1e-3 and the same arg-max per codebook.
+"""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_model import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def giga():
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    a = synth.make_args("giga830M")
+    sd = synth.make_state_dict(a, seed=0, fast=True)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
+    return a, sd, VoiceCraftOracle(a, sd)
+
+
+def forced_trajectory(a, n, seed, term):
+    """n steps of random plain codes whose last K steps are the staggered end of a span (voicecraft.py:1057-1066)."""
+    K = a.n_codebooks
+    toks = np.random.RandomState(seed).randint(0, 2048, size=(n, K)).astype(np.int64)
+    for j in range(K):
+        toks[n - K + j, :j] = a.empty_token
+        toks[n - K + j, j] = term
+    return toks
+
+
+def delta(after, before):
+    return {k: after[k] - before[k] for k in after}
+
+
+def test_c4_editing_shape_792_row_prefill(giga):
+    """BASELINE config 4: the 792-row editing prefill runs as a 512-row pass (128-channel side-by-side block GEMM on
+    QKV / FFN-up / FFN-down, MFMA tile attention at head_dim 128) plus a 280-row pass (64-channel form); bf16 logits of
+    the span's first / middle / last decode step against the oracle, then the first step in fp32."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga
+    x, xl, y = synth.random_prompt(a, 80, 800, seed=1)
+    mi = torch.tensor([[[300, 400]]], dtype=torch.int64)
+    n = 80                                                # the span ends on the forced terminator, before the length cap
+    toks = forced_trajectory(a, n, seed=4, term=a.eog)
+    steps = [0, 40, n - 1]
+    want = orc.edit_logits_for_trajectory(x, y, mi, toks, steps=steps).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024)
+    c0 = eng.launch_counts()
+    res, lg = eng.inference(x.cuda(), xl.cuda(), y.cuda(), mi, top_k=40, _forced=toks, _logit_steps=n)
+    c = delta(eng.launch_counts(), c0)
+    L = a.num_decoder_layers
+    assert c["blk128_sbs"] == 3 * L, c                    # QKV, FFN-up, FFN-down of the 512-row pass
+    assert c["blk64"] == L + 4 * L, c                     # its out-projection + the whole 280-row pass
+    assert c["tile_attn"] == 2 * L and c["ln_rows"] == 4 * L, c
+    assert res.shape == (1, a.n_codebooks, 800 - 100 + (n - a.n_codebooks))          # voicecraft.py:900
+    rel = rel_l2(lg.cpu().numpy()[steps], want)
+    assert rel.max() <= 2e-2, dict(zip(steps, rel.tolist()))
+    del eng
+    e32 = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=1, max_positions=1024)
+    _, lg32 = e32.inference(x.cuda(), xl.cuda(), y.cuda(), mi, top_k=40, _forced=toks, _logit_steps=1)
+    got = lg32.cpu().numpy()[0]
+    live = np.abs(want[0]) < 1e3
+    assert np.abs((got - want[0]) * live).max() <= 1e-3, float(np.abs((got - want[0]) * live).max())
+    assert np.array_equal(np.where(live, got, -1e9).argmax(-1), np.where(live, want[0], -1e9).argmax(-1))
+
+
+def test_c5_share_eight_utterances_one_prefill_stream(giga):
+    """BASELINE config 5's per-GPU share: 8 x (Lx 80, 150 frames) prefilled as ONE row stream (8 x 240 rows in passes
+    of 512) and decoded 8 rows per step for 654 steps; per-sequence bf16 logits at step 0 for every sequence and at
+    steps 300 / 653 for sequences 0, 3 and 7 (each an 884-position one-pass oracle evaluation)."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga
+    B, n, K = 8, 654, a.n_codebooks
+    prompts = [synth.random_prompt(a, 80, 150, seed=1 + u) for u in range(B)]
+    forced = np.stack([forced_trajectory(a, n, seed=50 + u, term=a.eos) for u in range(B)], axis=1)      # [n,B,K]
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=1024)
+    c0 = eng.launch_counts()
+    outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
+                                       _forced=forced, _logit_steps=n)
+    c = delta(eng.launch_counts(), c0)
+    L = a.num_decoder_layers
+    assert c["blk128_sbs"] >= 3 * 3 * L and c["tile_attn"] == 4 * L, c       # three 512-row passes + one of 384 rows
+    assert c["rows_gemm"] > 0 and c["mt2"] + c["mt4"] == 0, c                 # 8-row decode: the rows-GEMM, not the wide form
+    lg = lg.cpu().numpy()
+    worst = {}
+    for u in range(B):
+        assert outs[u][1].shape == (1, K, 650)
+        steps = [0, 300, 653] if u in (0, 3, 7) else [0]
+        want = orc.tts_logits_for_trajectory(prompts[u][0], prompts[u][2], forced[:, u], steps=steps).numpy()
+        rel = rel_l2(lg[steps, u], want)
+        worst[u] = float(rel.max())
+    assert max(worst.values()) <= 2e-2, worst
+
+
+def test_thirty_two_row_decode_on_the_weight_stationary_kernel(giga):
+    """32 sequences per step at d = 2048 (the 86 k codec-tokens/s line): rows_gemm_mt_k with 16 k-tiles per wave,
+    two 16-row head passes, unsplit attention - per-sequence bf16 logits at three steps."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga
+    B, n = 32, 12
+    prompts = [synth.random_prompt(a, 6 + (u % 5), 8 + (u % 7), seed=400 + u) for u in range(B)]
+    forced = np.stack([forced_trajectory(a, n, seed=90 + u, term=a.eos) for u in range(B)], axis=1)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256)
+    c0 = eng.launch_counts()
+    outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
+                                       _forced=forced, _logit_steps=n)
+    c = delta(eng.launch_counts(), c0)
+    assert c["mt2"] + c["mt4"] > 0, c
+    lg = lg.cpu().numpy()
+    steps = [0, 5, n - 1]
+    worst = 0.0
+    for u in range(B):
+        want = orc.tts_logits_for_trajectory(prompts[u][0], prompts[u][2], forced[:, u], steps=steps).numpy()
+        worst = max(worst, float(rel_l2(lg[steps, u], want).max()))
+        assert outs[u][1].shape[2] == n - a.n_codebooks
+    assert worst <= 2e-2, worst

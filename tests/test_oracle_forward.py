@@ -53,22 +53,6 @@ def test_layout_of_a_training_sequence():
     assert desc == [("piece", 0, 12, -1), ("mask", 0), ("piece", 25, 48, args.eos), ("mask", 0), ("piece", 12, 25, args.eog)]
 
 
-def test_interval_sampler_reproduces_the_reference_under_the_same_seed():
-    """voicecraft_amd.engine.draw_mask_intervals restates prepare_mask_intervals (models/voicecraft.py:198-237) call for
-    call on `random` / torch's generator: the fixture holds what the live reference returned for the same seeds."""
-    import random
-    from oracle.gen_golden import INTERVAL_CASES, interval_args
-    from voicecraft_amd.engine import draw_mask_intervals
-    g = np.load(os.path.join(GOLDEN, "mask_intervals.npz"))
-    for ci, case in enumerate(INTERVAL_CASES):
-        random.seed(case[6]); torch.manual_seed(case[6])
-        mi, nmi = draw_mask_intervals(interval_args(case), case[5])
-        got_m = np.array([[i, s0, e0] for i, v in enumerate(mi) for (s0, e0) in v], dtype=np.int64)
-        got_n = np.array([[i, s0, e0] for i, v in enumerate(nmi) for (s0, e0) in v], dtype=np.int64)
-        assert np.array_equal(got_m, g[f"mask_{ci}"]), (ci, got_m, g[f"mask_{ci}"])
-        assert np.array_equal(got_n, g[f"nonmask_{ci}"]), ci
-
-
 def test_engine_host_layout_equals_the_oracle_layout():
     """vc_eval_layout (the host half of vc_eval_forward: segment table + target table of one utterance) against the oracle's
     rearranged columns, placeholder positions and targets - no GPU involved, the library is only loaded."""

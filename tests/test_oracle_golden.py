@@ -96,3 +96,24 @@ def test_one_pass_trajectory_logits_equal_the_incremental_path():
     steps = [0, 1, 5, len(trace) // 2, len(trace) - 1]
     got = orc.tts_logits_for_trajectory(x, y, toks, steps=steps).numpy()
     np.testing.assert_allclose(got, want[steps], rtol=0, atol=2e-5)
+
+
+def test_edit_one_pass_evaluation_equals_the_cached_editing_loop():
+    """oracle.edit_logits_for_trajectory (one causal pass over [x ; rearranged prompt ; forced tokens], used to check
+    full-size editing contexts in seconds) against the step-by-step cached loop of `inference` on the same forced
+    trajectory - the loop itself is pinned to the reference by the editing goldens above."""
+    import torch
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    a = synth.make_args("tiny")
+    sd = synth.make_state_dict(a, seed=5)
+    x, xl, y = synth.random_prompt(a, 7, 40, seed=3)
+    mi = torch.tensor([[[12, 20]]], dtype=torch.int64)
+    orc = VoiceCraftOracle(a, sd)
+    trace = []
+    orc.inference(x, xl, y, mi, top_k=1, trace=trace)
+    toks = torch.stack([t["tokens"] for t in trace]).numpy()
+    want = torch.stack([t["logits"][0] for t in trace])
+    got = orc.edit_logits_for_trajectory(x, y, mi, toks, steps=list(range(len(trace))))
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 2e-4 * float(want.abs().max().clamp(max=1e3)) + 1e-4

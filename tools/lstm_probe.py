@@ -1,7 +1,5 @@
-"""Validates and times the EXPERIMENTAL persistent LSTM (VC_LSTM_PERSIST=1, lstm_persist_k) against the default
-two-layer wavefront (lstm_wave_k): codes must be identical (the waveform may differ in the last bits: the two kernels
-contract their multiply-adds differently).
-Run under a short `timeout`: every hand-off wait in the kernel is bounded, but this path has not seen hardware yet.
+"""Times the persistent LSTM (lstm_persist_k, the default) against the launch-per-step two-layer wavefront
+(lstm_wave_k, VC_LSTM_WAVE=1) and checks that codes and waveform are identical.
 usage: timeout 120 python tools/lstm_probe.py [batch]"""
 import os, sys
 import torch
@@ -16,11 +14,11 @@ torch.manual_seed(0)
 res = {}
 for secs in (1, 16):
     wav = (torch.randn(B, 1, 16000 * secs) * 0.1).cuda()
-    for mode in ("wave", "persist", "persist2"):
+    for mode in ("wave", "persist"):
         if mode == "wave":
-            os.environ.pop("VC_LSTM_PERSIST", None)
+            os.environ["VC_LSTM_WAVE"] = "1"
         else:
-            os.environ["VC_LSTM_PERSIST"] = "2" if mode == "persist2" else "1"   # 2: LDS-staged form (lstm_persist2_k)
+            os.environ.pop("VC_LSTM_WAVE", None)
         for _ in range(2):
             codes = tok.encode(wav)[0][0]
         enc_ms = tok.last_ms()
@@ -30,8 +28,7 @@ for secs in (1, 16):
         dec_ms = tok.last_ms()
         res[(secs, mode)] = (codes.cpu(), back.cpu())
         print(f"[lstm] {secs:2d} s x {B}: {mode:8s} encode {enc_ms:7.2f} ms (LSTM part {lstm_ms:6.2f} ms), decode {dec_ms:7.2f} ms", flush=True)
-    for mode in ("persist", "persist2"):
-        same_codes = bool((res[(secs, "wave")][0] == res[(secs, mode)][0]).all())
-        err = float((res[(secs, "wave")][1] - res[(secs, mode)][1]).abs().max())
-        print(f"[lstm] {secs:2d} s x {B}: {mode}: codes identical {same_codes}, waveform max |diff| {err:.3g}", flush=True)
-os.environ.pop("VC_LSTM_PERSIST", None)
+    same_codes = bool((res[(secs, "wave")][0] == res[(secs, "persist")][0]).all())
+    err = float((res[(secs, "wave")][1] - res[(secs, "persist")][1]).abs().max())
+    print(f"[lstm] {secs:2d} s x {B}: persist: codes identical {same_codes}, waveform max |diff| {err:.3g}", flush=True)
+os.environ.pop("VC_LSTM_WAVE", None)

@@ -175,6 +175,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s) {
   dim3 grid(rows_cap, a.H, a.nsplit);
+  ++vc_launch_counts[VC_LC_ROWS_ATTN];
   if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(rows_attn_k<bf16_t>, grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
   else hipLaunchKernelGGL(rows_attn_k<float>, grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
   return hipGetLastError();
@@ -397,6 +398,7 @@ static hipError_t launch_tile_attn(const AttnArgs& a, hipStream_t s) {
 // Prefill passes whose rows come in 16-row tiles of one sequence each (vc_engine.hip prefill_batch).
 hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s) {
   if (!a.x_out) return hipErrorInvalidValue;
+  ++vc_launch_counts[VC_LC_TILE_ATTN];
   if (dtype == VC_DTYPE_BF16) {
     if (a.hd == 128) return launch_tile_attn<bf16_t, 128>(a, s);
     if (a.hd == 64) return launch_tile_attn<bf16_t, 64>(a, s);

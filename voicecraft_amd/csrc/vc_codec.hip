@@ -36,6 +36,7 @@ struct ConvArgs {
   float* out_elu;        // optional [L_dst][Co]
   int L_in, T, Ci, Co, Kw;
   int s_in, dil, pad, reflect;
+  int L_ext;             // reflect padding of an input shorter than its padding: the input is first zero-extended to L_ext positions (EncodecConv1d._pad1d), else = L_in
   int s_out, o_off, L_dst;
   long w_phase_stride;   // float4 units
   int nphase;            // grid.z = nphase * batch: phase = z % nphase, batch item = z / nphase
@@ -75,8 +76,9 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvArgs a) {
       bool v = true;
       if (a.reflect) {
         if (p < 0) p = -p;
-        if (p >= a.L_in) p = 2 * (a.L_in - 1) - p;
-        p = max(0, min(p, a.L_in - 1));                  // only reached for inputs shorter than the padding
+        if (p >= a.L_ext) p = 2 * (a.L_ext - 1) - p;
+        v = p < a.L_in;                                  // the zero extension of an input shorter than its padding
+        p = max(0, min(p, a.L_in - 1));
       } else {
         v = (p >= 0 && p < a.L_in);
         p = max(0, min(p, a.L_in - 1));
@@ -151,7 +153,7 @@ __global__ void conv_pack_k(const float* __restrict__ W, float4* __restrict__ Wp
 // first layer: 1 -> Co channels, reflect padding (Ci = 1 has no 16-wide K tile)
 __global__ void conv_first_k(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
                              float* __restrict__ out_raw, float* __restrict__ out_elu, int L, int Co, int Kw, int pad,
-                             int reflect, int B) {
+                             int reflect, int B, int L_ext) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const int cq = Co >> 2;
   if (idx >= (long)B * L * cq) return;
@@ -164,7 +166,8 @@ __global__ void conv_first_k(const float* __restrict__ x, const float* __restric
     bool ok = true;
     if (reflect) {
       if (p < 0) p = -p;
-      if (p >= L) p = 2 * (L - 1) - p;
+      if (p >= L_ext) p = 2 * (L_ext - 1) - p;
+      ok = p < L;
     } else {
       ok = (p >= 0 && p < L);
     }
@@ -180,7 +183,7 @@ __global__ void conv_first_k(const float* __restrict__ x, const float* __restric
 
 // last layer: Ci -> 1 channel.  W is [1][Ci][Kw]; x is the ELU'd [L][Ci].
 __global__ void conv_last_k(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ bias,
-                            float* __restrict__ out, int L, int Ci, int Kw, int pad, int reflect) {
+                            float* __restrict__ out, int L, int Ci, int Kw, int pad, int reflect, int L_ext) {
   extern __shared__ float s_w[];                         // [Kw][Ci]
   for (int i = threadIdx.x; i < Kw * Ci; i += blockDim.x) { const int k = i / Ci, ci = i - k * Ci; s_w[i] = W[ci * Kw + k]; }
   __syncthreads();
@@ -193,7 +196,8 @@ __global__ void conv_last_k(const float* __restrict__ x, const float* __restrict
     int p = t + k - pad;
     if (reflect) {
       if (p < 0) p = -p;
-      if (p >= L) p = 2 * (L - 1) - p;
+      if (p >= L_ext) p = 2 * (L_ext - 1) - p;
+      if (p >= L) continue;                               // zero extension (input shorter than its padding)
     } else if (p < 0 || p >= L) {
       continue;
     }
@@ -360,15 +364,21 @@ __global__ __launch_bounds__(256) void lstm_wave_k(const LstmWaveArgs a) {
   }
 }
 
-// ---- EXPERIMENTAL (VC_LSTM_PERSIST=1, off by default: correct but 14.0 us per step against the wavefront's 10.4 us,
-// profiles/r02_lstm_persist_probe.log - every wave polling the whole hidden vector costs more than the weights): the same recurrence as ONE
-// persistent cooperative launch.  Every wave keeps its unit's gate rows (16 KB of W_hh, layer 1 also 16 KB of W_ih) in
-// registers for the whole sequence instead of re-reading 48 MB of weights per step, and hidden values travel between
-// workgroups as 8-byte granules {h bits, epoch} written and read with ONE relaxed agent-scope atomic each (value and
-// tag cannot tear and need no fence; MI355X_MICROARCH "data-tagged hand-off").  A granule is valid when its tag equals
-// the call's epoch, so nothing is cleared between calls.  The arithmetic (order of every sum) is lstm_wave_k's (codes
-// identical; the compiler contracts the multiply-adds of the two kernels differently, so the waveform differs in the last bits).  Launched cooperatively (all 2 x H/4 workgroups resident: a wait can only be for a
-// workgroup that is running); every wait is bounded and raises err instead of hanging.
+// ---- the recurrence as ONE persistent cooperative launch (the default for hidden 512 / 1024; lstm_wave_k is the fallback).
+// A wave keeps its unit's gate rows (16 KB of W_hh, layer 1 also 16 KB of W_ih) in registers for the whole sequence
+// instead of re-reading 48 MB of weights per step, and hidden values travel between workgroups as 8-byte granules
+// {h bits, epoch} written and read with ONE relaxed agent-scope atomic each (value and tag cannot tear and need no
+// fence; MI355X_MICROARCH "data-tagged hand-off").  A granule is valid when its tag equals the call's epoch, so nothing
+// is cleared between calls.  A workgroup is 8 waves = 8 units (2 x H/8 workgroups: one per CU at H = 1024); its waves
+// poll ONE EIGHTH of the hidden vector each (H/8 granules, one or two per lane), park the values in LDS and meet at one
+// block barrier per step; every wave then reads the whole vector from LDS (2 MB of L2 traffic per poll round; a first
+// form in which every wave polled the whole vector moved 24 MB and lost to the launches: 14.0 against 10.4 us per step,
+// profiles/r02_lstm_persist_probe.log).  The LDS vector is double-buffered by step parity, so one barrier per step is
+// enough.  The arithmetic (order of every sum) is lstm_wave_k's: codes AND waveform are bit-identical to it
+// (profiles/r03_next_round.log).  Launched cooperatively (every workgroup resident: a wait can only be for a workgroup
+// that is running); every wait is bounded: a wait that gives up raises an LDS flag BEFORE the barrier, the whole
+// workgroup leaves together and the host reports err instead of hanging.
+// Measured (16 s of audio): 4.8 us per step against 8.8 us for one launch per step - encode 9.4 -> 6.2 ms, decode 8.1 -> 5.3 ms.
 struct LstmPersistArgs {
   const float* Whh[2];
   const float* Wih1;
@@ -384,130 +394,10 @@ struct LstmPersistArgs {
   int* err;
 };
 #define VC_LSTM_SPIN_LIMIT 400000
-template <int NQ>
-__device__ __forceinline__ bool lstm_poll(const unsigned long long* g, unsigned epoch, int lane, float4 (&hv)[NQ]) {
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < NQ; ++j) {
-    const unsigned long long* p = g + 4 * (lane + 64 * j);
-    const unsigned long long a0 = __hip_atomic_load(p + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long a1 = __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long a2 = __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const unsigned long long a3 = __hip_atomic_load(p + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    ok = ok && (unsigned)(a0 >> 32) == epoch && (unsigned)(a1 >> 32) == epoch && (unsigned)(a2 >> 32) == epoch &&
-         (unsigned)(a3 >> 32) == epoch;
-    hv[j] = make_float4(__uint_as_float((unsigned)a0), __uint_as_float((unsigned)a1), __uint_as_float((unsigned)a2),
-                        __uint_as_float((unsigned)a3));
-  }
-  return ok;
-}
-// waits (bounded) until every granule of one hidden vector carries the epoch; false = gave up
-template <int NQ>
-__device__ __forceinline__ bool lstm_wait(const unsigned long long* g, unsigned epoch, int lane, float4 (&hv)[NQ], int* err) {
-  for (int spins = 0; spins < VC_LSTM_SPIN_LIMIT; ++spins) {
-    const bool ok = lstm_poll<NQ>(g, epoch, lane, hv);
-    if (__all(ok)) return true;
-    __builtin_amdgcn_s_sleep(1);
-  }
-  if (lane == 0) __hip_atomic_store(err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  return false;
-}
+#define VC_LSTM_BG 8            // clips advanced per hand-off round (LDS: 2 parities x BG x {h, x} x H floats = 128 KB at H = 1024)
 template <int NQ>   // H = 256 * NQ
-__global__ __launch_bounds__(256, 2) void lstm_persist_k(const LstmPersistArgs a) {
-  const int n = blockIdx.y;
-  const int H = a.H;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int u = blockIdx.x * 4 + wave;                   // hidden unit (grid.x = H / 4)
-  const int nq = H >> 2;
-  const long TH = (long)a.T * H;
-  const float4* whh = reinterpret_cast<const float4*>(a.Whh[n] + (long)(4 * u) * H);
-  float4 w[4][NQ], wi[4][NQ];
-#pragma unroll
-  for (int j = 0; j < NQ; ++j) {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) w[g][j] = whh[(long)g * nq + lane + 64 * j];
-  }
-  float4 gb = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (n == 1) {
-    const float4* wih = reinterpret_cast<const float4*>(a.Wih1 + (long)(4 * u) * H);
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) wi[g][j] = wih[(long)g * nq + lane + 64 * j];
-    }
-    gb = *reinterpret_cast<const float4*>(a.b1 + 4 * u);
-  } else {
-#pragma unroll
-    for (int j = 0; j < NQ; ++j) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) wi[g][j] = make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  }
-  for (int t = 0; t < a.T; ++t) {
-    for (int b = 0; b < a.B; ++b) {
-      float4 hv[NQ], xv[NQ];
-      if (t) {
-        if (!lstm_wait<NQ>(a.hg[n] + b * TH + (long)(t - 1) * H, a.epoch, lane, hv, a.err)) return;
-      } else {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j) hv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      float4 gi = gb;
-      if (n == 0) {
-        gi = *reinterpret_cast<const float4*>(a.G0 + (b * (long)a.T + t) * 4 * H + 4 * u);
-      } else {
-        if (!lstm_wait<NQ>(a.hg[0] + b * TH + (long)t * H, a.epoch, lane, xv, a.err)) return;
-      }
-      const float c_prev = t ? a.c[n][(long)b * H + u] : 0.f;
-      const float sk = (n == 1 && a.skip) ? a.skip[b * TH + (long)t * H + u] : 0.f;
-      float g4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j)
-          g4[g] += (w[g][j].x * hv[j].x + w[g][j].y * hv[j].y) + (w[g][j].z * hv[j].z + w[g][j].w * hv[j].w);
-      }
-      if (n == 1) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          float acc = 0.f;
-#pragma unroll
-          for (int j = 0; j < NQ; ++j)
-            acc += (wi[g][j].x * xv[j].x + wi[g][j].y * xv[j].y) + (wi[g][j].z * xv[j].z + wi[g][j].w * xv[j].w);
-          g4[g] += acc;
-        }
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
-      if (lane == 0) {
-        const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
-        const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
-        const float gg = tanhf(g4[2] + gi.z);
-        const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
-        const float c = fg * c_prev + ig * gg;
-        const float h = og * tanhf(c);
-        a.c[n][(long)b * H + u] = c;
-        __hip_atomic_store(a.hg[n] + b * TH + (long)t * H + u, ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(h),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n == 1 && a.skip) {
-          const float y = h + sk;
-          if (a.out_raw) a.out_raw[b * TH + (long)t * H + u] = y;
-          if (a.out_elu) a.out_elu[b * TH + (long)t * H + u] = elu1(y);
-        }
-      }
-    }
-  }
-}
-
-// ---- second form of the persistent LSTM (VC_LSTM_PERSIST=2; written after the first form's measurement, NOT yet run on
-// hardware): the polling traffic is what cost 14 us per step, so a workgroup is now 8 waves = 8 units (one per CU:
-// 2 x H/8 workgroups), its waves poll ONE EIGHTH of the hidden vector each (H/8 granules, two per lane), park the values
-// in LDS and meet at one block barrier per step; every wave then reads the whole vector from LDS.  L2 traffic per
-// poll round: 2 MB instead of 24 MB.  The LDS vector is double-buffered by step parity, so one barrier per step is
-// enough; a wait that gives up raises an LDS flag BEFORE the barrier and the whole workgroup leaves together.
-template <int NQ>   // H = 256 * NQ
-__global__ __launch_bounds__(512) void lstm_persist2_k(const LstmPersistArgs a) {
-  __shared__ __attribute__((aligned(16))) float s_h[2][2][256 * NQ];     // [parity][h_prev | x][H]
+__global__ __launch_bounds__(512) void lstm_persist_k(const LstmPersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s_hx[];          // [parity][clip][h_prev | x][H]
   __shared__ int s_abort;
   const int H = a.H;
   const int per_layer = H >> 3;                          // workgroups per layer
@@ -544,87 +434,100 @@ __global__ __launch_bounds__(512) void lstm_persist2_k(const LstmPersistArgs a) 
   // this wave's slice of a hidden vector: granules [wave * H/8, (wave + 1) * H/8) = GPL consecutive granules per lane
   // (this form accepts H = 512 or 1024: one or two per lane)
   constexpr int GPL = NQ / 2;
-  static_assert(NQ == 2 || NQ == 4, "lstm_persist2_k: hidden 512 or 1024");
+  static_assert(NQ == 2 || NQ == 4, "lstm_persist_k: hidden 512 or 1024");
   const int s0 = wave * (H >> 3) + GPL * lane;
-  auto fetch = [&](const unsigned long long* g, float* dst) -> bool {      // bounded wait for the slice, parked in LDS
-    for (int spins = 0; spins < VC_LSTM_SPIN_LIMIT; ++spins) {
+  // The clips of a batch advance together, VC_LSTM_BG at a time: ONE hand-off round (poll, park, barrier) per step serves
+  // every clip of the group, and the register-resident weights are reused for all of them.
+  for (int b0 = 0; b0 < a.B; b0 += VC_LSTM_BG) {
+    const int nb = min(VC_LSTM_BG, a.B - b0);
+    for (int t = 0; t < a.T; ++t) {
+      float* sbuf = s_hx + (size_t)(t & 1) * (VC_LSTM_BG * 2 * H);
+      // ---- bounded wait for this wave's slices of h_{t-1} (own layer) and, on layer 1, of the lower layer's h_t
       bool ok = true;
-      float v[GPL];
+      if (t || n == 1) {
+        ok = false;
+        for (int spins = 0; spins < VC_LSTM_SPIN_LIMIT && !ok; ++spins) {
+          bool all = true;
+#pragma unroll 1
+          for (int bb = 0; bb < nb; ++bb) {
+            const long bo = (long)(b0 + bb) * TH;
+            float* sh = sbuf + (size_t)bb * 2 * H;
 #pragma unroll
-      for (int q = 0; q < GPL; ++q) {
-        const unsigned long long a0 = __hip_atomic_load(g + s0 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        ok = ok && (unsigned)(a0 >> 32) == a.epoch;
-        v[q] = __uint_as_float((unsigned)a0);
+            for (int q = 0; q < GPL; ++q) {
+              if (t) {
+                const unsigned long long g0 = __hip_atomic_load(a.hg[n] + bo + (long)(t - 1) * H + s0 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all = all && (unsigned)(g0 >> 32) == a.epoch;
+                sh[s0 + q] = __uint_as_float((unsigned)g0);
+              }
+              if (n == 1) {
+                const unsigned long long g1 = __hip_atomic_load(a.hg[0] + bo + (long)t * H + s0 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                all = all && (unsigned)(g1 >> 32) == a.epoch;
+                sh[H + s0 + q] = __uint_as_float((unsigned)g1);
+              }
+            }
+          }
+          ok = __all(all);                                 // (values parked by an unsuccessful round are overwritten by the next)
+          if (!ok) __builtin_amdgcn_s_sleep(1);
+        }
       }
-      if (__all(ok)) {
-#pragma unroll
-        for (int q = 0; q < GPL; ++q) dst[s0 + q] = v[q];
-        return true;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    return false;
-  };
-  int it = 0;
-  for (int t = 0; t < a.T; ++t) {
-    for (int b = 0; b < a.B; ++b, ++it) {
-      float* sh = s_h[it & 1][0];
-      float* sx = s_h[it & 1][1];
-      bool ok = true;
-      if (t) ok = fetch(a.hg[n] + b * TH + (long)(t - 1) * H, sh);
-      if (n == 1 && ok) ok = fetch(a.hg[0] + b * TH + (long)t * H, sx);
       if (!ok && lane == 0) {
         s_abort = 1;
         __hip_atomic_store(a.err, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       }
       __syncthreads();
       if (s_abort) return;                               // every wave sees the flag behind the same barrier
-      float4 hv[NQ], xv[NQ];
+#pragma unroll 1
+      for (int bb = 0; bb < nb; ++bb) {
+        const int b = b0 + bb;
+        const float* sh = sbuf + (size_t)bb * 2 * H;
+        float4 hv[NQ], xv[NQ];
 #pragma unroll
-      for (int j = 0; j < NQ; ++j) {
-        hv[j] = t ? reinterpret_cast<const float4*>(sh)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
-        xv[j] = (n == 1) ? reinterpret_cast<const float4*>(sx)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
-      }
-      float4 gi = gb;
-      if (n == 0) gi = *reinterpret_cast<const float4*>(a.G0 + (b * (long)a.T + t) * 4 * H + 4 * u);
-      const float c_prev = t ? a.c[n][(long)b * H + u] : 0.f;
-      const float sk = (n == 1 && a.skip) ? a.skip[b * TH + (long)t * H + u] : 0.f;
-      float g4[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-#pragma unroll
-        for (int j = 0; j < NQ; ++j)
-          g4[g] += (w[g][j].x * hv[j].x + w[g][j].y * hv[j].y) + (w[g][j].z * hv[j].z + w[g][j].w * hv[j].w);
-      }
-      if (n == 1) {
+        for (int j = 0; j < NQ; ++j) {
+          hv[j] = t ? reinterpret_cast<const float4*>(sh)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+          xv[j] = (n == 1) ? reinterpret_cast<const float4*>(sh + H)[lane + 64 * j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        float4 gi = gb;
+        if (n == 0) gi = *reinterpret_cast<const float4*>(a.G0 + (b * (long)a.T + t) * 4 * H + 4 * u);
+        const float c_prev = t ? a.c[n][(long)b * H + u] : 0.f;
+        const float sk = (n == 1 && a.skip) ? a.skip[b * TH + (long)t * H + u] : 0.f;
+        float g4[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          float acc = 0.f;
 #pragma unroll
           for (int j = 0; j < NQ; ++j)
-            acc += (wi[g][j].x * xv[j].x + wi[g][j].y * xv[j].y) + (wi[g][j].z * xv[j].z + wi[g][j].w * xv[j].w);
-          g4[g] += acc;
+            g4[g] += (w[g][j].x * hv[j].x + w[g][j].y * hv[j].y) + (w[g][j].z * hv[j].z + w[g][j].w * hv[j].w);
         }
-      }
+        if (n == 1) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
-      if (lane == 0) {
-        const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
-        const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
-        const float gg = tanhf(g4[2] + gi.z);
-        const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
-        const float c = fg * c_prev + ig * gg;
-        const float h = og * tanhf(c);
-        a.c[n][(long)b * H + u] = c;
-        __hip_atomic_store(a.hg[n] + b * TH + (long)t * H + u, ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(h),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (n == 1 && a.skip) {
-          const float y = h + sk;
-          if (a.out_raw) a.out_raw[b * TH + (long)t * H + u] = y;
-          if (a.out_elu) a.out_elu[b * TH + (long)t * H + u] = elu1(y);
+          for (int g = 0; g < 4; ++g) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NQ; ++j)
+              acc += (wi[g][j].x * xv[j].x + wi[g][j].y * xv[j].y) + (wi[g][j].z * xv[j].z + wi[g][j].w * xv[j].w);
+            g4[g] += acc;
+          }
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) g4[g] = wave_sum(g4[g]);
+        if (lane == 0) {
+          const float ig = 1.f / (1.f + expf(-(g4[0] + gi.x)));
+          const float fg = 1.f / (1.f + expf(-(g4[1] + gi.y)));
+          const float gg = tanhf(g4[2] + gi.z);
+          const float og = 1.f / (1.f + expf(-(g4[3] + gi.w)));
+          const float c = fg * c_prev + ig * gg;
+          const float h = og * tanhf(c);
+          a.c[n][(long)b * H + u] = c;
+          __hip_atomic_store(a.hg[n] + b * TH + (long)t * H + u, ((unsigned long long)a.epoch << 32) | (unsigned long long)__float_as_uint(h),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (n == 1 && a.skip) {
+            const float y = h + sk;
+            if (a.out_raw) a.out_raw[b * TH + (long)t * H + u] = y;
+            if (a.out_elu) a.out_elu[b * TH + (long)t * H + u] = elu1(y);
+          }
         }
       }
     }
+    __syncthreads();   // the next group starts on parity 0 again: nobody may still be reading this group's last buffers
   }
 }
 
@@ -843,10 +746,11 @@ struct vc_codec {
   float *A_raw = nullptr, *C_raw = nullptr, *S_raw = nullptr, *A_elu = nullptr, *B_elu = nullptr, *H_elu = nullptr, *latent = nullptr;
   int B_max = 1;
   float *G = nullptr, *HS0 = nullptr, *HS1 = nullptr, *cstate = nullptr, *hzero = nullptr;
-  unsigned long long* hgran = nullptr;   // experimental persistent LSTM: 2 x [B_max][T_max][H] granules, allocated on first use
+  unsigned long long* hgran = nullptr;   // persistent LSTM: 2 x [B_max][T_max][H] granules, allocated on first use
   unsigned lstm_epoch = 0;
   int persist_ok = -1;                   // -1 not probed, 0 the cooperative grid does not fit, 1 usable
-  int persist_form = 0;
+  bool persist_used = false;             // a persistent launch is in flight / unchecked (check_lstm_flag)
+  int last_lstm_persist = 0;             // 1: the last LSTM ran as the persistent launch, 0: launch per step
   int* err_flag = nullptr;
   int* h_flag = nullptr;
   int T_max = 0;
@@ -971,13 +875,14 @@ int run_conv(vc_codec* c, const Conv& cv, const float* x, int L_in, const float*
   const int pl = c->cfg.causal ? pt : pt - pt / 2;
   const int T = (L_in + cv.stride - 1) / cv.stride;
   const int prt = (T - 1) * cv.stride + (cv.Kw - 1) * dil + 1 - pl - L_in;      // right padding incl. the extra part
-  if (c->cfg.pad_reflect && L_in <= std::max(pl, prt))   // the reference zero-extends then reflects here (_pad1d): not reproduced
-    return cfail(c, VC_EINVAL, "input of %d positions is shorter than the reflect padding of a layer (clips of fewer than 4 frames are not supported)", L_in);
+  // an input not longer than its reflect padding is zero-extended to max(pad) + 1 positions first, reflected, and the
+  // extension cut off again (EncodecConv1d._pad1d = audiocraft pad1d): clips of 1-3 frames
+  const int L_ext = (c->cfg.pad_reflect && L_in <= std::max(pl, prt)) ? std::max(pl, prt) + 1 : L_in;
   ConvArgs a;
   memset(&a, 0, sizeof a);
   a.x = x; a.Wp = cv.Wp; a.bias = cv.bias; a.res = res; a.out_raw = out_raw; a.out_elu = out_elu;
   a.L_in = L_in; a.T = T; a.Ci = cv.Ci; a.Co = cv.Co; a.Kw = cv.Kw;
-  a.s_in = cv.stride; a.dil = dil; a.pad = pl; a.reflect = c->cfg.pad_reflect;
+  a.s_in = cv.stride; a.dil = dil; a.pad = pl; a.reflect = c->cfg.pad_reflect; a.L_ext = L_ext;
   a.s_out = 1; a.o_off = 0; a.L_dst = T; a.w_phase_stride = cv.phase_stride;
   a.nphase = 1; a.x_bstride = (long)L_in * cv.Ci; a.o_bstride = (long)T * cv.Co;
   hipLaunchKernelGGL(conv_gemm_k, dim3((T + 127) / 128, (cv.Co + 31) / 32, B), dim3(256), 0, s, a);
@@ -1043,9 +948,10 @@ int run_conv1x1(vc_codec* c, const Conv& cv, const float* x, int T, float* out_r
   return VC_OK;
 }
 
-// experimental persistent LSTM: after a synchronise, report a wait that gave up (word 1 of err_flag)
+// persistent LSTM: after a synchronise, report a wait that gave up (word 1 of err_flag)
 int check_lstm_flag(vc_codec* c) {
-  if (!getenv("VC_LSTM_PERSIST")) return VC_OK;
+  if (!c->persist_used) return VC_OK;
+  c->persist_used = false;
   int w = 0;
   CCHK(c, hipMemcpy(&w, c->err_flag + 1, 4, hipMemcpyDeviceToHost));
   if (w) {
@@ -1063,44 +969,46 @@ int run_lstm(vc_codec* c, const Lstm& L, const float* x, int T, float* out_raw, 
     // two-layer wavefront: T + 1 launches (lstm_wave_k)
     int rc = run_conv1x1(c, L.Wih[0], x, T, c->G, s, B);                          // layer 0: G = x W_ih^T + b_ih + b_hh
     if (rc) return rc;
-    if (getenv("VC_LSTM_PERSIST")) {      // EXPERIMENTAL: one persistent cooperative launch (lstm_persist_k)
-      const int form = atoi(getenv("VC_LSTM_PERSIST"));          // 1: every wave polls the whole vector; 2: LDS-staged (8 units per workgroup)
-      if (form == 2 && H != 512 && H != 1024) return cfail(c, VC_EINVAL, "VC_LSTM_PERSIST=2 needs hidden 512 or 1024");
-      const void* kern = form == 2 ? (H == 512 ? (const void*)lstm_persist2_k<2> : (const void*)lstm_persist2_k<4>)
-                       : H == 256 ? (const void*)lstm_persist_k<1> : H == 512 ? (const void*)lstm_persist_k<2>
-                       : H == 768 ? (const void*)lstm_persist_k<3> : (const void*)lstm_persist_k<4>;
-      const dim3 pgrid = form == 2 ? dim3(2 * (H / 8)) : dim3(H / 4, 2);
-      const int pthreads = form == 2 ? 512 : 256;
-      const long n_wg = form == 2 ? 2L * (H / 8) : 2L * (H / 4);
-      if (c->persist_ok < 0 || c->persist_form != form) {
-        c->persist_form = form;
+    // one persistent cooperative launch (lstm_persist_k) when its 2 x H/8 workgroups are all resident at once;
+    // VC_LSTM_WAVE=1 forces the launch-per-step wavefront (the reference form of the tests)
+    if ((H == 512 || H == 1024) && !getenv("VC_LSTM_WAVE")) {
+      const void* kern = H == 512 ? (const void*)lstm_persist_k<2> : (const void*)lstm_persist_k<4>;
+      const long n_wg = 2L * (H / 8);
+      if (c->persist_ok < 0) {
         int per_cu = 0, coop = 0;
         hipDeviceProp_t prop;
         CCHK(c, hipGetDeviceProperties(&prop, c->device));
         CCHK(c, hipDeviceGetAttribute(&coop, hipDeviceAttributeCooperativeLaunch, c->device));
-        CCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, pthreads, 0));
+        const size_t lds_max = (size_t)2 * VC_LSTM_BG * 2 * H * sizeof(float);
+        CCHK(c, hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max));
+        CCHK(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, 512, lds_max));
         c->persist_ok = (coop && (long)per_cu * prop.multiProcessorCount >= n_wg) ? 1 : 0;
       }
-      if (!c->persist_ok) return cfail(c, VC_EINVAL, "VC_LSTM_PERSIST: the cooperative grid of %ld workgroups does not fit this device", n_wg);
-      if (!c->hgran) {
-        int rc2 = calloc_dev(c, &c->hgran, (size_t)2 * c->B_max * c->T_max * H);
-        if (rc2) return rc2;
-        CCHK(c, hipMemsetAsync(c->hgran, 0, (size_t)2 * c->B_max * c->T_max * H * 8, s));
+      if (c->persist_ok) {
+        if (!c->hgran) {
+          int rc2 = calloc_dev(c, &c->hgran, (size_t)2 * c->B_max * c->T_max * H);
+          if (rc2) return rc2;
+          CCHK(c, hipMemsetAsync(c->hgran, 0, (size_t)2 * c->B_max * c->T_max * H * 8, s));
+        }
+        if (++c->lstm_epoch == 0) c->lstm_epoch = 1;
+        LstmPersistArgs pa;
+        memset(&pa, 0, sizeof pa);
+        pa.Whh[0] = L.Whh[0]; pa.Whh[1] = L.Whh[1]; pa.Wih1 = L.WihP[1]; pa.b1 = L.bP[1]; pa.G0 = c->G;
+        pa.hg[0] = c->hgran; pa.hg[1] = c->hgran + (size_t)c->B_max * c->T_max * H;
+        pa.c[0] = c->cstate; pa.c[1] = c->cstate + (size_t)B * H;
+        pa.skip = x; pa.out_raw = out_raw; pa.out_elu = out_elu; pa.H = H; pa.T = T; pa.B = B;
+        pa.epoch = c->lstm_epoch; pa.err = c->err_flag + 1;      // word 1: a bounded wait gave up
+        void* kargs[] = {&pa};
+        const size_t lds = (size_t)2 * std::min(B, VC_LSTM_BG) * 2 * H * sizeof(float);
+        CCHK(c, hipEventRecord(c->ev_l[0], s));
+        CCHK(c, hipLaunchCooperativeKernel(kern, dim3((unsigned)n_wg), dim3(512), kargs, (unsigned)lds, s));
+        CCHK(c, hipEventRecord(c->ev_l[1], s));
+        c->persist_used = true;
+        c->last_lstm_persist = 1;
+        return VC_OK;
       }
-      if (++c->lstm_epoch == 0) c->lstm_epoch = 1;
-      LstmPersistArgs pa;
-      memset(&pa, 0, sizeof pa);
-      pa.Whh[0] = L.Whh[0]; pa.Whh[1] = L.Whh[1]; pa.Wih1 = L.WihP[1]; pa.b1 = L.bP[1]; pa.G0 = c->G;
-      pa.hg[0] = c->hgran; pa.hg[1] = c->hgran + (size_t)c->B_max * c->T_max * H;
-      pa.c[0] = c->cstate; pa.c[1] = c->cstate + (size_t)B * H;
-      pa.skip = x; pa.out_raw = out_raw; pa.out_elu = out_elu; pa.H = H; pa.T = T; pa.B = B;
-      pa.epoch = c->lstm_epoch; pa.err = c->err_flag + 1;      // word 1: a bounded wait of the persistent LSTM gave up
-      void* kargs[] = {&pa};
-      CCHK(c, hipEventRecord(c->ev_l[0], s));
-      CCHK(c, hipLaunchCooperativeKernel(kern, pgrid, dim3(pthreads), kargs, 0, s));
-      CCHK(c, hipEventRecord(c->ev_l[1], s));
-      return VC_OK;
     }
+    c->last_lstm_persist = 0;
     CCHK(c, hipMemsetAsync(c->cstate, 0, (size_t)2 * B * H * 4, s));
     LstmWaveArgs a;
     memset(&a, 0, sizeof a);
@@ -1307,9 +1215,8 @@ extern "C" int vc_codec_encode_batch(vc_codec* c, const float* wav_dev, int B, i
   if (!c || !c->finalized) return cfail(c, VC_ESTATE, "codec not finalized");
   if (!wav_dev || !codes_dev || !n_frames) return cfail(c, VC_EINVAL, "null argument to vc_codec_encode");
   if (B < 1 || B > c->B_max) return cfail(c, VC_ECAP, "batch %d outside [1, %d]", B, c->B_max);
-  if (n_samples < 4 * c->hop - c->hop + 1 || n_samples > c->cfg.max_samples)
-    return cfail(c, VC_ECAP, "n_samples %d outside [%d, %d] (clips of fewer than 4 frames are not supported)", n_samples,
-                 3 * c->hop + 1, c->cfg.max_samples);
+  if (n_samples < 1 || n_samples > c->cfg.max_samples)
+    return cfail(c, VC_ECAP, "n_samples %d outside [1, %d]", n_samples, c->cfg.max_samples);
   CCHK(c, hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
   const vc_codec_cfg& g = c->cfg;
@@ -1320,8 +1227,10 @@ extern "C" int vc_codec_encode_batch(vc_codec* c, const float* wav_dev, int B, i
     const long tot = (long)B * L * (F / 4);
     const int pt = g.kernel_size - 1;
     const int pad = g.causal ? pt : pt - pt / 2;
+    const int mp = std::max(pad, pt - pad);
     hipLaunchKernelGGL(conv_first_k, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, wav_dev, c->enc_first.w_raw,
-                       c->enc_first.bias, c->A_raw, c->A_elu, L, F, g.kernel_size, pad, g.pad_reflect, B);
+                       c->enc_first.bias, c->A_raw, c->A_elu, L, F, g.kernel_size, pad, g.pad_reflect, B,
+                       (g.pad_reflect && L <= mp) ? mp + 1 : L);
   }
   int rc, Lo;
   const int R = g.n_ratios;
@@ -1366,7 +1275,7 @@ extern "C" int vc_codec_decode_batch(vc_codec* c, const int64_t* codes_dev, int 
   if (!c || !c->finalized) return cfail(c, VC_ESTATE, "codec not finalized");
   if (!codes_dev || !wav_dev) return cfail(c, VC_EINVAL, "null argument to vc_codec_decode");
   if (B < 1 || B > c->B_max) return cfail(c, VC_ECAP, "batch %d outside [1, %d]", B, c->B_max);
-  if (T < 4 || T > c->T_max - 1) return cfail(c, VC_ECAP, "T %d outside [4, %d]", T, c->T_max - 1);
+  if (T < 1 || T > c->T_max - 1) return cfail(c, VC_ECAP, "T %d outside [1, %d]", T, c->T_max - 1);
   if ((long)T * c->hop > wav_cap) return cfail(c, VC_ECAP, "wav capacity %d < %ld", wav_cap, (long)T * c->hop);
   CCHK(c, hipSetDevice(c->device));
   hipStream_t s = stream ? (hipStream_t)stream : c->own_stream;
@@ -1393,8 +1302,9 @@ extern "C" int vc_codec_decode_batch(vc_codec* c, const int64_t* codes_dev, int 
     const int Ci = g.n_filters, Kw = g.last_kernel_size;
     const int pt = Kw - 1;
     const int pad = g.causal ? pt : pt - pt / 2;
+    const int mp = std::max(pad, pt - pad);
     hipLaunchKernelGGL(conv_last_k, dim3((L + 255) / 256, B), dim3(256), (size_t)Kw * Ci * 4, s, elu, c->dec_last.w_raw,
-                       c->dec_last.bias, wav_dev, L, Ci, Kw, pad, g.pad_reflect);
+                       c->dec_last.bias, wav_dev, L, Ci, Kw, pad, g.pad_reflect, (g.pad_reflect && L <= mp) ? mp + 1 : L);
   }
   CCHK(c, hipGetLastError());
   CCHK(c, hipEventRecord(c->ev[1], s));

@@ -284,7 +284,8 @@ struct PromptArgs {
   float* emb;               // [rows][d]
   int* row_seq;
   int* row_pos;
-  int* err;                 // set to 1 when an out-of-range token id is met
+  int* err;                 // bit 0: an out-of-range token id was met; bit 1: the text differs from x_shared inside the shared prefix
+  const int64_t* x_shared;  // skip > 0: sequence 0's text, whose first `skip` tokens this sequence claims to share (null = unchecked)
   int text_rows;
   int skip;                 // leading rows NOT emitted (their K/V are shared with sequence 0): the grid covers rows [skip, Lx + n_cols)
   int* logit_row;           // optional: *logit_row = logit_row_val (row of the last prefill group
@@ -353,6 +354,12 @@ hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ks
                           hipStream_t s);
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
 extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production
+// Launch census (process-wide, host side): which kernel FORM each launcher picked.  Read through
+// vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one
+// they compared with the oracle.
+enum { VC_LC_ROWS_GEMM = 0, VC_LC_MT2 = 1, VC_LC_MT4 = 2, VC_LC_BLK64 = 3, VC_LC_BLK128_SBS = 4, VC_LC_BLK128_2X2 = 5,
+       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_PERSIST = 10, VC_LC_N = 16 };
+extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);
 hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s);

@@ -603,6 +603,7 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   }
   e->host_ms[3] = now_ms() - t1;
   e->host_ms[4] = 0;
+  e->host_ms[5] = launched;                               // decode steps LAUNCHED (a multiple of steps_per_graph; the tail are no-ops)
   if (steps_run) *steps_run = launched;
   return rc;
 }
@@ -637,8 +638,10 @@ int check_ready(vc_engine* e) {
 int check_err_flag(vc_engine* e, hipStream_t s) {
   HIPCHK(e, hipMemcpyAsync(e->h_flag, e->err_flag, sizeof(int), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
-  if (*e->h_flag) {
+  if (const int bits = *e->h_flag) {
     (void)hipMemsetAsync(e->err_flag, 0, sizeof(int), s);   // already on the error path
+    if (bits & 2)
+      return fail(e, VC_EINVAL, "shared_text_prefix: a sequence's text differs from sequence 0's inside the shared prefix");
     return fail(e, VC_EINVAL, "token id out of range in x or y (text rows %d, audio vocab %d)", e->cfg.text_rows, e->V);
   }
   return VC_OK;
@@ -928,6 +931,12 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
     max_steps = std::max(max_steps, steps);
   }
   max_steps = std::min(max_steps, e->gen_cap);
+  // the device word share_len is non-zero only inside this call, whichever way it ends (a later vc_eval_forward or
+  // vc_edit would otherwise read positions below it from sequence 0's cache)
+  struct ShareGuard {
+    vc_engine* e; hipStream_t s; bool armed = false;
+    ~ShareGuard() { if (armed) (void)hipMemsetAsync(e->share_len, 0, sizeof(int), s); }
+  } share_guard{e, s};
   HIPCHK(e, hipEventRecord(e->ev[0], s));
   // ---- prompts + ONE prefill over all of them; best-of-N prefills once and replicates the cache
   {
@@ -939,11 +948,13 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
       pas[b].n_seg = 1; pas[b].n_cols = j.T + 1;
       pas[b].seg[0] = Segment{0, j.T + 1, 0, j.T, -1, -1};
       pas[b].skip = (b > 0) ? shared_prefix : 0;          // the shared text prefix is prefilled once, in sequence 0
+      pas[b].x_shared = jobs[0].x;                        // ... and checked on the device to be the same text (prompt_k)
       slots[b] = b;
       e->h_st[b] = init_state(e, j.Lx, j.T + 1, true, 1);
     }
     e->h_flag[2] = shared_prefix;
     HIPCHK(e, hipMemcpyAsync(e->share_len, e->h_flag + 2, sizeof(int), hipMemcpyHostToDevice, s));
+    share_guard.armed = shared_prefix > 0;
     int rc = prefill_batch(e, pas, slots, s);
     if (rc) return rc;
   }
@@ -981,7 +992,6 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];
-  if (shared_prefix) HIPCHK(e, hipMemsetAsync(e->share_len, 0, sizeof(int), s));
   if (steps_out) {   // steps really taken (the longest sequence), not the launched multiple of steps_per_graph
     int m = 0;
     for (int b = 0; b < B; ++b) m = std::max(m, e->h_st[b].total_steps);
@@ -1233,7 +1243,7 @@ int eval_layout(const vc_model_cfg& c, int K, int Lx, int T, const int32_t* iv, 
 }
 
 // ------------------------------------------------------------------------------------- training objective
-// VoiceCraft.forward (voicecraft.py:472-559) with given mask intervals.  EXPERIMENTAL (not yet run on hardware).
+// VoiceCraft.forward (voicecraft.py:472-559) with given mask intervals (validated on MI355X: tests/test_gpu_forward.py).
 // The decoder pass is the prefill's (row stream over all utterances, block GEMM + tile attention); after every pass the
 // heads run over its rows 16 at a time and ce_rows_k turns each group's logits into per-row terms straight away, so the
 // [rows][K][V] logits of the whole batch never exist.
@@ -1393,6 +1403,7 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "sampler_ts") { src = e->dbg_ts; avail = 16 * 8; }
   else if (n == "kernel_ts") { src = e->dbg_ts; avail = 64 * 8; }
   else if (n == "host_ms") { host_src = e->host_ms; avail = 8 * 8; }
+  else if (n == "launch_counts") { host_src = vc_launch_counts; avail = VC_LC_N * 8; }     // process-wide census of kernel forms (vc_common.h)
   else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
   if (nbytes > avail) return fail(e, VC_ECAP, "debug buffer '%s' holds %lld bytes", n.c_str(), (long long)avail);
   if (host_src) { memcpy(host_dst, host_src, (size_t)nbytes); return VC_OK; }
@@ -1417,6 +1428,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   if (!which || n_rows < 1 || iters < 1 || !avg_ms) return fail(e, VC_EINVAL, "bad argument to vc_bench_kernel");
   const bool pf = std::string(which).rfind("pf_", 0) == 0;      // prefill block GEMM: up to VC_MAX_ROWS rows
   if (n_rows > (pf ? VC_MAX_ROWS : VC_ROWS)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed %d", n_rows, pf ? VC_MAX_ROWS : VC_ROWS);
+  if (pf && (n_rows > e->emb_cap || n_rows > e->S_max)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed the prefill arena / cache", n_rows);
   hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
   const std::string w = which;
   const int d = e->d;
@@ -1425,6 +1437,13 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   for (int i = 0; i < VC_ROWS; ++i) pos[i] = i;
   if (std::string(which).rfind("attn", 0) == 0)          // attention: a 16 s utterance's worth of cached positions
     for (int i = 0; i < VC_ROWS; ++i) pos[i] = std::min(e->S_max - 1, 883);
+  if (pf) {   // prefill row tables: sequence 0, positions 0..n_rows-1
+    std::vector<int> pseq(n_rows, 0), ppos(n_rows);
+    for (int i = 0; i < n_rows; ++i) ppos[i] = i;
+    HIPCHK(e, hipMemcpyAsync(e->pre_row_seq, pseq.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipMemcpyAsync(e->pre_row_pos, ppos.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(e, hipStreamSynchronize(s));                   // the staging vectors die with this scope
+  }
   HIPCHK(e, hipMemcpyAsync(e->dec_row_seq, seq.data(), VC_ROWS * 4, hipMemcpyHostToDevice, s));
   HIPCHK(e, hipMemcpyAsync(e->dec_row_pos, pos.data(), VC_ROWS * 4, hipMemcpyHostToDevice, s));
   HIPCHK(e, hipMemsetAsync(e->dec_h, 0, (size_t)VC_ROWS * d * 4, s));
@@ -1482,6 +1501,14 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       hipError_t le = vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s);
       vc_blk_dbg_mask = 0;
       HIPCHK(e, le);
+    } else if (w == "pf_attn") {      // the prefill's MFMA tile attention: n_rows consecutive positions of sequence 0 (16-row tiles)
+      AttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = 1; a.scale = 1.0f / sqrtf((float)e->hd);
+      a.row_seq = e->pre_row_seq; a.row_pos = e->pre_row_pos; a.n_rows = n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
+      a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.x_out = e->xn;
+      HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);
       if (r) return r;
@@ -1509,6 +1536,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     else if (w == "oproj") b = 1.0 * d * d * es + n_rows * (d * 4.0 * 2);
     else if (w == "attn") b = n_rows * 2.0 * d * es * (std::min(e->S_max - 1, 883) + 1);   // K and V of every cached position
     else if (w == "pf_ffn1") b = 2.0 * n_rows * (double)d * 4.0 * d;                       // FLOPs, not bytes (MFMA roofline)
+    else if (w == "pf_attn") b = 4.0 * d * ((double)n_rows * (n_rows + 1) / 2.0);          // FLOPs of Q K^T and P V under the causal mask
     else b = (double)e->L * (12.0 * d * d + 13.0 * d) * es + 2.0 * d * es +
              (double)e->K * ((double)d * e->P + e->P + (double)e->P * e->V + e->V) * es;
     *alg_bytes = b;

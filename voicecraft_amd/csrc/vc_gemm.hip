@@ -16,11 +16,12 @@
 // :1084-1086), and LN(x) = (x - mean) * rstd * gamma + beta is affine in x up to two per-row scalars:
 //   W LN(x) + c = rstd * ( (W . gamma) x  -  mean * rowsum(W . gamma) )  +  (W beta + c)
 // so the engine stores W' = W . gamma (column-scaled at load time, pack_k), wg = rowsum(W') over the
-// ROUNDED elements and cb = W beta + c (fold_vecs_k).  A decode GEMM then multiplies the UN-normalised row
-// and applies mean / rstd in its epilogue: the row's statistics are two wave sums computed in the shadow of
-// the weight stream instead of a two-pass LayerNorm (2 block barriers, ~3000 clocks, measured) on the
-// critical path of every launch.  Multi-row passes normalise once per row in ln_rows_k (x_hat = (x - mean)
-// * rstd, no affine) and use the same W' / cb through the plain prologue.
+// ROUNDED elements and cb = W beta + c (fold_vecs_k).  A decode GEMM then multiplies the CENTRED, un-scaled row
+// xc = x - mean(x) (one block barrier for the mean; centring BEFORE the rounding to bf16 keeps the mantissa for the
+// signal when the residual stream carries a large common offset - tests/test_gpu_model.py, offset case) and applies
+// rstd and the small residual mean of the rounded row in its epilogue, from two wave sums computed in the shadow of
+// the weight stream.  Multi-row passes normalise once per row in ln_rows_k (x_hat = (x - mean) * rstd, no affine)
+// and use the same W' / cb through the plain prologue.
 //
 // Block = 4 waves sharing one 16-row output tile; the waves split the block's K range 4 ways and
 // reduce through LDS.  Cross-block split-K (EPI_PART) leaves fp32 partial slabs that the NEXT
@@ -234,7 +235,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   const int xs = kblk * (int)sizeof(WT) + 16;     // LDS row stride in bytes (+16: rotate bank slots)
   char* xl = smem;
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
-  float* stat = reinterpret_cast<float*>(red + 256);      // LN prologue: [row][wave][sum, sum of squares]
+  float* stat = reinterpret_cast<float*>(red + 256);      // LN prologue: [row][wave][sum, sum of squares] of the centred, rounded row
+  float* msum = stat + VC_ROWS * 4 * 2;                   // LN prologue: [row][wave] partial sums of the fp32 row (its mean)
 
   // Tile height: the QKV projection (N = 3d) uses 12-channel tiles, so that its 3d/12 = d/4 tiles are
   // a multiple of the CU count (512 workgroups of 48 KB at d = 2048 instead of 384 of 64 KB = 1.5 per
@@ -276,9 +278,9 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   // branch-free (out-of-range lanes re-read a valid address, unused split slabs are read and discarded
   // by a select): a load inside a branch makes the compiler drain the whole queue (vmcnt(0)).
   if constexpr (PRO == PRO_LN) {
-    // LayerNorm fold (see the top of this file): X = hn = h + prev_bias + sum(parts), un-normalised; the row's
-    // sum and sum of squares (of the ROUNDED values the MFMA multiplies) are reduced per wave here, in the
-    // shadow of the weight stream, and combined in the epilogue.  The whole block works on one row at a time:
+    // LayerNorm fold (see the top of this file): hn = h + prev_bias + sum(parts); X = hn - mean(hn), un-scaled; the
+    // sum and sum of squares of the ROUNDED centred values the MFMA multiplies are reduced per wave here, in the
+    // shadow of the weight stream, and combined in the epilogue (the residual mean of the rounded row and rstd).  The whole block works on one row at a time:
     // thread t owns float4 columns t and t+256.  Rows beyond the first are software-pipelined through two
     // register sets (the next row's loads fly during this row's arithmetic).
     const int d = a.d;
@@ -315,18 +317,27 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
         x1.x += u_ ? p1##S[s_].x : 0.f; x1.y += u_ ? p1##S[s_].y : 0.f; x1.z += u_ ? p1##S[s_].z : 0.f; x1.w += u_ ? p1##S[s_].w : 0.f; \
       }                                                                                          \
       const bool writer_ = a.h_out && grp == 0 && (((r) % (int)gridDim.x) == (int)blockIdx.x);   \
+      if (writer_ && on0) *reinterpret_cast<float4*>(a.h_out + (long)(r) * d + c0) = x0;         \
+      if (writer_ && on1) *reinterpret_cast<float4*>(a.h_out + (long)(r) * d + c1) = x1;         \
+      /* the row is CENTRED before it is rounded to the MFMA's input type: a residual stream with a large common   */ \
+      /* offset (|mean| >> sigma, usual in trained pre-LN stacks) would otherwise spend its bf16 mantissa on the   */ \
+      /* offset and the rounding error would come out of the fold amplified by |mean| / sigma                      */ \
+      float t_ = (on0 ? ((x0.x + x0.y) + (x0.z + x0.w)) : 0.f) + (on1 ? ((x1.x + x1.y) + (x1.z + x1.w)) : 0.f);  \
+      t_ = wave_sum(t_);                                                                         \
+      if (lane == 0) msum[(r) * 4 + wave] = t_;                                                  \
+      __syncthreads();                                                                           \
+      const float4 ms_ = *reinterpret_cast<const float4*>(msum + (r) * 4);                       \
+      const float mu_ = ((ms_.x + ms_.y) + (ms_.z + ms_.w)) * (1.0f / (float)d);                 \
       WT* xr_ = reinterpret_cast<WT*>(xl + (size_t)(r) * xs);                                    \
       float s1_ = 0.f, s2_ = 0.f;                                                                \
       if (on0) {                                                                                 \
-        if (writer_) *reinterpret_cast<float4*>(a.h_out + (long)(r) * d + c0) = x0;              \
-        const f32x4 y_ = {x0.x, x0.y, x0.z, x0.w};                                               \
+        const f32x4 y_ = {x0.x - mu_, x0.y - mu_, x0.z - mu_, x0.w - mu_};                       \
         const f32x4 q_ = store4r(xr_ + c0, y_);                                                  \
         s1_ += (q_[0] + q_[1]) + (q_[2] + q_[3]);                                                \
         s2_ += (q_[0] * q_[0] + q_[1] * q_[1]) + (q_[2] * q_[2] + q_[3] * q_[3]);                \
       }                                                                                          \
       if (on1) {                                                                                 \
-        if (writer_) *reinterpret_cast<float4*>(a.h_out + (long)(r) * d + c1) = x1;              \
-        const f32x4 y_ = {x1.x, x1.y, x1.z, x1.w};                                               \
+        const f32x4 y_ = {x1.x - mu_, x1.y - mu_, x1.z - mu_, x1.w - mu_};                       \
         const f32x4 q_ = store4r(xr_ + c1, y_);                                                  \
         s1_ += (q_[0] + q_[1]) + (q_[2] + q_[3]);                                                \
         s2_ += (q_[0] * q_[0] + q_[1] * q_[1]) + (q_[2] * q_[2] + q_[3] * q_[3]);                \
@@ -515,7 +526,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
     }
-    if constexpr (PRO == PRO_LN) {   // LayerNorm fold: y = rstd * (W'x - mean * rowsum(W')) [+ cb in the epilogue]
+    if constexpr (PRO == PRO_LN) {   // LayerNorm fold on the centred row xc: y = rstd * (W'xc - mean(xc) * rowsum(W')) [+ cb in the epilogue]
       const float4 sa = *reinterpret_cast<const float4*>(stat + m * 8), sb = *reinterpret_cast<const float4*>(stat + m * 8 + 4);
       const float inv_d = 1.0f / (float)a.d;
       const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * inv_d;
@@ -710,6 +721,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
 // channels: each X byte staged in LDS feeds twice as many MFMAs - the L2->LDS traffic of X is what bounds the
 // 64-channel form once the grid is large enough).
 int vc_blk_dbg_mask = 0;     // diagnostic mask of the block GEMM (see the kernel); only the kernel microbenchmark sets it
+long long vc_launch_counts[VC_LC_N] = {0};
 #define VC_BLK_M 128
 #define VC_BLK_KT 4          // k-tiles per pipeline chunk
 template <typename WT, int EPI, int NTW, int WM, int OCC>
@@ -963,6 +975,7 @@ __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   }
 }
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s) {
+  ++vc_launch_counts[VC_LC_LN_ROWS];
   if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(ln_rows_k<bf16_t>, dim3(a.n_rows), dim3(256), 0, s, a);
   else hipLaunchKernelGGL(ln_rows_k<float>, dim3(a.n_rows), dim3(256), 0, s, a);
   return hipGetLastError();
@@ -972,7 +985,7 @@ hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s) {
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   const int esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
   const size_t xs = (size_t)(a.K / ksplit) * esz + 16;
-  return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4) + VC_ROWS * 4 * 2 * sizeof(float);   // X rows, K-reduce area, LN statistics
+  return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4) + VC_ROWS * 4 * 3 * sizeof(float);   // X rows, K-reduce area, LN statistics + row means
 }
 
 template <typename WT, int KTW, int PRO, int EPI>
@@ -1002,6 +1015,7 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
       if ((1 << sft) == q4) b.att_q4_shift = sft;
     }
   }
+  ++vc_launch_counts[VC_LC_ROWS_GEMM];
   hipLaunchKernelGGL(kern, dim3(a.n_tiles, ksplit, groups), dim3(256), lds, s, b);
   return hipGetLastError();
 }
@@ -1024,6 +1038,7 @@ static hipError_t launch_blk_n(const GemmArgs& a, int ksplit, hipStream_t s) {
   dim3 grid(a.n_tiles / (WN * NTW), (a.n_rows + VC_BLK_M - 1) / VC_BLK_M, ksplit);
   GemmArgs b = a;
   b.att_q4_shift = vc_blk_dbg_mask;                     // 0 except inside vc_bench_kernel("pf_ffn1") under VC_BLK_DBG
+  ++vc_launch_counts[(NTW == 2 && WM == 1) ? VC_LC_BLK128_SBS : (NTW == 4) ? VC_LC_BLK128_2X2 : (OCC == 2) ? VC_LC_BLK64_OCC2 : VC_LC_BLK64];
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, b);
   return hipGetLastError();
 }
@@ -1074,6 +1089,7 @@ static hipError_t launch_mt_n(const GemmArgs& a, int dtype, int ksplit, int grou
       granted[dev] = lds;
     }
   }
+  ++vc_launch_counts[NTW == 4 ? VC_LC_MT4 : VC_LC_MT2];
   hipLaunchKernelGGL(kern, dim3((a.n_tiles + NTW - 1) / NTW, ksplit, groups), dim3(256 * NTW), lds, s, b);
   return hipGetLastError();
 }

@@ -87,9 +87,15 @@ __global__ __launch_bounds__(256) void prompt_k(const PromptArgs a) {
     a.row_pos[a.row0 + blockIdx.x] = row;
     if (blockIdx.x == 0 && a.logit_row) *a.logit_row = a.logit_row_val;
   }
+  // rows [0, skip) are not emitted: their K/V are read from sequence 0's cache, so the texts must agree there
+  if (blockIdx.x == 0 && a.skip > 0 && a.x_shared) {
+    bool bad = false;
+    for (int i = threadIdx.x; i < a.skip; i += blockDim.x) bad |= (a.x[i] != a.x_shared[i]);
+    if (bad) atomicOr(a.err, 2);
+  }
   if (row < a.Lx) {
     long tok = a.x[row];
-    if (tok < 0 || tok >= a.text_rows) { if (threadIdx.x == 0) *a.err = 1; tok = 0; }
+    if (tok < 0 || tok >= a.text_rows) { if (threadIdx.x == 0) atomicOr(a.err, 1); tok = 0; }
     const float* e = a.text_emb + tok * d;
     const float* pe = a.pe + (long)row * d;
     for (int c = threadIdx.x; c < d; c += blockDim.x) dst[c] = e[c] + a.alpha_text * pe[c];
@@ -113,7 +119,7 @@ __global__ __launch_bounds__(256) void prompt_k(const PromptArgs a) {
     const int i = s - 1 - q;
     long tok = a.empty_token;
     if (i >= 0 && i < n) tok = (i < sg.src_len) ? a.y[(long)(sg.src0 + i) * a.K + q] : sg.term;
-    if (tok < 0 || tok >= a.V) { if (threadIdx.x == 0) *a.err = 1; tok = a.empty_token; }
+    if (tok < 0 || tok >= a.V) { if (threadIdx.x == 0) atomicOr(a.err, 1); tok = a.empty_token; }
     e[q] = a.audio_emb + ((long)q * a.V + tok) * d;
   }
   for (int c = threadIdx.x; c < d; c += blockDim.x) {

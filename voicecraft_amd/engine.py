@@ -37,41 +37,6 @@ def _sine_table(n: int, d: int) -> torch.Tensor:
     return pe.contiguous()
 
 
-def draw_mask_intervals(args, y_lens):
-    """`VoiceCraft.prepare_mask_intervals` (models/voicecraft.py:198-237), call for call on Python's `random` (and
-    torch's generator for the Poisson option), so that `random.seed(n)` gives the reference's intervals.  Needs the
-    training fields of `args` (mask_sample_dist, mask_len_min, mask_len_max, min_gap, max_n_spans).
-    Returns (mask_intervals, non_mask_intervals) as the reference does."""
-    import random
-    a = args
-    mask_intervals, non_mask_intervals = [], []
-    for y_len in [int(v) for v in y_lens]:
-        if a.mask_sample_dist == "uniform":
-            n_spans = random.choice(range(1, a.max_n_spans + 1))
-        elif "poisson" in a.mask_sample_dist.lower():
-            param = float(a.mask_sample_dist[len("poisson"):])
-            n_spans = int(torch.poisson(torch.tensor([param])).clamp(1, a.max_n_spans).item())
-        else:
-            raise AssertionError(f"mask_sample_dist {a.mask_sample_dist!r}")
-        starts = sorted(random.sample(range(1, y_len - 1 - a.mask_len_min), n_spans))
-        for j in range(len(starts) - 1, 0, -1):
-            if starts[j] - starts[j - 1] < a.min_gap:
-                del starts[j]
-        assert len(starts) > 0, f"there is no masked span left, y_len: {y_len}, sampled n_spans: {n_spans}"
-        temp = starts + [y_len]
-        gaps = [temp[j + 1] - temp[j] for j in range(len(temp) - 1)]
-        ends = []
-        for start, gap in zip(starts, gaps):
-            mask_len = random.randint(a.mask_len_min, a.mask_len_max)
-            if mask_len > gap - 1:
-                mask_len = random.randint(1, gap - 1)
-            ends.append(start + mask_len)
-        mask_intervals.append([(s, e) for s, e in zip(starts, ends)])
-        non_mask_intervals.append([(ns, ne) for ns, ne in zip([0] + ends, starts + [y_len])])
-    return mask_intervals, non_mask_intervals
-
-
-
 class VoiceCraftEngine:
     """Drop-in for `VoiceCraft(args)` + `load_state_dict` + `.to(device).eval()` on the inference path.
 
@@ -303,19 +268,15 @@ class VoiceCraftEngine:
             return outs, logits
         return outs
 
-    # ---- the training objective, teacher-forced.  EXPERIMENTAL: not yet validated on hardware.
-    def draw_mask_intervals(self, y_lens):
-        """`VoiceCraft.prepare_mask_intervals` (models/voicecraft.py:198-237): see the module-level function."""
-        return draw_mask_intervals(self.args, y_lens)
-
+    # ---- the training objective, teacher-forced
     @torch.no_grad()
-    def forward(self, batch, mask_intervals=None, mask_values=None, _per_row: bool = False):
+    def forward(self, batch, mask_intervals, mask_values=None, _per_row: bool = False):
         """`VoiceCraft.forward` (models/voicecraft.py:472-559) as an evaluation pass: batch = {"x" [B,Lx], "x_lens" [B],
         "y" [B,K,T], "y_lens" [B]} exactly as the reference's collate gives it; returns the reference's dict
         (`loss` = sum over codebooks of weight * summed cross-entropy, `top10acc`, `top10acc_by_codebook`,
-        `effective_ntoken`).  The reference draws the mask intervals inside (`prepare_mask_intervals`); pass them as
-        `mask_intervals` (list per utterance of (start, end) frames) to evaluate fixed spans, otherwise they are drawn
-        by the restated procedure.  `mask_values[i]` = the utterance's `emb_inds_use` (default 0..M-1; the reference
+        `effective_ntoken`).  The reference SAMPLES the masked spans inside (`prepare_mask_intervals`, :198-237 - training
+        data augmentation, out of this engine's scope); here they are an argument: `mask_intervals[i]` = the (start, end)
+        frame pairs of utterance i.  `mask_values[i]` = the utterance's `emb_inds_use` (default 0..M-1; the reference
         shuffles them when `shuffle_mask_embedding` is set).  No gradients: this engine does not train."""
         import ast
         import random
@@ -329,8 +290,7 @@ class VoiceCraftEngine:
         assert y_lens.ndim == 1, y_lens.shape
         B = int(x.shape[0])
         assert B <= self.max_seqs, (B, self.max_seqs)
-        if mask_intervals is None:
-            mask_intervals, _ = self.draw_mask_intervals(y_lens)
+        assert mask_intervals is not None and len(mask_intervals) == B, "one list of (start, end) spans per utterance"
         if mask_values is None:
             mask_values = []
             for iv in mask_intervals:
@@ -479,6 +439,15 @@ class VoiceCraftEngine:
         check(self.lib.vc_bench_kernel(self._h, which.encode(), n_rows, iters, C.byref(ms), C.byref(nbytes), self._stream()),
               self._h, "vc_bench_kernel")
         return ms.value, nbytes.value
+
+    LAUNCH_FORMS = ("rows_gemm", "mt2", "mt4", "blk64", "blk128_sbs", "blk128_2x2", "blk64_occ2", "ln_rows", "rows_attn",
+                    "tile_attn", "persist")
+
+    def launch_counts(self) -> dict:
+        """Process-wide census of the kernel FORMS launched so far (vc_common.h VC_LC_*): the parity tests take the
+        difference around a call to assert which form a benchmarked shape really runs on."""
+        c = self.debug_read("launch_counts", (16,), torch.int64)
+        return {n: int(c[i]) for i, n in enumerate(self.LAUNCH_FORMS)}
 
     def debug_read(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
         out = torch.empty(shape, dtype=dtype)

@@ -40,7 +40,7 @@ def make_args(preset: str = "giga830M", *, eos: int = 2051, n_special: int = 4, 
 
 
 def make_state_dict(args: Namespace, seed: int = 0, perturb: bool = True, mute_eos: bool = True,
-                    head_gain: float = 1.0, fast: bool = False, boost=None) -> dict[str, torch.Tensor]:
+                    head_gain: float = 1.0, fast: bool = False, boost=None, mute_special: bool = False) -> dict[str, torch.Tensor]:
     """fp32 state_dict with the reference's keys and shapes.
 
     mute_eos: bias of the terminator logit = -1e4 on every head, so that no terminator is ever
@@ -49,6 +49,8 @@ def make_state_dict(args: Namespace, seed: int = 0, perturb: bool = True, mute_e
     head_gain: scales the last head matrices; > 1 gives peaked distributions (clear arg-max margins).
     fast: draw with torch's CPU generator instead of numpy's RandomState (10x faster for the
       multi-GB presets; deterministic for a given torch build, not used by the golden fixtures).
+    mute_special: the same bias on EVERY special token (empty / eog / pad / eos), so that generated frames hold plain
+      codes only and can be handed to the codec (a trained model never emits them mid-utterance; random weights do).
     boost: iterable of (codebook, token, delta): `predict_layer[codebook][2].bias[token] += delta` after
       everything else.  With mute_eos=False this makes the terminator / a silence token likely, so
       that the end-of-generation and silence-penalty branches of the state machine actually fire
@@ -107,6 +109,8 @@ def make_state_dict(args: Namespace, seed: int = 0, perturb: bool = True, mute_e
         b = uni((V,), P ** -0.5)
         if mute_eos:
             b[term] = -1e4
+        if mute_special:
+            b[args.audio_vocab_size:] = -1e4
         for (bk, tok, delta) in (boost or ()):
             if bk == k or bk < 0:
                 b[int(tok)] += float(delta)
