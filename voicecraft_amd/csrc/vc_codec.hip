@@ -438,10 +438,11 @@ __global__ __launch_bounds__(512) void lstm_persist_k(const LstmPersistArgs a) {
   const int s0 = wave * (H >> 3) + GPL * lane;
   // The clips of a batch advance together, VC_LSTM_BG at a time: ONE hand-off round (poll, park, barrier) per step serves
   // every clip of the group, and the register-resident weights are reused for all of them.
+  const int bg = min(VC_LSTM_BG, a.B);                    // clips per group = what the launcher sized the LDS for
   for (int b0 = 0; b0 < a.B; b0 += VC_LSTM_BG) {
     const int nb = min(VC_LSTM_BG, a.B - b0);
     for (int t = 0; t < a.T; ++t) {
-      float* sbuf = s_hx + (size_t)(t & 1) * (VC_LSTM_BG * 2 * H);
+      float* sbuf = s_hx + (size_t)(t & 1) * (bg * 2 * H);
       // ---- bounded wait for this wave's slices of h_{t-1} (own layer) and, on layer 1, of the lower layer's h_t
       bool ok = true;
       if (t || n == 1) {
