@@ -99,3 +99,83 @@ def test_bulk_encode_follows_the_reference_batching():
         T = round(n / 16000 * 50)
         assert out[i].shape == (4, T)
         assert torch.equal(out[i][0], i * 10000 + torch.arange(T))
+
+
+def audiocraft_checkpoint_keys():
+    """The tensor names of an audiocraft EncodecModel `best_state` at the VoiceCraft codec shape (encodec_4cb2048_giga.th;
+    audiocraft @ c5157b5, README.md:105), written out from its constructors: SEANetEncoder.model = [conv, (resblock,
+    ELU, down-conv) x 4 ratios (reversed), LSTM, ELU, conv]; SEANetDecoder.model = [conv, LSTM, (ELU, up-convtr,
+    resblock) x 4, ELU, conv]; StreamableConv1d -> NormConv1d (`.conv.conv`, weight_norm: weight_g / weight_v),
+    StreamableConvTranspose1d (`.convtr.convtr`); SEANetResnetBlock.block = [ELU, conv k3, ELU, conv k1] with an
+    identity skip (true_skip); StreamableLSTM.lstm; ResidualVectorQuantizer.vq.layers[q]._codebook with its EMA
+    buffers.  -> {name: shape}"""
+    F, ratios, H, Kc, D = 64, [8, 5, 4, 2], 128, 2048, 128
+    keys = {}
+
+    def conv(prefix, co, ci, k, tr=False):
+        inner = "convtr.convtr" if tr else "conv.conv"
+        keys[f"{prefix}.{inner}.weight_g"] = ((ci if tr else co), 1, 1)
+        keys[f"{prefix}.{inner}.weight_v"] = (ci, co, k) if tr else (co, ci, k)
+        keys[f"{prefix}.{inner}.bias"] = (co,)
+
+    def res(prefix, dim):
+        conv(f"{prefix}.block.1", dim // 2, dim, 3)
+        conv(f"{prefix}.block.3", dim, dim // 2, 1)
+
+    def lstm(prefix, h):
+        for n in range(2):
+            keys[f"{prefix}.lstm.weight_ih_l{n}"] = (4 * h, h)
+            keys[f"{prefix}.lstm.weight_hh_l{n}"] = (4 * h, h)
+            keys[f"{prefix}.lstm.bias_ih_l{n}"] = (4 * h,)
+            keys[f"{prefix}.lstm.bias_hh_l{n}"] = (4 * h,)
+
+    conv("encoder.model.0", F, 1, 7)
+    i, ch = 1, F
+    for r in reversed(ratios):
+        res(f"encoder.model.{i}", ch)
+        conv(f"encoder.model.{i + 2}", 2 * ch, ch, 2 * r)
+        i, ch = i + 3, 2 * ch
+    lstm(f"encoder.model.{i}", ch)
+    conv(f"encoder.model.{i + 2}", H, ch, 7)
+    conv("decoder.model.0", ch, H, 7)
+    lstm("decoder.model.1", ch)
+    i = 2
+    for r in ratios:
+        conv(f"decoder.model.{i + 1}", ch // 2, ch, 2 * r, tr=True)
+        res(f"decoder.model.{i + 2}", ch // 2)
+        i, ch = i + 3, ch // 2
+    conv(f"decoder.model.{i + 1}", 1, F, 7)
+    for q in range(4):
+        p = f"quantizer.vq.layers.{q}._codebook"
+        keys[p + ".inited"] = (1,)
+        keys[p + ".cluster_size"] = (Kc,)
+        keys[p + ".embed"] = (Kc, D)
+        keys[p + ".embed_avg"] = (Kc, D)
+    return keys
+
+
+def test_a_whole_audiocraft_checkpoint_key_set_loads_with_strict_coverage():
+    """Every tensor name an audiocraft checkpoint of this codec holds - 28 convolutions (weight_g / weight_v / bias), two
+    2-layer LSTMs, 4 codebooks with their EMA buffers: 112 tensors - must map onto EXACTLY the canonical names the
+    engine's strict loader expects (voicecraft_amd.codec.expected_keys), with the folded weights' shapes right; the
+    restatement's own (transformers) names of the same architecture must normalise to the same set.  No arithmetic is
+    pinned by this (parity with audiocraft's outputs stays unpinned): it pins the NAME layout the loader accepts."""
+    from voicecraft_amd.codec import expected_keys
+    names = audiocraft_checkpoint_keys()
+    assert len(names) == 28 * 3 + 2 * 8 + 4 * 4
+    rs = np.random.RandomState(0)
+    sd = {k: torch.from_numpy(rs.standard_normal(size=s).astype(np.float32)) for k, s in names.items()}
+    n = normalize_state_dict(sd)
+    buffers = (".inited", ".cluster_size", ".embed_avg")
+    got = {k for k in n if not k.endswith(buffers)}
+    want = expected_keys(DEFAULT_CFG)
+    assert got == want, (sorted(got - want)[:5], sorted(want - got)[:5])
+    ours = {k for k in normalize_state_dict(synth.make_codec_state_dict(0)) if not k.endswith(buffers)}
+    assert ours == want
+    # shapes of the folded convolution weights = the restatement's module weights
+    m = eo.build(synth.make_codec_state_dict(0))
+    for name, mod in m.named_modules():
+        if hasattr(mod, "conv") and hasattr(mod.conv, "weight") and name:
+            assert tuple(n[name + ".conv.weight"].shape) == tuple(mod.conv.weight.shape), name
+    g, v = sd["encoder.model.3.conv.conv.weight_g"], sd["encoder.model.3.conv.conv.weight_v"]
+    assert torch.allclose(n["encoder.layers.3.conv.weight"], fold_weight_norm(g, v))

@@ -66,36 +66,39 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
   const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int k = 0; k < a.Kw; ++k) {
-    const float* xp[2];
-    bool ok[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-      const int t = min(t0 + ni * 16 + m, a.T - 1);
-      int p = t * a.s_in + k * a.dil - a.pad;
-      bool v = true;
-      if (a.reflect) {
-        if (p < 0) p = -p;
-        if (p >= a.L_ext) p = 2 * (a.L_ext - 1) - p;
-        v = p < a.L_in;                                  // the zero extension of an input shorter than its padding
-        p = max(0, min(p, a.L_in - 1));
-      } else {
-        v = (p >= 0 && p < a.L_in);
-        p = max(0, min(p, a.L_in - 1));
-      }
-      ok[ni] = v;
-      xp[ni] = xbase + (long)p * a.Ci + 4 * g;
+  // input position of output position t for tap k: (pointer, valid) - explicit scalars (an indexed pair of pointers is
+  // demoted to scratch memory by the compiler)
+  auto tap = [&](int ni, int k, const float*& xp, bool& ok) {
+    const int t = min(t0 + ni * 16 + m, a.T - 1);
+    int p = t * a.s_in + k * a.dil - a.pad;
+    bool v = true;
+    if (a.reflect) {
+      if (p < 0) p = -p;
+      if (p >= a.L_ext) p = 2 * (a.L_ext - 1) - p;
+      v = p < a.L_in;                                    // the zero extension of an input shorter than its padding
+      p = max(0, min(p, a.L_in - 1));
+    } else {
+      v = (p >= 0 && p < a.L_in);
+      p = max(0, min(p, a.L_in - 1));
     }
+    ok = v;
+    xp = xbase + (long)p * a.Ci + 4 * g;
+  };
+  for (int k = 0; k < a.Kw; ++k) {
+    const float *xp0, *xp1;
+    bool ok0, ok1;
+    tap(0, k, xp0, ok0);
+    tap(1, k, xp1, ok1);
     const float4* w0 = wp0 + (long)k * ktpk * 64;
     const float4* w1 = wp1 + (long)k * ktpk * 64;
 #pragma unroll 2
     for (int c = 0; c < ktpk; ++c) {
       const float4 wa = w0[(long)c * 64];
       const float4 wb = two ? w1[(long)c * 64] : z4;
-      float4 xa = *reinterpret_cast<const float4*>(xp[0] + c * 16);
-      float4 xb = *reinterpret_cast<const float4*>(xp[1] + c * 16);
-      if (!ok[0]) xa = z4;
-      if (!ok[1]) xb = z4;
+      float4 xa = *reinterpret_cast<const float4*>(xp0 + c * 16);
+      float4 xb = *reinterpret_cast<const float4*>(xp1 + c * 16);
+      if (!ok0) xa = z4;
+      if (!ok1) xb = z4;
       const uint4 uwa = __builtin_bit_cast(uint4, wa), uwb = __builtin_bit_cast(uint4, wb);
       const uint4 uxa = __builtin_bit_cast(uint4, xa), uxb = __builtin_bit_cast(uint4, xb);
       acc[0][0] = mfma_frag(uwa, uxa, acc[0][0], (float*)nullptr);
