@@ -65,7 +65,6 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvArgs a) {
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
   // input position of output position t for tap k: (pointer, valid) - explicit scalars (an indexed pair of pointers is
   // demoted to scratch memory by the compiler)
   auto tap = [&](int ni, int k, const float*& xp, bool& ok) {
@@ -90,15 +89,16 @@ __global__ __launch_bounds__(256) void conv_gemm_k(const ConvArgs a) {
     tap(0, k, xp0, ok0);
     tap(1, k, xp1, ok1);
     const float4* w0 = wp0 + (long)k * ktpk * 64;
-    const float4* w1 = wp1 + (long)k * ktpk * 64;
+    const float4* w1 = (two ? wp1 : wp0) + (long)k * ktpk * 64;      // (a select between a load and a zero constant puts the constant in scratch)
 #pragma unroll 2
     for (int c = 0; c < ktpk; ++c) {
       const float4 wa = w0[(long)c * 64];
-      const float4 wb = two ? w1[(long)c * 64] : z4;
+      float4 wb = w1[(long)c * 64];
+      if (!two) wb = make_float4(0.f, 0.f, 0.f, 0.f);
       float4 xa = *reinterpret_cast<const float4*>(xp0 + c * 16);
       float4 xb = *reinterpret_cast<const float4*>(xp1 + c * 16);
-      if (!ok0) xa = z4;
-      if (!ok1) xb = z4;
+      if (!ok0) xa = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (!ok1) xb = make_float4(0.f, 0.f, 0.f, 0.f);
       const uint4 uwa = __builtin_bit_cast(uint4, wa), uwb = __builtin_bit_cast(uint4, wb);
       const uint4 uxa = __builtin_bit_cast(uint4, xa), uxb = __builtin_bit_cast(uint4, xb);
       acc[0][0] = mfma_frag(uwa, uxa, acc[0][0], (float*)nullptr);

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "vc_common.h"
+#include "vc_stream.h"
 
 namespace {
 
@@ -93,6 +94,16 @@ struct vc_engine {
   float ms[3]{0, 0, 0};
   double host_ms[8]{};                  // host wall clock of the last call's phases (vc_debug_read "host_ms")
   double bytes_total = 0;               // HBM bytes owned by the engine
+  // stream engine (vc_stream.hip): the batch-1 decode step as one persistent launch; off unless VC_STREAM=1 and the
+  // model / device fit it (finalize)
+  bool stream_on = false;
+  int sG = 0;                           // workgroups = d / 8
+  uint4* sW = nullptr;                  // stream-layout weights [L][G][spl][16 KB]
+  StreamLayerDev* sLayers = nullptr;    // device table
+  unsigned long long* sGran = nullptr;  // granule arena
+  unsigned* sCtl = nullptr;             // [0] epoch, [1] error
+  float* sDbg = nullptr;                // VC_STREAM_DBG=1: [L][5][4d] inputs of every op as the kernel saw them
+  bool heads_finished_h = false;        // run_heads16: hB holds the finished residual (no slabs, no pending bias)
   // training objective (vc_eval_forward), allocated on first use
   int *ce_tgt = nullptr, *ce_hit = nullptr;
   float *ce_nll = nullptr;
@@ -342,6 +353,7 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
     g.Wp = e->Wh1; g.bias = e->bh1;
     g.h_in = e->hB + (size_t)in_row0 * e->d; g.h_out = nullptr;
     g.parts = e->parts + (size_t)in_row0 * e->d; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
+    if (e->heads_finished_h) { g.n_parts = 0; g.has_prev_bias = 0; }      // the stream engine left the finished residual in hB
     g.wg = e->wg_h1; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
     if (!gather && n >= e->ln_split_rows) {
@@ -528,12 +540,51 @@ int push_sample_dyn(vc_engine* e, const vc_sample_cfg* sc, const int64_t* forced
   return VC_OK;
 }
 
+StreamArgs stream_args(vc_engine* e) {
+  StreamArgs a;
+  memset(&a, 0, sizeof a);
+  a.Ws = e->sW; a.layers = e->sLayers; a.gran = e->sGran; a.ctl = e->sCtl;
+  a.h_in = e->dec_h; a.h_out = e->hB;
+  a.n_active = e->n_active; a.row_pos = e->dec_row_pos; a.row_seq = e->dec_row_seq;
+  a.d = e->d; a.H = e->H; a.hd = e->hd; a.L = e->L; a.G = e->sG; a.NS = e->sG / e->H; a.S_max = e->S_max;
+  a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+  a.rpc = e->d / 512;
+  a.sq = (6 * a.rpc + 3) / 4; a.so = (2 * a.rpc + 3) / 4; a.s1 = 2 * a.rpc; a.s2 = 2 * a.rpc;
+  a.spl = a.sq + a.so + a.s1 + a.s2;
+  a.gran_layer_stride = sg_gran_per_layer(a);
+  a.scale = 1.0f / sqrtf((float)e->hd);
+  a.dbg = e->sDbg;
+  return a;
+}
+
+int stream_step(vc_engine* e, hipStream_t s) {
+  HIPCHK(e, vc_stream_launch(stream_args(e), s));
+  return VC_OK;
+}
+
+// after a synchronise: a bounded wait of the stream engine that gave up (sCtl[1]); the epoch is moved on so that the
+// granules of the broken step cannot be taken for the next step's
+int check_stream_flag(vc_engine* e) {
+  if (!e->stream_on) return VC_OK;
+  unsigned w[2] = {0, 0};
+  HIPCHK(e, hipMemcpy(w, e->sCtl, 8, hipMemcpyDeviceToHost));
+  if (w[1]) {
+    const unsigned fresh[2] = {w[0] + 2u ? w[0] + 2u : 1u, 0u};
+    (void)hipMemcpy(e->sCtl, fresh, 8, hipMemcpyHostToDevice);
+    return fail(e, VC_EHIP, "stream engine: a hand-off wait exceeded its bound (code 0x%x; workgroups not co-resident?)", w[1]);
+  }
+  return VC_OK;
+}
+
 int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, hipStream_t s) {
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = B * rps; rs.nsplit = attn_nsplit(e, B * rps); rs.n_active = e->n_active;
   int rc;
-  if (rs.n_rows > VC_ROWS) {      // more than one MFMA row tile: the step runs on the block GEMM (per-row LayerNorm launch,
+  const bool stream = e->stream_on && B == 1 && rps == 1 && !grouped;
+  if (stream) {                   // one sequence, one row: ALL layers as one persistent launch (vc_stream.hip)
+    rc = stream_step(e, s);
+  } else if (rs.n_rows > VC_ROWS) {      // more than one MFMA row tile: the step runs on the block GEMM (per-row LayerNorm launch,
     rs.nsplit = 1;                // attention one workgroup per (row, head), no split partials)
     rc = prefill_rows(e, rs, s);
   } else {
@@ -541,7 +592,10 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   }
   if (rc) return rc;
   // rps == 1: logit_row[b] == b (vc_tokens.hip advance_phase); the 3-row span switch is single-sequence
-  if ((rc = run_heads(e, rps == 1 ? nullptr : e->logit_row, B, 0, e->n_active, s))) return rc;
+  e->heads_finished_h = stream;
+  rc = run_heads(e, rps == 1 ? nullptr : e->logit_row, B, 0, e->n_active, s);
+  e->heads_finished_h = false;
+  if (rc) return rc;
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
   return VC_OK;
 }
@@ -765,6 +819,20 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     }
     HIPCHK(e, hipMemcpy(e->pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
   }
+  // ---- stream engine (vc_stream.hip): opt-in (VC_STREAM=1); needs bf16, d a multiple of 512, one workgroup per 8
+  // model channels resident at once (G = d / 8 <= CUs), a whole number of workgroups per head, head_dim 32 / 64 / 128
+  {
+    const char* sv = getenv("VC_STREAM");
+    hipDeviceProp_t prop;
+    HIPCHK(e, hipGetDeviceProperties(&prop, e->device));
+    const int G = d / 8;
+    e->stream_on = sv && atoi(sv) != 0 && e->dtype == VC_DTYPE_BF16 && d % 512 == 0 && G <= prop.multiProcessorCount &&
+                   G % e->H == 0 && (e->hd == 32 || e->hd == 64 || e->hd == 128);
+    if (e->stream_on) {
+      e->sG = G;
+      if ((rc = dalloc(e, (char**)&e->sW, (size_t)L * vc_stream_layer_bytes(d, G)))) return rc;
+    }
+  }
   // ---- decoder layers
   e->layers.resize(L);
   for (int l = 0; l < L; ++l) {
@@ -783,6 +851,17 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if ((rc = dalloc(e, &kc, cache_bytes))) return rc;
     if ((rc = dalloc(e, &vc, cache_bytes))) return rc;
     ly.kc = kc; ly.vc = vc;
+    if (e->stream_on) {   // the same four matrices once more, in the stream layout (LayerNorm gammas folded as in pack_folded)
+      const RawTensor *tq, *to, *t1, *t2, *tg1, *tg2;
+      if ((rc = need(e, pre + "self_attn.in_proj_weight", {3 * d, d}, &tq))) return rc;
+      if ((rc = need(e, pre + "self_attn.out_proj.weight", {d, d}, &to))) return rc;
+      if ((rc = need(e, pre + "linear1.weight", {4 * d, d}, &t1))) return rc;
+      if ((rc = need(e, pre + "linear2.weight", {d, 4 * d}, &t2))) return rc;
+      if ((rc = need(e, pre + "norm1.weight", {d}, &tg1))) return rc;
+      if ((rc = need(e, pre + "norm2.weight", {d}, &tg2))) return rc;
+      HIPCHK(e, vc_stream_pack_layer(tq->dev, to->dev, t1->dev, t2->dev, tg1->dev, tg2->dev,
+                                     (char*)e->sW + (size_t)l * vc_stream_layer_bytes(d, e->sG), d, e->sG, 0));
+    }
     // free the staging copies of this layer right away (3.3 GB for the 830M shape otherwise)
     for (const char* k2 : {"self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"}) {
       auto it = e->raw.find(pre + k2);
@@ -830,6 +909,27 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipDeviceSynchronize());
   for (auto& kv : e->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
   e->raw.clear();
+  if (e->stream_on) {
+    std::vector<StreamLayerDev> tab(L);
+    for (int l = 0; l < L; ++l) {
+      const Layer& ly = e->layers[l];
+      tab[l] = StreamLayerDev{ly.wg_qkv, ly.bqkv, ly.bo, ly.wg_1, ly.b1, ly.b2, ly.kc, ly.vc};
+    }
+    if ((rc = dalloc(e, &e->sLayers, (size_t)L))) return rc;
+    HIPCHK(e, hipMemcpy(e->sLayers, tab.data(), sizeof(StreamLayerDev) * L, hipMemcpyHostToDevice));
+    StreamArgs probe;
+    memset(&probe, 0, sizeof probe);
+    probe.d = d; probe.G = e->sG; probe.hd = e->hd;
+    const size_t ng = (size_t)sg_gran_per_layer(probe) * L;
+    if ((rc = dalloc(e, &e->sGran, ng))) return rc;
+    HIPCHK(e, hipMemset(e->sGran, 0, ng * 8));           // tag 0 is never a live epoch
+    if ((rc = dalloc(e, &e->sCtl, (size_t)4))) return rc;
+    { const unsigned init[4] = {1u, 0u, 0u, 0u}; HIPCHK(e, hipMemcpy(e->sCtl, init, 16, hipMemcpyHostToDevice)); }
+    if (getenv("VC_STREAM_DBG")) {
+      if ((rc = dalloc(e, &e->sDbg, (size_t)L * 5 * 4 * d))) return rc;
+      HIPCHK(e, hipMemset(e->sDbg, 0, (size_t)L * 5 * 4 * d * 4));
+    }
+  }
   // ---- launch plans
   e->p_qkv = make_plan(3 * d, d, e->dtype, false, nullptr, VC_TH_QKV);
   e->p_o = make_plan(d, d, e->dtype, true, "VC_KSPLIT_O");
@@ -989,6 +1089,7 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
+  if ((rc = check_stream_flag(e))) return rc;
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];
@@ -1403,6 +1504,8 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "sampler_ts") { src = e->dbg_ts; avail = 16 * 8; }
   else if (n == "kernel_ts") { src = e->dbg_ts; avail = 64 * 8; }
   else if (n == "host_ms") { host_src = e->host_ms; avail = 8 * 8; }
+  else if (n == "stream_dbg" && e->sDbg) { src = e->sDbg; avail = (int64_t)e->L * 5 * 4 * e->d * 4; }
+  else if (n == "stream_ctl" && e->sCtl) { src = e->sCtl; avail = 16; }
   else if (n == "launch_counts") { host_src = vc_launch_counts; avail = VC_LC_N * 8; }     // process-wide census of kernel forms (vc_common.h)
   else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
   if (nbytes > avail) return fail(e, VC_ECAP, "debug buffer '%s' holds %lld bytes", n.c_str(), (long long)avail);
