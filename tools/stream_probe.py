@@ -93,3 +93,23 @@ for l in range(L):
         out.append(f"{nm} {float((g - r).norm() / (r.norm() + 1e-9)):.4f}")
     print(f"[probe] layer {l}: rel-L2 of the kernel's view vs fp32 CPU: " + " | ".join(out), flush=True)
     h = h3
+
+# ---- phase stamps of the last executed step (100 MHz wall clock -> us), workgroups 0 (a head leader), 1 and G-1
+G = a.d_model // 8
+raw = e1.debug_read("stream_ts", (3 * L * 16 + G * 4,), torch.int64).numpy().astype(np.float64) / 100.0
+ts = raw[: 3 * L * 16].reshape(3, L, 16)
+per_cu = raw[3 * L * 16:].reshape(G, 4)                  # layer L/2, every workgroup: ffn1 done, act gathered, ffn2 done, h gathered
+if per_cu[0, 0] > 0:
+    t0 = per_cu[:, 0].min()
+    q = lambda v: " ".join(f"{np.percentile(v - t0, p):.2f}" for p in (0, 10, 50, 90, 100))
+    print(f"[probe] layer {L // 2}, all {G} workgroups, us after the first ffn1-done (min p10 p50 p90 max): ffn1-done {q(per_cu[:, 0])} | act-gathered {q(per_cu[:, 1])} | "
+          f"ffn2-done {q(per_cu[:, 2])} | h-gathered {q(per_cu[:, 3])}", flush=True)
+lab = ["ln1", "qkv", "q-edge", "attn", "merge", "o-edge", "oproj", "h2-edge", "ln2", "ffn1", "act-edge", "ffn2", "h-edge"]
+for w in range(3):
+    t = ts[w]
+    if t[0, 0] == 0:
+        continue
+    dur = np.diff(t[:, :14], axis=1)                      # [L,13]
+    mean = dur[1:-1].mean(axis=0) if L > 2 else dur.mean(axis=0)
+    print(f"[probe] wg {['0', '1', 'G-1'][w]}: step {(t[-1, 13] - t[0, 0]):.1f} us; per layer (mean of the inner layers) "
+          + " ".join(f"{n} {v:.2f}" for n, v in zip(lab, mean)) + f" | layer {mean.sum():.2f} us", flush=True)

@@ -239,6 +239,8 @@ struct GemmArgs {
   float* part_out;          // PART: [ksplit][rows_cap][N]
   void* x_out;              // ln_rows_k: normalised rows, WT [rows][d]
   long long* dbg_ts;        // shader-clock stamps (diagnostic builds with -DVC_KERNEL_TS only)
+  unsigned* progress;       // optional (decode steps): the launch stores progress_val here when it starts - the pace the weight
+  unsigned progress_val;    // prefetcher follows (vc_stream.hip); progress_val = index of this launch's matrix in the step, + 1
 };
 
 struct AttnArgs {

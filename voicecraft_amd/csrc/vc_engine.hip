@@ -102,8 +102,17 @@ struct vc_engine {
   StreamLayerDev* sLayers = nullptr;    // device table
   unsigned long long* sGran = nullptr;  // granule arena
   unsigned* sCtl = nullptr;             // [0] epoch, [1] error
+  long long* sTs = nullptr;             // VC_STREAM_DBG=1: [3][L][16] phase stamps
   float* sDbg = nullptr;                // VC_STREAM_DBG=1: [L][5][4d] inputs of every op as the kernel saw them
   bool heads_finished_h = false;        // run_heads16: hB holds the finished residual (no slabs, no pending bias)
+  // weight prefetcher of the launch path (weight_prefetch_k): one persistent side-stream launch per call (VC_PREFETCH=<matrices ahead>, default off)
+  int pf_ahead = 0;                     // 0 = off; else matrices it may run ahead of the decode launches
+  hipStream_t pf_stream = nullptr;
+  hipEvent_t pf_ev = nullptr;
+  PrefetchSeg* pf_segs = nullptr;
+  unsigned* pf_prog = nullptr;
+  bool pf_running = false;
+  int pf_G = 0;
   // training objective (vc_eval_forward), allocated on first use
   int *ce_tgt = nullptr, *ce_hit = nullptr;
   float *ce_nll = nullptr;
@@ -255,6 +264,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
+  g.progress = (rs.n_active != nullptr && e->pf_ahead > 0 && rs.n_rows <= VC_ROWS) ? e->pf_prog : nullptr;   // decode steps pace the prefetcher
   return g;
 }
 
@@ -287,6 +297,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.has_prev_bias = (l == 0) ? 0 : 1;
       g.wg = ly.wg_qkv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      g.progress_val = 4 * l + 1;
       if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
@@ -313,6 +324,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wo;
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
+      g.progress_val = 4 * l + 2;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
@@ -322,6 +334,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.wg = ly.wg_1;
       g.out = e->act; g.out_ld = 4 * d;
+      g.progress_val = 4 * l + 3;
       if (split_ln) {
         g.x_out = e->xn;
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
@@ -336,6 +349,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.W2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.part_out = e->parts;
+      g.progress_val = 4 * l + 4;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     }
   }
@@ -355,6 +369,7 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
     g.parts = e->parts + (size_t)in_row0 * e->d; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     if (e->heads_finished_h) { g.n_parts = 0; g.has_prev_bias = 0; }      // the stream engine left the finished residual in hB
     g.wg = e->wg_h1; g.gather_rows = gather;
+    g.progress_val = 4 * e->L + 1;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
     if (!gather && n >= e->ln_split_rows) {
       g.x_out = e->xn;
@@ -371,6 +386,7 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
     g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
     g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits + (size_t)out_row0 * e->K * e->V;
+    g.progress_val = 4 * e->L + 2;
     HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
   }
   return VC_OK;
@@ -554,6 +570,7 @@ StreamArgs stream_args(vc_engine* e) {
   a.gran_layer_stride = sg_gran_per_layer(a);
   a.scale = 1.0f / sqrtf((float)e->hd);
   a.dbg = e->sDbg;
+  a.ts = e->sTs;
   return a;
 }
 
@@ -600,6 +617,28 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   return VC_OK;
 }
 
+// The weight prefetcher runs beside the decode loop of ONE call (vc_stream.hip, weight_prefetch_k).
+int prefetch_start(vc_engine* e, int n_rows, hipStream_t s) {
+  if (e->pf_ahead <= 0 || n_rows > VC_ROWS || e->pf_running) return VC_OK;
+  e->h_flag[12] = 0;                                            // stop word (pinned)
+  HIPCHK(e, hipMemsetAsync(e->pf_prog, 0, sizeof(unsigned), s));
+  HIPCHK(e, hipEventRecord(e->pf_ev, s));
+  HIPCHK(e, hipStreamWaitEvent(e->pf_stream, e->pf_ev, 0));
+  PrefetchArgs a;
+  memset(&a, 0, sizeof a);
+  a.segs = e->pf_segs; a.n_seg = 4 * e->L + 2; a.prog = e->pf_prog; a.n_active = e->n_active; a.stop = e->h_flag + 12;
+  a.ahead = e->pf_ahead; a.G = e->pf_G;
+  HIPCHK(e, vc_prefetch_launch(a, e->pf_stream));
+  e->pf_running = true;
+  return VC_OK;
+}
+void prefetch_stop(vc_engine* e) {
+  if (!e->pf_running) return;
+  __atomic_store_n(e->h_flag + 12, 1, __ATOMIC_RELEASE);
+  (void)hipStreamSynchronize(e->pf_stream);
+  e->pf_running = false;
+}
+
 // The decode loop: every step is the same launch sequence (all step-dependent values live in HBM, the
 // per-call sampler values behind a pointer), so `steps_per_graph` steps are captured ONCE per (sequences,
 // rows per sequence, best-of-N) into a hipGraphExec that is kept for the life of the engine and replayed.
@@ -637,6 +676,7 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   const double t1 = now_ms();
   volatile int* live = e->h_flag + 8;
   int launched = 0, rc = VC_OK, batch = 0;
+  if (!(e->stream_on && B == 1 && rps == 1 && !grouped)) rc = prefetch_start(e, B * rps, s);
   while (launched < max_steps && rc == VC_OK) {
     if (batch >= 2) {   // pace: at most two batches in flight; the older one must have ended before a third is queued
       hipError_t we = hipEventSynchronize(e->ev_pace[batch & 1]);
@@ -654,6 +694,10 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
     hipError_t re = hipEventRecord(e->ev_pace[batch & 1], s);
     if (re != hipSuccess) { rc = fail(e, VC_EHIP, "hipEventRecord: %s", hipGetErrorString(re)); break; }
     ++batch;
+  }
+  if (e->pf_running) {              // the prefetcher ends by itself when the last sequence retires; a call that ends
+    (void)hipStreamSynchronize(s);  // otherwise (step budget, error) stops it - after the steps it serves
+    prefetch_stop(e);
   }
   e->host_ms[3] = now_ms() - t1;
   e->host_ms[4] = 0;
@@ -743,7 +787,10 @@ extern "C" int vc_create(const vc_model_cfg* c, int hip_device, vc_engine** out)
 extern "C" void vc_destroy(vc_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
+  prefetch_stop(e);
   (void)hipDeviceSynchronize();
+  if (e->pf_stream) (void)hipStreamDestroy(e->pf_stream);
+  if (e->pf_ev) (void)hipEventDestroy(e->pf_ev);
   for (auto& kv : e->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->h_st) (void)hipHostFree(e->h_st);
@@ -928,6 +975,40 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if (getenv("VC_STREAM_DBG")) {
       if ((rc = dalloc(e, &e->sDbg, (size_t)L * 5 * 4 * d))) return rc;
       HIPCHK(e, hipMemset(e->sDbg, 0, (size_t)L * 5 * 4 * d * 4));
+      if ((rc = dalloc(e, &e->sTs, (size_t)3 * L * 16 + (size_t)e->sG * 4))) return rc;
+      HIPCHK(e, hipMemset(e->sTs, 0, ((size_t)3 * L * 16 + (size_t)e->sG * 4) * 8));
+    }
+  }
+  // ---- weight prefetcher of the launch path: the matrices of a decode step in launch order
+  {
+    const char* pv = getenv("VC_PREFETCH");
+    // off by default: measured a LOSS (B = 1 step 0.59 -> 0.69 ms at 4 matrices ahead, profiles/r03_prefetch_sweep.log).  A launch
+    // whose matrix was streamed just before by another kernel runs 7.7 us against 9.1 cold and 5.1 "hot" (tools/pf_probe.py): what
+    // makes the hot launch fast is the XCD's own L2 (it re-reads what its CUs read last time), which one matrix already fills;
+    // the Infinity Cache alone is worth ~1.4 us, less than the bandwidth the prefetcher takes from the running launch.
+    e->pf_ahead = pv ? atoi(pv) : 0;                  // matrices ahead (4 = one layer, ~100 MB of the 256 MB Infinity Cache); 0 = off
+    hipDeviceProp_t prop;
+    HIPCHK(e, hipGetDeviceProperties(&prop, e->device));
+    e->pf_G = prop.multiProcessorCount;
+    if (e->pf_ahead > 0) {
+      const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
+      auto image = [&](int N, int Kd, int th) { return (size_t)((N + th - 1) / th) * (Kd / KW) * 4 * th * 16; };
+      std::vector<PrefetchSeg> segs;
+      for (int l = 0; l < L; ++l) {
+        const Layer& ly = e->layers[l];
+        segs.push_back({(const char*)ly.Wqkv, image(3 * d, d, VC_TH_QKV)});
+        segs.push_back({(const char*)ly.Wo, image(d, d, 16)});
+        segs.push_back({(const char*)ly.W1, image(4 * d, d, 16)});
+        segs.push_back({(const char*)ly.W2, image(d, 4 * d, 16)});
+      }
+      segs.push_back({(const char*)e->Wh1, image(K * P, d, 16)});
+      segs.push_back({(const char*)e->Wh2, (size_t)e->wh2_group_stride * 16 * K});
+      if ((rc = dalloc(e, &e->pf_segs, segs.size()))) return rc;
+      HIPCHK(e, hipMemcpy(e->pf_segs, segs.data(), segs.size() * sizeof(PrefetchSeg), hipMemcpyHostToDevice));
+      if ((rc = dalloc(e, &e->pf_prog, (size_t)4))) return rc;
+      HIPCHK(e, hipMemset(e->pf_prog, 0, 16));
+      HIPCHK(e, hipStreamCreateWithFlags(&e->pf_stream, hipStreamNonBlocking));
+      HIPCHK(e, hipEventCreateWithFlags(&e->pf_ev, hipEventDisableTiming));
     }
   }
   // ---- launch plans
@@ -1505,6 +1586,7 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "kernel_ts") { src = e->dbg_ts; avail = 64 * 8; }
   else if (n == "host_ms") { host_src = e->host_ms; avail = 8 * 8; }
   else if (n == "stream_dbg" && e->sDbg) { src = e->sDbg; avail = (int64_t)e->L * 5 * 4 * e->d * 4; }
+  else if (n == "stream_ts" && e->sTs) { src = e->sTs; avail = ((int64_t)3 * e->L * 16 + (int64_t)e->sG * 4) * 8; }
   else if (n == "stream_ctl" && e->sCtl) { src = e->sCtl; avail = 16; }
   else if (n == "launch_counts") { host_src = vc_launch_counts; avail = VC_LC_N * 8; }     // process-wide census of kernel forms (vc_common.h)
   else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
@@ -1564,9 +1646,21 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   bool hot = false;
   std::string w2 = w;
   if (w.size() > 4 && w.substr(w.size() - 4) == "_hot") { hot = true; w2 = w.substr(0, w.size() - 4); }
+  bool with_pf = false, pf_only = false;      // "<kernel>_pf": the layer's matrix is prefetched (weight_prefetch_k, direct form) right before
+  if (w2.size() > 3 && w2.substr(w2.size() - 3) == "_pf") { with_pf = true; w2 = w2.substr(0, w2.size() - 3); }
+  if (w2.size() > 7 && w2.substr(w2.size() - 7) == "_pfonly") { pf_only = true; w2 = w2.substr(0, w2.size() - 7); }
   auto one = [&](int i) -> int {
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
+    if ((with_pf || pf_only) && e->pf_ahead > 0) {
+      const int segi = 4 * (i % e->L) + (w == "qkv" ? 0 : w == "oproj" ? 1 : w == "ffn1" ? 2 : 3);
+      PrefetchArgs pa;
+      memset(&pa, 0, sizeof pa);
+      pa.segs = e->pf_segs; pa.n_seg = 4 * e->L + 2; pa.prog = e->pf_prog; pa.n_active = e->one; pa.stop = e->h_flag + 12;
+      pa.ahead = -(segi + 1); pa.G = e->pf_G;
+      HIPCHK(e, vc_prefetch_launch(pa, s));
+      if (pf_only) return VC_OK;
+    }
     const bool split_ln = n_rows >= e->ln_split_rows;   // the engine then normalises in ln_rows_k and takes the plain prologue
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);

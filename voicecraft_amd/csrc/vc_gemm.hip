@@ -244,6 +244,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;
   constexpr int SPT = 4 * TH;                     // fragment slots per (n_tile, k_tile)
   const int active = *a.n_active;                 // scalar; looked at once the burst is on its way
+  if (a.progress && tid == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)      // "matrix progress_val - 1 of the step is being read": the
+    __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // weight prefetcher's pace (a store, not a read-modify-write: the word is polled)
   const int m = lane & 15;
   const int kg = lane >> 4;
   const int n = nt * TH + 4 * kg;

@@ -26,6 +26,7 @@ struct StreamArgs {
   int rpc;                             // 1 KB rows per K = d channel (d / 512)
   int sq, so, s1, s2, spl;             // slots per op and per layer
   float scale;
+  long long* ts;                       // optional [3][L][16] phase stamps (100 MHz) of workgroups 0, 1 and G-1 (tools/stream_probe.py)
   float* dbg;                          // optional [L][5][4d] dump of the op outputs as the kernel saw its INPUTS (parity bisect)
 };
 // granule offsets inside a layer's arena (in granules)
@@ -43,3 +44,16 @@ hipError_t vc_stream_pack_layer(const float* Wqkv, const float* Wo, const float*
                                 const float* g2, void* dst, int d, int G, hipStream_t s);
 size_t vc_stream_layer_bytes(int d, int G);
 hipError_t vc_stream_launch(const StreamArgs& a, hipStream_t s);
+
+// ---- weight prefetcher of the launch path (weight_prefetch_k)
+struct PrefetchSeg { const char* ptr; size_t bytes; };   // one weight matrix (packed image), in launch order
+struct PrefetchArgs {
+  const PrefetchSeg* segs;   // device array [n_seg]: the 4 L + 2 matrices of a decode step
+  int n_seg;
+  unsigned* prog;            // index + 1 of the matrix the running launch reads (stored by the GEMM kernels; 0 before the first)
+  const int* n_active;       // 0 once the last sequence retired
+  const int* stop;           // pinned host word: raised by the host when the call ends early
+  int ahead;                 // matrices the prefetcher may run ahead of the launches
+  int G;                     // workgroups (one per CU)
+};
+hipError_t vc_prefetch_launch(const PrefetchArgs& a, hipStream_t s);
