@@ -374,6 +374,7 @@ def main():
                     "frac": round(fl_ / (ms_ * 1e-3) / 1e12 / pk, 4), "traffic": None, "flops_per_launch": fl_, "avg_launch_us": round(ms_ * 1e3, 2)}
         mfma = mfma_obj("pf_ffn1", 512, "rows_gemm_blk_k<ReLU> (prefill FFN up-projection, 512 rows)")
         mfma["at_run_rows"] = mfma_obj("pf_ffn1", own_rows, f"rows_gemm_blk_k<ReLU> (prefill FFN up-projection, this run's {own_rows}-row pass)")
+        mfma["at_2048_rows"] = mfma_obj("pf_ffn1", 2048, "rows_gemm_big_k<ReLU> (prefill FFN up-projection, a 2048-row stream: 256 x 256 tiles, LDS-DMA)")
         mfma["attention"] = mfma_obj("pf_attn", 512, "tile_attn_k (prefill attention, 512 causal rows of one sequence, all heads)")
         dec_step_ms = dec_ms / max(1, steps_launched or steps_run)     # the timed region covers every LAUNCHED step (graph-rounded)
         out = {

@@ -11,7 +11,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define VC_ROWS 16          // rows (token positions) of one MFMA tile = the N dimension of the rows-GEMM
 #define VC_MAX_SEQS 64      // sequences one engine decodes together (passes of more than VC_ROWS rows run on the block GEMM)
-#define VC_MAX_ROWS 512     // rows one forward pass may carry (prefill: four 128-row tiles of the block GEMM)
+#define VC_MAX_ROWS 2048    // rows one forward pass may carry (prefill: eight 256-row tiles of the long-stream GEMM)
 #define VC_SLAB_ROWS (VC_MAX_ROWS + 5)   // row stride of the split-K slabs: not a power of two, so the slabs of a row do not share a cache channel
 #define VC_MAX_NSPLIT 8     // split-S factor cap of the decode attention (the out-projection prologue loads this many partials)
 #define VC_MAX_KSPLIT 4     // cross-block split-K cap of the rows-GEMM (the LN prologue prefetches this many slabs)
@@ -360,7 +360,7 @@ extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill blo
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one
 // they compared with the oracle.
 enum { VC_LC_ROWS_GEMM = 0, VC_LC_MT2 = 1, VC_LC_MT4 = 2, VC_LC_BLK64 = 3, VC_LC_BLK128_SBS = 4, VC_LC_BLK128_2X2 = 5,
-       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_PERSIST = 10, VC_LC_N = 16 };
+       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_PERSIST = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_N = 16 };
 extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);

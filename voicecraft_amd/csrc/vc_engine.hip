@@ -1613,7 +1613,8 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   if (!which || n_rows < 1 || iters < 1 || !avg_ms) return fail(e, VC_EINVAL, "bad argument to vc_bench_kernel");
   const bool pf = std::string(which).rfind("pf_", 0) == 0;      // prefill block GEMM: up to VC_MAX_ROWS rows
   if (n_rows > (pf ? VC_MAX_ROWS : VC_ROWS)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed %d", n_rows, pf ? VC_MAX_ROWS : VC_ROWS);
-  if (pf && (n_rows > e->emb_cap || n_rows > e->S_max)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed the prefill arena / cache", n_rows);
+  if (pf && (n_rows > e->emb_cap || (std::string(which) == "pf_attn" && n_rows > e->S_max)))
+    return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed the prefill arena / cache", n_rows);
   hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
   const std::string w = which;
   const int d = e->d;

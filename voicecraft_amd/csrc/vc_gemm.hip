@@ -917,6 +917,150 @@ __global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
   }
 }
 
+// ------------------------------------------------------------------ prefill, long row streams: 256 x 256 tiles, everything through LDS-DMA
+// The 128 x 128 block GEMM above is bound by what its workgroups pull out of L2: every weight byte is fetched once per
+// 128 rows and every X byte once per 128 channels - 268 MB per 512-row FFN-up launch, ~11 TB/s, 0.25 of the bf16 MFMA peak
+// whatever the schedule (profiles/r02_blk_probe.log).  A pass of >= 768 rows (several prompts of a batch as one row
+// stream, a long editing prompt) can afford a 256 x 256 tile on every CU, which halves the bytes per FLOP:
+//   workgroup  8 waves side by side: wave w owns ALL 16 row tiles of the 256-row block and weight tiles 2w, 2w+1 of its
+//              16 (256 channels; 192 for the 12-channel QKV tiles) - 32 accumulators of 16 x 16, two waves per SIMD
+//   staging    BOTH operands by LDS-DMA (global_load_lds_dwordx4), one 1 KB MFMA fragment per instruction: the weights
+//              already ARE fragments in HBM; an X fragment is 16 rows x 64 B, its lane order IS the B operand's, so the
+//              LDS image is fragment-linear and every ds_read_b128 is conflict-free.  Nothing passes through registers on
+//              the way in (the compiler would drain the DMA queue before every use of an ordinary load next to it).
+//   pipeline   4 stages of one k-tile (16 X + 16 W fragments = 32 KB), three in flight: per k-tile a wave issues its 4
+//              DMA instructions, waits with a COUNTED vmcnt for the stage issued three steps ago, meets the workgroup at
+//              one raw s_barrier and feeds 32 MFMAs from 18 fragment reads
+// Epilogues are the decode ones (gemm_epilogue).  bf16 only (the exact fp32 mode keeps the 128 x 128 kernel).
+#define VC_BIG_M 256
+#define VC_BIG_STAGES 4
+#define VC_BIG_STAGE_BYTES 32768
+template <int EPI, int NTW>      // NTW weight tiles per wave: 2 = 256-channel tile (the only form dispatched, see launch_blk)
+__global__ __launch_bounds__(512) void rows_gemm_big_k(const GemmArgs a) {
+  using WT = bf16_t;
+  constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;
+  constexpr int SPT = 4 * TH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (*a.n_active == 0) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kg = lane >> 4;
+  const int row_blk = blockIdx.y * VC_BIG_M;
+  const int nt_blk = blockIdx.x * 8 * NTW;
+  const int ks = blockIdx.z;
+  const int kt_blk = a.KT / (int)gridDim.z, kt0 = ks * kt_blk;
+  const bool wvalid = m < TH;
+  // DMA sources of this wave: X row tiles 2 wv, 2 wv + 1 and its own NTW weight tiles of every stage
+  const long rstride = (long)a.x_ld * 2;
+  const char* xsrc[2];
+  const uint4* wsrc[NTW];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int row = row_blk + (2 * wv + j) * 16 + m;            // (rows past n_rows exist in the VC_MAX_ROWS-row buffer; dropped by the epilogue)
+    xsrc[j] = reinterpret_cast<const char*>(a.x_in) + (long)row * rstride + ((long)kt0 * 32 + 8 * kg) * 2;
+  }
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) wsrc[j] = a.Wp + ((long)(nt_blk + NTW * wv + j) * a.KT + kt0) * SPT + (kg * TH + min(m, TH - 1));
+  auto issue = [&](int kt) {
+    char* st = smem + (size_t)(kt & (VC_BIG_STAGES - 1)) * VC_BIG_STAGE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xsrc[j] + (long)kt * 64),
+                                       (__attribute__((address_space(3))) void*)(st + (2 * wv + j) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NTW; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wsrc[j] + (long)kt * SPT),
+                                       (__attribute__((address_space(3))) void*)(st + 16384 + (NTW * wv + j) * 1024), 16, 0, 0);
+  };
+  f32x4 acc[16][NTW];
+#pragma unroll
+  for (int i = 0; i < 16; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const int nck = kt_blk;
+  const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
+  issue(0);
+  if (nck > 1) issue(1);
+  if (nck > 2) issue(2);
+  for (int kt = 0; kt < nck; ++kt) {
+    // the stage of this step was issued three steps ago: 2 + NTW DMA instructions per step, so it has landed once no more
+    // than two steps' worth (one, none at the tail) are outstanding - a wave's requests land in order
+    const int ahead = nck - 1 - kt;
+    if (ahead >= 2) { if (NTW == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+    else if (ahead == 1) { if (NTW == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); }
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();                       // every wave's share of the stage is in; the stage read last step is free
+    asm volatile("" ::: "memory");
+    if (kt + 3 < nck) issue(kt + 3);
+    // Fragment reads in inline asm: next to an LDS-DMA in flight the compiler drains the whole DMA queue (vmcnt(0)) before
+    // any LDS read it cannot prove disjoint from the DMA's destination - here the read stage and the three stages in flight
+    // are disjoint by construction (kt & 3).  Reads of the second half of the row tiles fly during the first half's MFMAs.
+    const unsigned sa = (unsigned)((kt & (VC_BIG_STAGES - 1)) * VC_BIG_STAGE_BYTES + lane * 16) + lds_base;
+    const unsigned wa = sa + 16384u + (unsigned)(NTW * wv) * 1024u;
+    u32x4 wf0, wf1, xa0, xa1, xa2, xa3, xa4, xa5, xa6, xa7, xb0, xb1, xb2, xb3, xb4, xb5, xb6, xb7;   // (vector types: asm operands)
+    asm volatile("ds_read_b128 %0, %10\n\tds_read_b128 %1, %10 offset:1024\n\t"      /* (NTW == 1: the second tile's slot is read and ignored) */
+                 "ds_read_b128 %2, %11\n\tds_read_b128 %3, %11 offset:1024\n\tds_read_b128 %4, %11 offset:2048\n\t"
+                 "ds_read_b128 %5, %11 offset:3072\n\tds_read_b128 %6, %11 offset:4096\n\tds_read_b128 %7, %11 offset:5120\n\t"
+                 "ds_read_b128 %8, %11 offset:6144\n\tds_read_b128 %9, %11 offset:7168\n\t"
+                 : "=&v"(wf0), "=&v"(wf1), "=&v"(xa0), "=&v"(xa1), "=&v"(xa2), "=&v"(xa3), "=&v"(xa4), "=&v"(xa5), "=&v"(xa6), "=&v"(xa7)
+                 : "v"(wa), "v"(sa) : "memory");
+    asm volatile("ds_read_b128 %0, %8 offset:8192\n\tds_read_b128 %1, %8 offset:9216\n\tds_read_b128 %2, %8 offset:10240\n\t"
+                 "ds_read_b128 %3, %8 offset:11264\n\tds_read_b128 %4, %8 offset:12288\n\tds_read_b128 %5, %8 offset:13312\n\t"
+                 "ds_read_b128 %6, %8 offset:14336\n\tds_read_b128 %7, %8 offset:15360\n\t"
+                 : "=&v"(xb0), "=&v"(xb1), "=&v"(xb2), "=&v"(xb3), "=&v"(xb4), "=&v"(xb5), "=&v"(xb6), "=&v"(xb7)
+                 : "v"(sa) : "memory");
+    // the first ten reads have returned once at most eight are outstanding (LDS returns in order)
+    asm volatile("s_waitcnt lgkmcnt(8)" : "+v"(wf0), "+v"(wf1), "+v"(xa0), "+v"(xa1), "+v"(xa2), "+v"(xa3), "+v"(xa4), "+v"(xa5), "+v"(xa6), "+v"(xa7) :: "memory");
+    if (TH < 16 && !wvalid) { wf0 = u32x4{0u, 0u, 0u, 0u}; wf1 = u32x4{0u, 0u, 0u, 0u}; }
+#define VC_BIG_MM(i_, x_)                                                                        \
+    acc[i_][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf0), __builtin_bit_cast(bf16x8, x_), acc[i_][0], 0, 0, 0); \
+    if constexpr (NTW == 2) acc[i_][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, wf1), __builtin_bit_cast(bf16x8, x_), acc[i_][1], 0, 0, 0);
+    VC_BIG_MM(0, xa0) VC_BIG_MM(1, xa1) VC_BIG_MM(2, xa2) VC_BIG_MM(3, xa3)
+    VC_BIG_MM(4, xa4) VC_BIG_MM(5, xa5) VC_BIG_MM(6, xa6) VC_BIG_MM(7, xa7)
+    __builtin_amdgcn_sched_barrier(0);                  // the first half's MFMAs stay ahead of the wait for the second half's reads
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(xb0), "+v"(xb1), "+v"(xb2), "+v"(xb3), "+v"(xb4), "+v"(xb5), "+v"(xb6), "+v"(xb7) :: "memory");
+    VC_BIG_MM(8, xb0) VC_BIG_MM(9, xb1) VC_BIG_MM(10, xb2) VC_BIG_MM(11, xb3)
+    VC_BIG_MM(12, xb4) VC_BIG_MM(13, xb5) VC_BIG_MM(14, xb6) VC_BIG_MM(15, xb7)
+#undef VC_BIG_MM
+    asm volatile("" ::: "memory");
+  }
+  // ---- epilogue: lane holds channels n..n+3 of row (row tile i, m) for weight tile j
+  const bool nvalid = 4 * kg < TH;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int mg = row_blk + i * 16 + m;
+    if (mg >= a.n_rows) continue;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      const int nt = nt_blk + NTW * wv + j;
+      if (nt >= a.n_tiles || !nvalid) continue;
+      const int n = nt * TH + 4 * kg;
+      float4 eb;
+      int epos, eseq;
+      epi_preload<WT, EPI>(a, mg, n, 0, eb, epos, eseq);
+      gemm_epilogue<WT, EPI>(a, acc[i][j], mg, n, ks, 0, 1, eb, epos, eseq);
+    }
+  }
+}
+
+template <int EPI, int NTW>
+static hipError_t launch_big(const GemmArgs& a, int ksplit, hipStream_t s) {
+  auto kern = rows_gemm_big_k<EPI, NTW>;
+  constexpr size_t lds = (size_t)VC_BIG_STAGES * VC_BIG_STAGE_BYTES;
+  static size_t granted[16] = {0};
+  int dev = 0;
+  if (hipError_t ge = hipGetDevice(&dev); ge != hipSuccess) return ge;
+  if (dev >= 0 && dev < 16 && granted[dev] < lds) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    granted[dev] = lds;
+  }
+  dim3 grid(a.n_tiles / (8 * NTW), (a.n_rows + VC_BIG_M - 1) / VC_BIG_M, ksplit);
+  ++vc_launch_counts[NTW == 2 ? VC_LC_BIG256 : VC_LC_BIG128];
+  hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, a);
+  return hipGetLastError();
+}
+
 // h_new = h + prev_bias + sum of split-K slabs ; x_hat = (h_new - mean) * rstd as WT (the affine part of the
 // LayerNorm lives in the folded weights, see the top of this file).  One block per row.
 template <typename WT>
@@ -1062,6 +1206,21 @@ static hipError_t launch_blk_e(const GemmArgs& a, int ksplit, hipStream_t s) {
 template <typename WT>
 static hipError_t launch_blk(const GemmArgs& a, int pro, int epi, int ksplit, hipStream_t s) {
   if (pro != PRO_PLAIN) return hipErrorInvalidValue;       // LayerNorm comes from ln_rows_k, attention normalises itself
+  // long row streams (bf16): 256 x 256 tiles once they give (nearly) every CU a workgroup
+  if constexpr (sizeof(WT) == 2) {
+    static const int big_off = getenv("VC_NO_BIG_GEMM") ? 1 : 0;
+    const long wgs = (long)(a.n_tiles / 16) * ((a.n_rows + VC_BIG_M - 1) / VC_BIG_M) * ksplit;
+    if (!big_off && a.n_rows > 512 && a.n_tiles % 16 == 0) {
+      if (wgs >= 160) {                    // 256 x 256 tiles
+        if (epi == EPI_QKV) return launch_big<EPI_QKV, 2>(a, ksplit, s);
+        if (epi == EPI_PART) return launch_big<EPI_PART, 2>(a, ksplit, s);
+        if (epi == EPI_RELU) return launch_big<EPI_RELU, 2>(a, ksplit, s);
+      }
+      // (256 x 128 tiles - NTW = 1, twice the workgroups - for passes of 513..1279 rows were measured: no gain over the 128 x 128
+      // kernel, e.g. 800 rows 48.0 us either way, profiles/r03_pf_gemm_probe.log: only the weight re-reads shrink, the X re-reads
+      // that make up the other half of the L2 traffic do not.  Not dispatched.)
+    }
+  }
   if (epi == EPI_QKV) return launch_blk_e<WT, EPI_QKV>(a, ksplit, s);
   if (epi == EPI_PART) return launch_blk_e<WT, EPI_PART>(a, ksplit, s);
   if (epi == EPI_RELU) return launch_blk_e<WT, EPI_RELU>(a, ksplit, s);

@@ -441,7 +441,7 @@ class VoiceCraftEngine:
         return ms.value, nbytes.value
 
     LAUNCH_FORMS = ("rows_gemm", "mt2", "mt4", "blk64", "blk128_sbs", "blk128_2x2", "blk64_occ2", "ln_rows", "rows_attn",
-                    "tile_attn", "persist")
+                    "tile_attn", "persist", "big256", "big128")
 
     def launch_counts(self) -> dict:
         """Process-wide census of the kernel FORMS launched so far (vc_common.h VC_LC_*): the parity tests take the
