@@ -1,15 +1,14 @@
 #!/bin/bash
-# First GPU call of the next round (from the repo root on the GPU box; ~3 minutes):
-#   gpurun --timeout 400 -- 'bash tools/next_round.sh > gpurun_out/next_round.log 2>&1; tail -40 gpurun_out/next_round.log'
-# Validates what round 2 wrote after its GPU budget was spent, each step under its own timeout.
+# First GPU call of a round (from the repo root on the GPU box; ~6 minutes):
+#   gpurun --timeout 900 -- 'bash tools/next_round.sh > gpurun_out/next_round.log 2>&1; tail -40 gpurun_out/next_round.log'
+# Re-establishes the state the previous round ended in: full GPU suite, the default bench line, and the two opt-in paths.
 set -u
 export TMPDIR=/tmp
-echo "== f4: vc_eval_forward against the reference fixtures (opt-in tests)"
-VC_TEST_EXPERIMENTAL=1 timeout 150 python -m pytest tests/test_gpu_forward.py -x -q 2>&1 | tail -5
-echo "== persistent LSTM, both forms, against the wavefront path"
-timeout 90 python tools/lstm_probe.py 1 2>&1 | tail -10
-VC_TEST_EXPERIMENTAL=1 timeout 60 python -m pytest tests/test_gpu_codec.py -x -q -k experimental 2>&1 | tail -3
-echo "== attention split count of a single-row decode step (VC_ATTN_BLOCKS1 = blocks per row)"
-for b in 16 32 64 128; do   # = 1, 2, 4, 8 splits at 16 heads (VC_MAX_NSPLIT caps at 8)
-  VC_ATTN_BLOCKS1=$b timeout 60 python tools/variant_sweep.py 1 2>&1 | tail -1 | sed "s/^/blocks1=$b  /"
-done
+echo "== GPU suite"
+timeout 700 python -m pytest tests -m gpu -q 2>&1 | tail -4
+echo "== default bench line"
+timeout 200 python bench.py --steps 5 --warmup 2 2>/dev/null | tail -c 2500
+echo "== stream engine (VC_STREAM=1): parity + phase stamps at giga830M"
+timeout 200 python tools/stream_probe.py giga830M 16 80 150 2>&1 | grep -v "layer [0-9]*: rel" | tail -6
+echo "== prefill GEMM by pass size"
+timeout 200 python tools/pf_gemm_probe.py 2>&1 | grep pf_gemm
