@@ -11,7 +11,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
 
 #define VC_ROWS 16          // rows (token positions) of one MFMA tile = the N dimension of the rows-GEMM
 #define VC_MAX_SEQS 64      // sequences one engine decodes together (passes of more than VC_ROWS rows run on the block GEMM)
+#ifndef VC_MAX_ROWS
 #define VC_MAX_ROWS 2048    // rows one forward pass may carry (prefill: eight 256-row tiles of the long-stream GEMM)
+#endif
 #define VC_SLAB_ROWS (VC_MAX_ROWS + 5)   // row stride of the split-K slabs: not a power of two, so the slabs of a row do not share a cache channel
 #define VC_MAX_NSPLIT 8     // split-S factor cap of the decode attention (the out-projection prologue loads this many partials)
 #define VC_MAX_KSPLIT 4     // cross-block split-K cap of the rows-GEMM (the LN prologue prefetches this many slabs)
