@@ -386,6 +386,273 @@ __global__ __launch_bounds__(256) void tile_attn_k(const AttnArgs a) {
   }
 }
 
+// Round 3: the same product with the key loop software-pipelined.  tile_attn_k above leaves every key tile's K/V requests
+// un-overlapped (a 512-row pass = 4 dependent L2 round trips per wave = 26 us for 1 GFLOP); here
+//   * the NEXT key tile's K fragments and V items are requested as soon as the current tile's have been consumed (after
+//     Q K^T and the V^T copy), so they fly under the softmax and P V - in the SAME registers: a second register set
+//     costs 300 VGPRs = one wave per SIMD, measured worse than the latency it hides,
+//   * workgroups are numbered head-first (blockIdx.x = head): the hardware deals consecutive workgroups round-robin
+//     over the 8 XCDs, so a head's K/V prefix (re-read by every row tile of that head) stays in ONE XCD's L2 instead of
+//     being fetched into all eight; the longest row tiles are dealt first,
+//   * the softmax runs in base 2 (Q pre-scaled by log2 e, v_exp_f32 directly).
+// NW waves split the key tiles of one (16-row tile, head).
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+template <typename WT, int HD, int NW, int OCC = 1>
+__global__ __launch_bounds__(64 * NW, OCC) void tile_attn2_k(const AttnArgs a) {
+  using T = WTr<WT>;
+  constexpr int EPL = T::EPL, KW = T::KW;
+  constexpr int NSUB = KW / 16, NKS = HD / KW, NDT = HD / 16;
+  constexpr int SZ = (int)sizeof(WT);
+  constexpr int VS = KW * SZ + 16;
+  constexpr bool TR = SZ == 2;                       // bf16: V stays row-major in LDS and is read through ds_read_b64_tr_b16
+  constexpr int SUBT = KW * 32 + 32;                 // bytes of one [KW keys][16 dims] sub-tile (+32: the 16 stores of a key hit 64 banks)
+  constexpr int VBYTES = TR ? NDT * SUBT : HD * VS;
+  constexpr int WAVE_LDS = VBYTES + 16 * VS;
+  constexpr int NPK = 4 / SZ;
+  constexpr int VITEMS = (KW / NPK) * (HD / EPL) / 64;
+  struct KV { uint4 kf[NSUB][NKS]; uint4 vu[VITEMS][NPK]; };
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kg = lane >> 4;
+  const int h = blockIdx.x, r0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 16;
+  const int share = *a.share_len;
+  const int rp = (r0 + m < a.n_rows) ? a.row_pos[r0 + m] : -1;
+  const int pos0 = __builtin_amdgcn_readfirstlane(rp);
+  const int seq = a.row_seq[r0];
+  const int na = __popcll(__ballot(rp >= 0 && lane < 16));
+  char* vt = smem + wave * WAVE_LDS;
+  char* pt = vt + VBYTES;
+  float mrun[4], lrun[4];
+  f32x4 o[NDT];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (na > 0 && pos0 >= 0) {
+    const int last = pos0 + na - 1;
+    const long hbase = (long)h * a.S_max * HD;
+    const WT* kc = reinterpret_cast<const WT*>(a.kcache) + hbase;
+    const WT* vc = reinterpret_cast<const WT*>(a.vcache) + hbase;
+    const long own = (long)seq * a.cache_seq_stride;
+    constexpr int DG = HD / EPL;                           // 16-byte groups per cached row
+    const unsigned koff = (unsigned)(m * HD + EPL * kg);   // this lane's K fragment inside a key tile (elements)
+    const unsigned voff = (unsigned)((lane / DG) * NPK * HD + (lane % DG) * EPL);
+    auto issue = [&](KV& t, int kt0) __attribute__((always_inline)) {
+      // Common case: the tile lies inside the prefix and on one side of the shared-prefix boundary - ONE wave-uniform
+      // base, every request a constant offset from it (scalar base + 32-bit lane offset + immediate).
+      if (kt0 + KW - 1 <= last && (kt0 >= share || kt0 + KW <= share)) {
+        const WT* kb = kc + ((kt0 < share) ? 0 : own) + (long)kt0 * HD;
+        const WT* vb = vc + ((kt0 < share) ? 0 : own) + (long)kt0 * HD;
+#pragma unroll
+        for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+          for (int ks = 0; ks < NKS; ++ks)
+            t.kf[sub][ks] = *reinterpret_cast<const uint4*>(kb + (koff + (unsigned)(sub * 16 * HD + KW * ks)));
+#pragma unroll
+        for (int it = 0; it < VITEMS; ++it)
+#pragma unroll
+          for (int q = 0; q < NPK; ++q)
+            t.vu[it][q] = *reinterpret_cast<const uint4*>(vb + (voff + (unsigned)((it * (64 / DG) * NPK + q) * HD)));
+        return;
+      }
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        const int kp = min(kt0 + sub * 16 + m, last);
+        const WT* kr = kc + ((kp < share) ? 0 : own) + (long)kp * HD + EPL * kg;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) t.kf[sub][ks] = *reinterpret_cast<const uint4*>(kr + KW * ks);
+      }
+#pragma unroll
+      for (int it = 0; it < VITEMS; ++it) {
+        const int item = it * 64 + lane;
+        const int kgrp = item / DG, dgrp = item - kgrp * DG;
+#pragma unroll
+        for (int q = 0; q < NPK; ++q) {
+          const int kp = min(kt0 + kgrp * NPK + q, last);
+          t.vu[it][q] = *reinterpret_cast<const uint4*>(vc + ((kp < share) ? 0 : own) + (long)kp * HD + dgrp * EPL);
+        }
+      }
+    };
+    const int kt_first = wave * KW;
+    KV A;
+    if (kt_first <= last) issue(A, kt_first);              // in flight while Q is fetched and converted
+    uint4 qf[NKS];
+    {
+      const float qs = a.scale * 1.4426950408889634f;      // scores in log2 units
+      const float* qp = a.q + (long)min(r0 + m, a.n_rows - 1) * a.d + h * HD + EPL * kg;
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        WT tmp[EPL];
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) T::st(&tmp[j], qp[KW * ks + j] * qs);
+        qf[ks] = *reinterpret_cast<const uint4*>(tmp);
+      }
+    }
+    f32x4 sc[NSUB];
+    auto scores_and_vt = [&](const KV& t) __attribute__((always_inline)) {
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub) {
+        sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) sc[sub] = mfma_frag(qf[ks], t.kf[sub][ks], sc[sub], (WT*)nullptr);
+      }
+      if constexpr (TR) {
+        // V tile as NDT sub-tiles [key][16 dims] (32-byte rows): one 16-byte store per item; the transposition happens
+        // in the read (ds_read_b64_tr_b16: lane i of a 16-lane group supplies the 8-byte chunk C_i, lane n receives
+        // element n&3 of chunks 4j + (n>>2), j = 0..3 - measured, tools/tr_probe.hip)
+        char* dst = vt + ((lane % DG) >> 1) * SUBT + ((lane % DG) & 1) * 16 + (lane / DG) * NPK * 32;
+#pragma unroll
+        for (int it = 0; it < VITEMS; ++it)
+#pragma unroll
+          for (int q = 0; q < NPK; ++q)
+            *reinterpret_cast<uint4*>(dst + (it * (64 / DG) * NPK + q) * 32) = t.vu[it][q];
+      } else {
+#pragma unroll
+        for (int it = 0; it < VITEMS; ++it) {
+          const int item = it * 64 + lane;
+          const int kgrp = item / DG, dgrp = item - kgrp * DG;
+          char* dst = vt + (dgrp * EPL) * VS + kgrp * 4;
+          const uint32_t a0[4] = {t.vu[it][0].x, t.vu[it][0].y, t.vu[it][0].z, t.vu[it][0].w};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t*>(dst + j * VS) = a0[j];
+        }
+      }
+    };
+    auto softmax_and_pv = [&](int kt0) __attribute__((always_inline)) {
+      float p[NSUB][4], corr[4];
+      if (kt0 + KW - 1 <= pos0) {
+        // interior tile: every key is visible to every row (padding rows ride along; their output is zeroed at the store)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float mx = sc[0][r];
+#pragma unroll
+          for (int sub = 1; sub < NSUB; ++sub) mx = fmaxf(mx, sc[sub][r]);
+          mx = fmaxf(mx, dpp_f<VC_DPP_QP_1032>(mx));
+          mx = fmaxf(mx, dpp_f<VC_DPP_QP_2301>(mx));
+          mx = fmaxf(mx, dpp_f<VC_DPP_ROW_HALF_MIRROR>(mx));
+          mx = fmaxf(mx, dpp_f<VC_DPP_ROW_MIRROR>(mx));
+          const float mn = fmaxf(mrun[r], mx);
+          corr[r] = fast_exp2(mrun[r] - mn);               // first tile: exp2(-inf) = 0
+          float ps = 0.f;
+#pragma unroll
+          for (int sub = 0; sub < NSUB; ++sub) { p[sub][r] = fast_exp2(sc[sub][r] - mn); ps += p[sub][r]; }
+          lrun[r] = lrun[r] * corr[r] + row_sum(ps);
+          mrun[r] = mn;
+        }
+      } else {
+        // edge tile: the causal mask cuts through it
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qrow = 4 * kg + r;
+          const int qpos = (qrow < na) ? pos0 + qrow : -1;
+          float mx = -INFINITY;
+#pragma unroll
+          for (int sub = 0; sub < NSUB; ++sub) {
+            const int kp = kt0 + sub * 16 + m;
+            p[sub][r] = (kp <= qpos) ? sc[sub][r] : -INFINITY;
+            mx = fmaxf(mx, p[sub][r]);
+          }
+          mx = fmaxf(mx, dpp_f<VC_DPP_QP_1032>(mx));
+          mx = fmaxf(mx, dpp_f<VC_DPP_QP_2301>(mx));
+          mx = fmaxf(mx, dpp_f<VC_DPP_ROW_HALF_MIRROR>(mx));
+          mx = fmaxf(mx, dpp_f<VC_DPP_ROW_MIRROR>(mx));
+          const float mn = fmaxf(mrun[r], mx);
+          const float msafe = (mn == -INFINITY) ? 0.f : mn;  // nothing visible yet: exp2(-inf - 0) = 0 everywhere
+          corr[r] = (mrun[r] == mn) ? 1.f : fast_exp2(mrun[r] - msafe);
+          float ps = 0.f;
+#pragma unroll
+          for (int sub = 0; sub < NSUB; ++sub) { p[sub][r] = fast_exp2(p[sub][r] - msafe); ps += p[sub][r]; }
+          lrun[r] = lrun[r] * corr[r] + row_sum(ps);
+          mrun[r] = mn;
+        }
+      }
+      // the accumulators are rescaled only when some row's running maximum moved (rare after the first tiles)
+      if (__any(corr[0] != 1.f || corr[1] != 1.f || corr[2] != 1.f || corr[3] != 1.f)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) { o[dt][0] *= corr[0]; o[dt][1] *= corr[1]; o[dt][2] *= corr[2]; o[dt][3] *= corr[3]; }
+      }
+#pragma unroll
+      for (int sub = 0; sub < NSUB; ++sub)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) T::st(reinterpret_cast<WT*>(pt + (4 * kg + r) * VS) + sub * 16 + m, p[sub][r]);
+      const uint4 pf = *reinterpret_cast<const uint4*>(pt + m * VS + kg * 16);
+      if constexpr (TR) {
+        typedef short s16x4 __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+        const char* vrd = vt + (8 * kg + (m >> 2)) * 32 + (m & 3) * 8;       // keys 8 kg .. 8 kg + 3 of dims 4 (m & 3) ..: chunk of lane m
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vrd + dt * SUBT));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vrd + dt * SUBT + 128));   // keys 8 kg + 4 ..
+          uint4 vf;
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          vf.x = l2.x; vf.y = l2.y; vf.z = h2.x; vf.w = h2.y;
+          o[dt] = mfma_frag(pf, vf, o[dt], (WT*)nullptr);
+        }
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const uint4 vf = *reinterpret_cast<const uint4*>(vt + (dt * 16 + m) * VS + kg * 16);
+          o[dt] = mfma_frag(pf, vf, o[dt], (WT*)nullptr);
+        }
+      }
+    };
+    if (kt_first <= last) {
+      for (int kt0 = kt_first;;) {
+        scores_and_vt(A);                                  // the last reads of this tile's K fragments and V items
+        const int nx = kt0 + NW * KW;
+        const bool more = nx <= last;
+        if (more) issue(A, nx);                            // ... so the next tile's requests fly under the softmax and P V
+        softmax_and_pv(kt0);
+        if (!more) break;
+        kt0 = nx;
+      }
+    }
+  }
+  __syncthreads();
+  float* mo = reinterpret_cast<float*>(smem);            // [NW waves][16 rows][HD]
+  float* mm = mo + NW * 16 * HD;                         // [NW][16][2]
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int qrow = 4 * kg + r;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) mo[(wave * 16 + qrow) * HD + dt * 16 + m] = o[dt][r];
+    if (m == 0) { mm[(wave * 16 + qrow) * 2] = mrun[r]; mm[(wave * 16 + qrow) * 2 + 1] = lrun[r]; }
+  }
+  __syncthreads();
+  for (int e = tid; e < 16 * HD; e += 64 * NW) {
+    const int qrow = e / HD, dim = e - qrow * HD;
+    if (r0 + qrow >= a.n_rows) continue;
+    float M = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) M = fmaxf(M, mm[(w * 16 + qrow) * 2]);
+    const float Ms = (M == -INFINITY) ? 0.f : M;
+    float L = 0.f, O = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+      const float c = fast_exp2(mm[(w * 16 + qrow) * 2] - Ms);
+      L += c * mm[(w * 16 + qrow) * 2 + 1];
+      O += c * mo[(w * 16 + qrow) * HD + dim];
+    }
+    T::st(reinterpret_cast<WT*>(a.x_out) + (long)(r0 + qrow) * a.d + h * HD + dim, (qrow < na && L > 0.f) ? O / L : 0.f);
+  }
+}
+
+template <typename WT, int HD, int NW, int OCC = 1>
+static hipError_t launch_tile_attn2(const AttnArgs& a, hipStream_t s) {
+  constexpr int VS = WTr<WT>::KW * (int)sizeof(WT) + 16;
+  constexpr size_t vbytes = sizeof(WT) == 2 ? (size_t)(HD / 16) * (WTr<WT>::KW * 32 + 32) : (size_t)HD * VS;   // as in the kernel
+  constexpr size_t wave_lds = vbytes + (size_t)16 * VS;
+  constexpr size_t merge = (size_t)(NW * 16 * HD + NW * 16 * 2) * sizeof(float);
+  constexpr size_t lds = (NW * wave_lds > merge) ? NW * wave_lds : merge;
+  static bool attr = false;
+  if (!attr) { (void)hipFuncSetAttribute((const void*)tile_attn2_k<WT, HD, NW, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+  hipLaunchKernelGGL((tile_attn2_k<WT, HD, NW, OCC>), dim3(a.H, (a.n_rows + 15) / 16), dim3(64 * NW), lds, s, a);
+  return hipGetLastError();
+}
+
 template <typename WT, int HD>
 static hipError_t launch_tile_attn(const AttnArgs& a, hipStream_t s) {
   constexpr int VS = WTr<WT>::KW * (int)sizeof(WT) + 16;
@@ -399,6 +666,19 @@ static hipError_t launch_tile_attn(const AttnArgs& a, hipStream_t s) {
 hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s) {
   if (!a.x_out) return hipErrorInvalidValue;
   ++vc_launch_counts[VC_LC_TILE_ATTN];
+  static const int form = [] { const char* v = getenv("VC_TILE_ATTN"); return v ? atoi(v) : 2; }();   // 1 = the round-2 kernel, 2 = pipelined (4 waves), 8 = pipelined with 8 waves
+  if (form != 1) {
+    if (dtype == VC_DTYPE_BF16) {
+      if (a.hd == 128) return form == 8 ? launch_tile_attn2<bf16_t, 128, 8>(a, s) : form == 3 ? launch_tile_attn2<bf16_t, 128, 4, 3>(a, s) : launch_tile_attn2<bf16_t, 128, 4>(a, s);
+      if (a.hd == 64) return launch_tile_attn2<bf16_t, 64, 4>(a, s);
+      if (a.hd == 32) return launch_tile_attn2<bf16_t, 32, 4>(a, s);
+    } else {
+      if (a.hd == 128) return launch_tile_attn2<float, 128, 4>(a, s);
+      if (a.hd == 64) return launch_tile_attn2<float, 64, 4>(a, s);
+      if (a.hd == 32) return launch_tile_attn2<float, 32, 4>(a, s);
+    }
+    return hipErrorInvalidValue;
+  }
   if (dtype == VC_DTYPE_BF16) {
     if (a.hd == 128) return launch_tile_attn<bf16_t, 128>(a, s);
     if (a.hd == 64) return launch_tile_attn<bf16_t, 64>(a, s);
