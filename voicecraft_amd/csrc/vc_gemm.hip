@@ -210,6 +210,94 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int 
   }
 }
 
+// Epilogue of the block GEMMs (rows_gemm_blk_k, rows_gemm_big_k): the lane holds channels n .. n+3 (n = nt TH + 4 kg) of
+// MT x NTW (row tile, weight tile) pairs, rows row0 + 16 i.  THREE passes: every operand from HBM (the rows' cache slots)
+// is requested in one batch; every value is finished (bias, activation, bf16 packing) and PINNED in its own registers;
+// then the stores go out back to back.  Written as one loop, the compiler sinks the arithmetic into the predicated store
+// blocks and re-uses the data registers - and on gfx950 a store's data registers may only be overwritten once the store
+// has COMPLETED (it emits s_waitcnt vmcnt(0) before every store: each of a lane's 8-32 stores waits out the previous
+// one's round trip; 25 us of the 256 x 256 QKV launch, 10 us of every other form).  Same results, same addresses as
+// gemm_epilogue (the decode kernels keep that one: a single store per lane).
+template <typename WT, int EPI, int MT, int NTW>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NTW], const float4 (&ebias)[NTW],
+                                              int row0, int nt0, int TH, int kg, int ks, int n_rows) {
+  static_assert(EPI == EPI_QKV || EPI == EPI_PART || EPI == EPI_RELU, "block GEMM epilogues");
+  constexpr bool PACK = sizeof(WT) == 2;
+  int n[NTW];
+  bool ok[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    n[j] = (nt0 + j) * TH + 4 * kg;
+    ok[j] = 4 * kg < TH && nt0 + j < a.n_tiles && n[j] < a.N;
+  }
+  long rowoff[MT], choff[NTW];
+  bool isq[NTW], isv[NTW];
+  if constexpr (EPI == EPI_QKV) {
+    int pos[MT], seq[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+      const int mg = min(row0 + 16 * i, n_rows - 1);
+      pos[i] = a.row_pos[mg];
+      seq[i] = a.row_seq[mg];
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {               // which matrix / head / element the lane's four channels are (once, not per store)
+      const int d = a.d;
+      isq[j] = n[j] < d;
+      const int c0 = max(n[j] - d, 0);
+      isv[j] = c0 >= d;
+      const int c = c0 - (isv[j] ? d : 0);
+      const int h = c / a.hd;
+      choff[j] = (long)h * a.S_max * a.hd + (c - h * a.hd);
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rowoff[i] = (pos[i] >= 0) ? (long)seq[i] * a.cache_seq_stride + (long)pos[i] * a.hd : -1;
+  }
+  // ---- values
+#pragma unroll
+  for (int i = 0; i < MT; ++i)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      f32x4 v = acc[i][j];
+      if constexpr (EPI != EPI_PART) { v[0] += ebias[j].x; v[1] += ebias[j].y; v[2] += ebias[j].z; v[3] += ebias[j].w; }
+      if constexpr (EPI == EPI_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+      if constexpr (PACK && EPI != EPI_PART) {    // bf16 outputs ride in the first two registers (q of the QKV form stays fp32)
+        const float p0 = __uint_as_float(pack_bf16x2(v[0], v[1])), p1 = __uint_as_float(pack_bf16x2(v[2], v[3]));
+        const bool keep = EPI == EPI_QKV && isq[j];
+        v[0] = keep ? v[0] : p0;
+        v[1] = keep ? v[1] : p1;
+      }
+      asm volatile("" : "+v"(v));
+      acc[i][j] = v;
+    }
+  // ---- stores
+#pragma unroll
+  for (int i = 0; i < MT; ++i) {
+    const int mg = row0 + 16 * i;
+    if (mg >= n_rows) continue;
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) {
+      if (!ok[j]) continue;
+      const f32x4 v = acc[i][j];
+      if constexpr (EPI == EPI_PART) {
+        *reinterpret_cast<f32x4*>(a.part_out + ((long)(ks * a.rows_cap + mg)) * a.N + n[j]) = v;
+      } else if constexpr (EPI == EPI_QKV) {
+        if (isq[j]) {
+          *reinterpret_cast<f32x4*>(a.q_out + (long)mg * a.d + n[j]) = v;
+        } else if (rowoff[i] >= 0) {
+          WT* dst = reinterpret_cast<WT*>(isv[j] ? a.vcache : a.kcache) + rowoff[i] + choff[j];
+          if constexpr (PACK) *reinterpret_cast<uint2*>(dst) = make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1]));
+          else *reinterpret_cast<f32x4*>(dst) = v;
+        }
+      } else {
+        WT* dst = reinterpret_cast<WT*>(a.out) + (long)mg * a.out_ld + n[j];
+        if constexpr (PACK) *reinterpret_cast<uint2*>(dst) = make_uint2(__float_as_uint(v[0]), __float_as_uint(v[1]));
+        else *reinterpret_cast<f32x4*>(dst) = v;
+      }
+    }
+  }
+}
+
 // Decode-step kernel.  The dependency chain of a launch is what the ~80 launches of a step pay for, so
 // the kernel is written around it: (1) everything any later stage needs from HBM - epilogue operands,
 // the first row's prologue operands, the "any sequence still active" word - is requested first, in the
@@ -898,23 +986,16 @@ __global__ __launch_bounds__(256, OCC) void rows_gemm_blk_k(const GemmArgs a) {
 #undef VC_BLK_LDX
 #undef VC_BLK_MM
 #undef VC_BLK_SCHED
-  // ---- epilogue: lane holds channels n..n+3 of row (row tile i, m) for weight tile j
+  // ---- epilogue (tile_epilogue: operands, then values, then the stores back to back)
   const bool nvalid = 4 * kg < TH;
+  float4 ebias[NTW];
 #pragma unroll
-  for (int i = 0; i < MT; ++i) {
-    const int mg = row_blk + wm * (16 * MT) + i * 16 + m;
-    if (mg >= n_rows) continue;
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int nt = nt0 + j;
-      if (nt >= a.n_tiles || !nvalid) continue;
-      const int n = nt * TH + 4 * kg;
-      float4 eb;
-      int epos, eseq;
-      epi_preload<WT, EPI>(a, mg, n, 0, eb, epos, eseq);
-      gemm_epilogue<WT, EPI>(a, acc[i][j], mg, n, ks, 0, 1, eb, epos, eseq);
-    }
+  for (int j = 0; j < NTW; ++j) {
+    const int nt = min(nt0 + j, a.n_tiles - 1);
+    int p0, s0;
+    epi_preload<WT, EPI>(a, 0, nt * TH + (nvalid ? 4 * kg : 0), 0, ebias[j], p0, s0);
   }
+  tile_epilogue<WT, EPI, MT, NTW>(a, acc, ebias, row_blk + wm * (16 * MT) + m, nt0, TH, kg, ks, n_rows);
 }
 
 // ------------------------------------------------------------------ prefill, long row streams: 256 x 256 tiles, everything through LDS-DMA
@@ -977,6 +1058,18 @@ __global__ __launch_bounds__(512) void rows_gemm_big_k(const GemmArgs a) {
   for (int i = 0; i < 16; ++i)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  // Epilogue operands: the bias of the lane's channels is requested HERE, the cache slots of its 16 rows in one batch
+  // right after the k-loop (32 more live registers across the loop spill).  Fetched inside the store loop each is a
+  // dependent L2 round trip between two stores - 32 of them in a row cost the QKV form 25 us.
+  const bool nvalid = 4 * kg < TH;
+  float4 ebias[NTW];
+#pragma unroll
+  for (int j = 0; j < NTW; ++j) {
+    const int nt = min(nt_blk + NTW * wv + j, a.n_tiles - 1);
+    int p0, s0;
+    epi_preload<WT, EPI>(a, 0, nt * TH + (nvalid ? 4 * kg : 0), 0, ebias[j], p0, s0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
   const int nck = kt_blk;
   const unsigned lds_base = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)smem;
   issue(0);
@@ -1025,22 +1118,7 @@ __global__ __launch_bounds__(512) void rows_gemm_big_k(const GemmArgs a) {
     asm volatile("" ::: "memory");
   }
   // ---- epilogue: lane holds channels n..n+3 of row (row tile i, m) for weight tile j
-  const bool nvalid = 4 * kg < TH;
-#pragma unroll
-  for (int i = 0; i < 16; ++i) {
-    const int mg = row_blk + i * 16 + m;
-    if (mg >= a.n_rows) continue;
-#pragma unroll
-    for (int j = 0; j < NTW; ++j) {
-      const int nt = nt_blk + NTW * wv + j;
-      if (nt >= a.n_tiles || !nvalid) continue;
-      const int n = nt * TH + 4 * kg;
-      float4 eb;
-      int epos, eseq;
-      epi_preload<WT, EPI>(a, mg, n, 0, eb, epos, eseq);
-      gemm_epilogue<WT, EPI>(a, acc[i][j], mg, n, ks, 0, 1, eb, epos, eseq);
-    }
-  }
+  tile_epilogue<WT, EPI, 16, NTW>(a, acc, ebias, row_blk + m, nt_blk + NTW * wv, TH, kg, ks, a.n_rows);
 }
 
 template <int EPI, int NTW>
