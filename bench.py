@@ -351,17 +351,19 @@ def main():
         w_bytes = esz * (L * (12 * d * d + 13 * d) + 2 * d + K * (d * P + P + P * V + V))
         s_mean = args.lx + args.prompt_frames + 1 + Tg / 2
         step_bytes = w_bytes + B * esz * 2 * L * d * (s_mean + 1)        # weights (once per step) + KV read + KV write of each of the B sequences
-        # dominant kernel: the FFN up-projection rows-GEMM (LayerNorm prologue, ReLU epilogue)
+        # dominant kernel: the FFN down-projection rows-GEMM (plain prologue, split-K partial slabs) - the largest share of
+        # kernel time in every round-3 profile once the up-projection's first half is prefetched under the attention launch
+        # (profiles/r03g_*: 22.4 % against 17.9 %); timed in isolation here, so in agreement with its in-situ rocprof average
         mb_rows = min(B, 16)       # the kernel microbenchmarks drive the <=16-row decode kernels
-        k_ms, k_bytes = eng.bench_kernel("ffn1", n_rows=mb_rows, iters=64)
+        k_ms, k_bytes = eng.bench_kernel("ffn2", n_rows=mb_rows, iters=64)
         step_ms, _ = eng.bench_kernel("step", n_rows=mb_rows, iters=8)
         kernels = {}
         for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
             ms_, by_ = eng.bench_kernel(kn, n_rows=mb_rows, iters=64)
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
-        roof = {"bound": "hbm", "kernel": "rows_gemm_k<LN,ReLU> (FFN up-projection)",
+        roof = {"bound": "hbm", "kernel": "rows_gemm_k<plain,split-K slabs> (FFN down-projection)",
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn1", args),
+                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn2", args),
                 "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
         # the prefill is GEMM-shaped: MFMA rooflines of its widest block GEMM (FFN up-projection) at the run's own pass
         # size and at a full 512-row pass, and of the MFMA tile attention

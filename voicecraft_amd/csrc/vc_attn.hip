@@ -30,6 +30,42 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 #ifndef VC_ATT_WAVES
 #define VC_ATT_WAVES 8
 #endif
+
+// ---------------------------------------------------------------- piggyback weight prefetch (decode, one row)
+// At one row per step the attention launch is the only one of a layer that does not saturate HBM (7 MB of K/V in 5 us on
+// half the CUs), and the launches behind it start cold: the same out-projection takes 3.5 us instead of 4.4 when its
+// 8.4 MB are still in L2, the FFN up-projection 5.1 instead of 9.1 (profiles/r03_prefetch_probe.log).  "In L2" means in
+// the L2 of the XCD that will ask: each XCD has its own, and a GEMM workgroup x (= weight tile x) runs on XCD x % 8
+// because the hardware deals workgroups to the XCDs round-robin in launch order.  So the attention launch carries pf_z
+// extra grid.z slices of workgroups; each works out which XCD it landed on from its own launch-order index and reads
+// the leading `len` bytes of that XCD's tiles of up to two matrices (results discarded: the point is the L2 fill).
+// No synchronisation, no extra launch, no second stream (round 1's fork/join per layer and this round's paced
+// side-stream prefetcher both cost more than the misses they removed) - if the dealing order ever
+// differs the only loss is the hit rate.
+__device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned lin0 = gridDim.x * gridDim.y * (unsigned)a.nsplit;        // first prefetch workgroup
+  const unsigned npf = gridDim.x * gridDim.y * (unsigned)a.pf_z;
+  const unsigned xcd = lin & 7u;
+  const unsigned j = (lin - lin0) >> 3, nj = max(npf >> 3, 1u);            // this workgroup among its XCD's prefetchers
+  const unsigned tid = threadIdx.x, nthr = blockDim.x;
+  // The loads land in ONE register quad that stays live ("+v") until the final wait: the compiler treats an asm load as
+  // complete when the statement ends, so a dead "=v" destination is handed to the next address computation while the
+  // data is still in flight (first version: the late write corrupted a later address - memory aperture violation).
+  u32x4 sink = {0u, 0u, 0u, 0u};
+#pragma unroll
+  for (int sgi = 0; sgi < 2; ++sgi) {
+    const PfSeg sg = a.pf[sgi];
+    if (sg.len <= 0) continue;
+    for (unsigned t = j; t < (unsigned)sg.n_tiles / 8u; t += nj) {
+      const char* src = sg.base + (size_t)(xcd + 8u * t) * (size_t)sg.tile_bytes;
+      for (unsigned off = tid * 16u; off < (unsigned)sg.len; off += nthr * 16u) {
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src + off) : "memory");
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+}
 template <typename WT>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;
@@ -39,6 +75,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
   VC_KTS_DECL();
   VC_KTS(0);
   const int r = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;     // grid.x == n_rows
+  if (sp >= a.nsplit) { prefetch_role(a); return; }              // (wave-uniform, kernel arguments only)
   // one scalar round trip for everything the addresses depend on (no early exit in between: a
   // branch would let the compiler serialise these three loads)
   const int active = *a.n_active;
@@ -174,7 +211,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 }
 
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s) {
-  dim3 grid(rows_cap, a.H, a.nsplit);
+  dim3 grid(rows_cap, a.H, a.nsplit + a.pf_z);
   ++vc_launch_counts[VC_LC_ROWS_ATTN];
   if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(rows_attn_k<bf16_t>, grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
   else hipLaunchKernelGGL(rows_attn_k<float>, grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
@@ -208,186 +245,17 @@ hipError_t vc_launch_copy_kv(void* cache, long seq_stride, int H, int S_max, int
 // prefill_batch), so a tile of 16 consecutive rows belongs to ONE sequence and holds consecutive positions
 // pos0 .. pos0+na-1 (na <= 16: the tail of a prompt's last tile is padding, row_pos = -1).  rows_attn_k walks the
 // whole prefix once per ROW (2 GB of K/V out of L2 per layer for a 700-row prompt - that was 45 % of the prefill);
-// here a workgroup owns (row tile, head), its 4 waves take every 4th key tile, and per key tile of KW keys
+// here a workgroup owns (row tile, head), its NW waves take every NW-th key tile, and per key tile of KW keys
 // (bf16: 32, fp32: 16):
 //   S = Q K^T   MFMA: A = Q fragments (registers, pre-scaled), B = K straight from the cache (a cached row IS a B fragment)
 //   online softmax on the D layout (lane = 4 query rows x 1 key): row max / row sum are 16-lane DPP reductions
-//   O += P V    MFMA: A = P (re-laid out through a 1 KB wave-private LDS tile), B = V^T (the V tile is transposed
-//               into wave-private LDS while it is copied: the contraction index of this product is the KEY)
-// The four partial (max, sum, O) sets are merged through LDS at the end.  No block barrier inside the key loop.
-template <typename WT, int HD>
-__global__ __launch_bounds__(256) void tile_attn_k(const AttnArgs a) {
-  using T = WTr<WT>;
-  constexpr int EPL = T::EPL, KW = T::KW;            // elements per 16-byte fragment; keys per tile = k-extent of a fragment
-  constexpr int NSUB = KW / 16;                      // 16-key sub-tiles of S per key tile
-  constexpr int NKS = HD / KW;                       // k-steps of Q K^T
-  constexpr int NDT = HD / 16;                       // 16-wide dim tiles of O
-  constexpr int SZ = (int)sizeof(WT);
-  constexpr int VS = KW * SZ + 16;                   // LDS row stride of V^T [HD][KW] and of P [16][KW]
-  constexpr int WAVE_LDS = (HD + 16) * VS;
-  constexpr int NPK = 4 / SZ;                        // keys packed into one 32-bit LDS word of V^T (bf16: 2)
-  constexpr int VITEMS = (KW / NPK) * (HD / EPL) / 64;   // (key group, dim group) items per lane per tile
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int m = lane & 15, kg = lane >> 4;
-  const int r0 = blockIdx.x * 16, h = blockIdx.y;
-  const int share = *a.share_len;
-  const int rp = (r0 + m < a.n_rows) ? a.row_pos[r0 + m] : -1;
-  const int pos0 = __builtin_amdgcn_readfirstlane(rp);
-  const int seq = a.row_seq[r0];
-  const int na = __popcll(__ballot(rp >= 0 && lane < 16));       // active rows: positions pos0 .. pos0+na-1
-  char* vt = smem + wave * WAVE_LDS;                   // V^T tile of this wave
-  char* pt = vt + HD * VS;                             // P tile of this wave
-  float mrun[4], lrun[4];
-  f32x4 o[NDT];
-#pragma unroll
-  for (int r = 0; r < 4; ++r) { mrun[r] = -INFINITY; lrun[r] = 0.f; }
-#pragma unroll
-  for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-  if (na > 0 && pos0 >= 0) {
-    const int last = pos0 + na - 1;
-    // ---- Q fragments (A operand): lane holds Q[row m][dims KW*ks + EPL*kg ..), pre-scaled, as WT
-    uint4 qf[NKS];
-    {
-      const float* qp = a.q + (long)min(r0 + m, a.n_rows - 1) * a.d + h * HD + EPL * kg;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) {
-        WT tmp[EPL];
-#pragma unroll
-        for (int j = 0; j < EPL; ++j) T::st(&tmp[j], qp[KW * ks + j] * a.scale);
-        qf[ks] = *reinterpret_cast<const uint4*>(tmp);
-      }
-    }
-    const long hbase = (long)h * a.S_max * HD;
-    const WT* kc = reinterpret_cast<const WT*>(a.kcache) + hbase;
-    const WT* vc = reinterpret_cast<const WT*>(a.vcache) + hbase;
-    const long own = (long)seq * a.cache_seq_stride;   // positions below `share` live in sequence 0's cache
-    for (int kt0 = wave * KW; kt0 <= last; kt0 += 4 * KW) {
-      // ---- requests: K fragments (B operand: lane = key kt0 + 16 sub + m, dims KW ks + EPL kg), V items
-      uint4 kf[NSUB][NKS];
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
-        const int kp = min(kt0 + sub * 16 + m, last);
-        const WT* kr = kc + ((kp < share) ? 0 : own) + (long)kp * HD + EPL * kg;
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) kf[sub][ks] = *reinterpret_cast<const uint4*>(kr + KW * ks);
-      }
-      uint4 vu[VITEMS][NPK];
-#pragma unroll
-      for (int it = 0; it < VITEMS; ++it) {
-        const int item = it * 64 + lane;
-        const int kgrp = item / (HD / EPL), dgrp = item - kgrp * (HD / EPL);
-#pragma unroll
-        for (int q = 0; q < NPK; ++q) {
-          const int kp = min(kt0 + kgrp * NPK + q, last);
-          vu[it][q] = *reinterpret_cast<const uint4*>(vc + ((kp < share) ? 0 : own) + (long)kp * HD + dgrp * EPL);
-        }
-      }
-      // ---- S = Q K^T : D[row 4 kg + r][key 16 sub + m]
-      f32x4 sc[NSUB];
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub) {
-        sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int ks = 0; ks < NKS; ++ks) sc[sub] = mfma_frag(qf[ks], kf[sub][ks], sc[sub], (WT*)nullptr);
-      }
-      // ---- V tile -> V^T in LDS (wave-private): word (dim, key group) = the NPK keys' values of that dim
-#pragma unroll
-      for (int it = 0; it < VITEMS; ++it) {
-        const int item = it * 64 + lane;
-        const int kgrp = item / (HD / EPL), dgrp = item - kgrp * (HD / EPL);
-        char* dst = vt + (dgrp * EPL) * VS + kgrp * 4;
-        if constexpr (NPK == 2) {
-          const uint32_t a0[4] = {vu[it][0].x, vu[it][0].y, vu[it][0].z, vu[it][0].w};
-          const uint32_t a1[4] = {vu[it][1].x, vu[it][1].y, vu[it][1].z, vu[it][1].w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {                  // dims 2j, 2j+1 of both keys
-            *reinterpret_cast<uint32_t*>(dst + (2 * j) * VS) = (a0[j] & 0xffffu) | (a1[j] << 16);
-            *reinterpret_cast<uint32_t*>(dst + (2 * j + 1) * VS) = (a0[j] >> 16) | (a1[j] & 0xffff0000u);
-          }
-        } else {
-          const uint32_t a0[4] = {vu[it][0].x, vu[it][0].y, vu[it][0].z, vu[it][0].w};
-#pragma unroll
-          for (int j = 0; j < 4; ++j) *reinterpret_cast<uint32_t*>(dst + j * VS) = a0[j];
-        }
-      }
-      // ---- causal mask + online softmax (rows of a DPP row = the 16 keys of a sub-tile)
-      float p[NSUB][4], corr[4];
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qrow = 4 * kg + r;
-        const int qpos = (qrow < na) ? pos0 + qrow : -1;
-        float mx = -INFINITY;
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-          const int kp = kt0 + sub * 16 + m;
-          p[sub][r] = (kp <= qpos) ? sc[sub][r] : -INFINITY;
-          mx = fmaxf(mx, p[sub][r]);
-        }
-        mx = fmaxf(mx, dpp_f<VC_DPP_QP_1032>(mx));
-        mx = fmaxf(mx, dpp_f<VC_DPP_QP_2301>(mx));
-        mx = fmaxf(mx, dpp_f<VC_DPP_ROW_HALF_MIRROR>(mx));
-        mx = fmaxf(mx, dpp_f<VC_DPP_ROW_MIRROR>(mx));
-        const float mn = fmaxf(mrun[r], mx);
-        corr[r] = (mn == -INFINITY) ? 0.f : expf(mrun[r] - mn);          // exp(-inf) = 0 on the first tile
-        float ps = 0.f;
-#pragma unroll
-        for (int sub = 0; sub < NSUB; ++sub) {
-          p[sub][r] = (p[sub][r] == -INFINITY) ? 0.f : expf(p[sub][r] - mn);
-          ps += p[sub][r];
-        }
-        lrun[r] = lrun[r] * corr[r] + row_sum(ps);
-        mrun[r] = mn;
-      }
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) { o[dt][0] *= corr[0]; o[dt][1] *= corr[1]; o[dt][2] *= corr[2]; o[dt][3] *= corr[3]; }
-      // ---- P -> LDS as [row][key], read back as the A fragment (row m, keys EPL kg ..)
-#pragma unroll
-      for (int sub = 0; sub < NSUB; ++sub)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) T::st(reinterpret_cast<WT*>(pt + (4 * kg + r) * VS) + sub * 16 + m, p[sub][r]);
-      const uint4 pf = *reinterpret_cast<const uint4*>(pt + m * VS + kg * 16);
-      // ---- O += P V : D[row 4 kg + r][dim 16 dt + m]
-#pragma unroll
-      for (int dt = 0; dt < NDT; ++dt) {
-        const uint4 vf = *reinterpret_cast<const uint4*>(vt + (dt * 16 + m) * VS + kg * 16);
-        o[dt] = mfma_frag(pf, vf, o[dt], (WT*)nullptr);
-      }
-    }
-  }
-  // ---- merge the four waves' partials, normalise, store (rows past na get zeros)
-  __syncthreads();                                       // every wave is done with its V^T / P tiles
-  float* mo = reinterpret_cast<float*>(smem);            // [4 waves][16 rows][HD]
-  float* mm = mo + 4 * 16 * HD;                          // [4][16][2]
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const int qrow = 4 * kg + r;
-#pragma unroll
-    for (int dt = 0; dt < NDT; ++dt) mo[(wave * 16 + qrow) * HD + dt * 16 + m] = o[dt][r];
-    if (m == 0) { mm[(wave * 16 + qrow) * 2] = mrun[r]; mm[(wave * 16 + qrow) * 2 + 1] = lrun[r]; }
-  }
-  __syncthreads();
-  for (int e = tid; e < 16 * HD; e += 256) {
-    const int qrow = e / HD, dim = e - qrow * HD;
-    if (r0 + qrow >= a.n_rows) continue;
-    float M = -INFINITY;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) M = fmaxf(M, mm[(w * 16 + qrow) * 2]);
-    float L = 0.f, O = 0.f;
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      const float mw = mm[(w * 16 + qrow) * 2];
-      const float c = (mw == -INFINITY) ? 0.f : expf(mw - M);
-      L += c * mm[(w * 16 + qrow) * 2 + 1];
-      O += c * mo[(w * 16 + qrow) * HD + dim];
-    }
-    T::st(reinterpret_cast<WT*>(a.x_out) + (long)(r0 + qrow) * a.d + h * HD + dim, (L > 0.f) ? O / L : 0.f);
-  }
-}
-
-// Round 3: the same product with the key loop software-pipelined.  tile_attn_k above leaves every key tile's K/V requests
-// un-overlapped (a 512-row pass = 4 dependent L2 round trips per wave = 26 us for 1 GFLOP); here
+//   O += P V    MFMA: A = P (re-laid out through a 1 KB wave-private LDS tile), B = V^T.  The contraction index of this
+//               product is the KEY, which the cache stores as the slow index: bf16 keeps the V tile row-major in
+//               wave-private LDS and reads it back through ds_read_b64_tr_b16; fp32 transposes while it copies.
+// The partial (max, sum, O) sets of the waves are merged through LDS at the end.  No block barrier inside the key loop.
+//
+// Round 3 (the round-2 kernel left every key tile's requests un-overlapped: a 512-row pass = 4 dependent L2 round trips
+// per wave = 26 us for 1 GFLOP; now 14.7 us, 800 rows 49 -> 25 us, 2048 rows 213 -> 90 us):
 //   * the NEXT key tile's K fragments and V items are requested as soon as the current tile's have been consumed (after
 //     Q K^T and the V^T copy), so they fly under the softmax and P V - in the SAME registers: a second register set
 //     costs 300 VGPRs = one wave per SIMD, measured worse than the latency it hides,
@@ -395,11 +263,12 @@ __global__ __launch_bounds__(256) void tile_attn_k(const AttnArgs a) {
 //     over the 8 XCDs, so a head's K/V prefix (re-read by every row tile of that head) stays in ONE XCD's L2 instead of
 //     being fetched into all eight; the longest row tiles are dealt first,
 //   * the softmax runs in base 2 (Q pre-scaled by log2 e, v_exp_f32 directly).
-// NW waves split the key tiles of one (16-row tile, head).
+//   * tiles the causal mask does not cut take a mask-free softmax, the accumulators are rescaled only when a running
+//     maximum moved, a tile inside the prefix is addressed from ONE wave-uniform base.
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <typename WT, int HD, int NW, int OCC = 1>
-__global__ __launch_bounds__(64 * NW, OCC) void tile_attn2_k(const AttnArgs a) {
+template <typename WT, int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void tile_attn_k(const AttnArgs a) {
   using T = WTr<WT>;
   constexpr int EPL = T::EPL, KW = T::KW;
   constexpr int NSUB = KW / 16, NKS = HD / KW, NDT = HD / 16;
@@ -640,53 +509,30 @@ __global__ __launch_bounds__(64 * NW, OCC) void tile_attn2_k(const AttnArgs a) {
   }
 }
 
-template <typename WT, int HD, int NW, int OCC = 1>
-static hipError_t launch_tile_attn2(const AttnArgs& a, hipStream_t s) {
+template <typename WT, int HD, int NW>
+static hipError_t launch_tile_attn(const AttnArgs& a, hipStream_t s) {
   constexpr int VS = WTr<WT>::KW * (int)sizeof(WT) + 16;
   constexpr size_t vbytes = sizeof(WT) == 2 ? (size_t)(HD / 16) * (WTr<WT>::KW * 32 + 32) : (size_t)HD * VS;   // as in the kernel
   constexpr size_t wave_lds = vbytes + (size_t)16 * VS;
   constexpr size_t merge = (size_t)(NW * 16 * HD + NW * 16 * 2) * sizeof(float);
   constexpr size_t lds = (NW * wave_lds > merge) ? NW * wave_lds : merge;
-  static bool attr = false;
-  if (!attr) { (void)hipFuncSetAttribute((const void*)tile_attn2_k<WT, HD, NW, OCC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-  hipLaunchKernelGGL((tile_attn2_k<WT, HD, NW, OCC>), dim3(a.H, (a.n_rows + 15) / 16), dim3(64 * NW), lds, s, a);
+  static_assert(lds <= 64 * 1024, "tile_attn_k: raise the dynamic LDS limit (hipFuncSetAttribute) for this shape");
+  hipLaunchKernelGGL((tile_attn_k<WT, HD, NW>), dim3(a.H, (a.n_rows + 15) / 16), dim3(64 * NW), lds, s, a);
   return hipGetLastError();
 }
 
-template <typename WT, int HD>
-static hipError_t launch_tile_attn(const AttnArgs& a, hipStream_t s) {
-  constexpr int VS = WTr<WT>::KW * (int)sizeof(WT) + 16;
-  constexpr size_t wave_lds = (size_t)(HD + 16) * VS;
-  constexpr size_t merge = (size_t)(4 * 16 * HD + 4 * 16 * 2) * sizeof(float);
-  constexpr size_t lds = (4 * wave_lds > merge) ? 4 * wave_lds : merge;
-  hipLaunchKernelGGL((tile_attn_k<WT, HD>), dim3((a.n_rows + 15) / 16, a.H), dim3(256), lds, s, a);
-  return hipGetLastError();
-}
 // Prefill passes whose rows come in 16-row tiles of one sequence each (vc_engine.hip prefill_batch).
 hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s) {
   if (!a.x_out) return hipErrorInvalidValue;
   ++vc_launch_counts[VC_LC_TILE_ATTN];
-  static const int form = [] { const char* v = getenv("VC_TILE_ATTN"); return v ? atoi(v) : 2; }();   // 1 = the round-2 kernel, 2 = pipelined (4 waves), 8 = pipelined with 8 waves
-  if (form != 1) {
-    if (dtype == VC_DTYPE_BF16) {
-      if (a.hd == 128) return form == 8 ? launch_tile_attn2<bf16_t, 128, 8>(a, s) : form == 3 ? launch_tile_attn2<bf16_t, 128, 4, 3>(a, s) : launch_tile_attn2<bf16_t, 128, 4>(a, s);
-      if (a.hd == 64) return launch_tile_attn2<bf16_t, 64, 4>(a, s);
-      if (a.hd == 32) return launch_tile_attn2<bf16_t, 32, 4>(a, s);
-    } else {
-      if (a.hd == 128) return launch_tile_attn2<float, 128, 4>(a, s);
-      if (a.hd == 64) return launch_tile_attn2<float, 64, 4>(a, s);
-      if (a.hd == 32) return launch_tile_attn2<float, 32, 4>(a, s);
-    }
-    return hipErrorInvalidValue;
-  }
   if (dtype == VC_DTYPE_BF16) {
-    if (a.hd == 128) return launch_tile_attn<bf16_t, 128>(a, s);
-    if (a.hd == 64) return launch_tile_attn<bf16_t, 64>(a, s);
-    if (a.hd == 32) return launch_tile_attn<bf16_t, 32>(a, s);
+    if (a.hd == 128) return launch_tile_attn<bf16_t, 128, 4>(a, s);
+    if (a.hd == 64) return launch_tile_attn<bf16_t, 64, 4>(a, s);
+    if (a.hd == 32) return launch_tile_attn<bf16_t, 32, 4>(a, s);
   } else {
-    if (a.hd == 128) return launch_tile_attn<float, 128>(a, s);
-    if (a.hd == 64) return launch_tile_attn<float, 64>(a, s);
-    if (a.hd == 32) return launch_tile_attn<float, 32>(a, s);
+    if (a.hd == 128) return launch_tile_attn<float, 128, 4>(a, s);
+    if (a.hd == 64) return launch_tile_attn<float, 64, 4>(a, s);
+    if (a.hd == 32) return launch_tile_attn<float, 32, 4>(a, s);
   }
   return hipErrorInvalidValue;
 }

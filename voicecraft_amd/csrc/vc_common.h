@@ -245,6 +245,12 @@ struct GemmArgs {
   unsigned progress_val;    // prefetcher follows (vc_stream.hip); progress_val = index of this launch's matrix in the step, + 1
 };
 
+struct PfSeg {              // a packed weight matrix whose workgroup x reads tile x (rows_gemm_k: grid.x = tile, XCD = x % 8)
+  const char* base;
+  int n_tiles;              // multiple of 8
+  int tile_bytes;           // bytes between consecutive tiles
+  int len;                  // leading bytes of every tile to fetch (multiple of 8 KB; 0 = segment unused)
+};
 struct AttnArgs {
   const float* q;           // [VC_ROWS][d]
   const void* kcache;
@@ -262,6 +268,10 @@ struct AttnArgs {
   float* att_ml;
   void* x_out;              // nsplit == 1 only: normalised output rows, WT [rows][d] (the out-projection then takes the plain prologue)
   long long* dbg_ts;        // diagnostic builds only
+  // rows_attn_k only: pf_z extra grid.z slices of workgroups that do no attention - they pull the head of the NEXT launches'
+  // weight tiles into the L2 of the XCD whose workgroups will read them (vc_attn.hip, "piggyback prefetch"); 0 = none
+  PfSeg pf[2];
+  int pf_z;
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence

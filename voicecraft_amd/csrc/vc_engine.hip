@@ -88,6 +88,11 @@ struct vc_engine {
 
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
   int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
+  // piggyback weight prefetch of the one-row attention launch (vc_attn.hip prefetch_role): VC_ATTN_PF=z[,wo_kb[,w1_kb]], 0 = off.
+  // Measured (profiles/r03g_attn_prefetch_sweep.log): 8 slices x the first 32 KB of every FFN-up tile 0.598 -> 0.589 ms per step;
+  // the out-projection's own matrix gains nothing (that launch waits for the attention partials, not for its weights),
+  // 48-64 KB per tile or 4 slices lose (the attention launch ends with its slowest prefetcher).
+  int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = 32;
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
@@ -317,6 +322,15 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
+      if (e->apf_z > 0 && rs.n_rows == 1 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0) {
+        // one row: the launch leaves HBM mostly idle - extra workgroups pull the next two matrices' tiles into the L2 of
+        // the XCD that will read them (prefetch_role)
+        const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
+        const int tile_b = (d / KW) * 64 * 16;                 // out-projection and FFN-up tiles: 16 channels x d
+        a.pf_z = e->apf_z;
+        a.pf[0] = PfSeg{(const char*)ly.Wo, e->p_o.n_tiles, tile_b, std::min(tile_b, e->apf_wo_kb * 1024)};
+        a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->apf_w1_kb * 1024)};
+      }
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {  // out-projection of the merged attention output -> split-K partial slabs
@@ -1073,6 +1087,13 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));   // 16: decode kernels only
     const char* ls = getenv("VC_LN_SPLIT_ROWS");
     if (ls) e->ln_split_rows = std::max(2, atoi(ls));
+    if (const char* ap = getenv("VC_ATTN_PF")) {
+      int z = 0, wo = e->apf_wo_kb, w1 = e->apf_w1_kb;
+      const int n = sscanf(ap, "%d,%d,%d", &z, &wo, &w1);
+      if (n >= 1) e->apf_z = std::max(0, std::min(z, 16));
+      if (n >= 2) e->apf_wo_kb = std::max(0, wo);
+      if (n >= 3) e->apf_w1_kb = std::max(0, w1);
+    }
     const char* gs = getenv("VC_GRAPH_STEPS");
     if (gs) e->steps_per_graph = std::max(1, std::min(64, atoi(gs)));
   }
