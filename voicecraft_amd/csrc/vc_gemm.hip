@@ -751,6 +751,11 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
     const int row1 = row0 + VC_ROWS;
     const int nr1 = min(VC_ROWS, n_rows - row1);
     __syncthreads();                       // X(row0) is in LDS
+    // the epilogue's operands (bias, the rows' cache slots) are requested HERE, ahead of the next X tile: asked for next
+    // to the stores they are a dependent L2 round trip per 16-row tile on the critical path of every workgroup
+    float4 eb = make_float4(0.f, 0.f, 0.f, 0.f);
+    int epos = -1, eseq = 0;
+    if (wave == 0) epi_preload<WT, EPI>(a, row0 + min(m, nr - 1), n, grp, eb, epos, eseq);
     if (nr1 > 0) x_fetch(row1, nr1);       // next tile on its way while this one is in the MFMAs
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int mrow = (m < nr) ? m : 0;
@@ -776,9 +781,6 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
     if (wave == 0 && m < nr && nvalid && tile_ok) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
-      float4 eb;
-      int epos, eseq;
-      epi_preload<WT, EPI>(a, row0 + m, n, grp, eb, epos, eseq);
       gemm_epilogue<WT, EPI>(a, acc, row0 + m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
     }
     __syncthreads();            // x and red are rewritten for the next tile

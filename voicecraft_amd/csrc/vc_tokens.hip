@@ -460,6 +460,10 @@ __device__ void advance_phase(const SampleArgs& a, const SampleDyn& dy, int b, b
         n_eog += 1;
       }
       cur += 1;
+      // every token final and in its own register BEFORE the first store: consumed inside the predicated store blocks, the
+      // (test-only) forced-token loads above make the compiler wait vmcnt(0) in each block - every store behind the last
+#pragma unroll
+      for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) asm volatile("" : "+v"(tok[k]));
       if (step < dy.max_steps) {
 #pragma unroll
         for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) a.gen[((long)b * a.gen_stride + step) * K + k] = tok[k];
@@ -518,26 +522,37 @@ __device__ void advance_phase(const SampleArgs& a, const SampleDyn& dy, int b, b
   float* h0 = a.dec_h + (long)(b * a.rps) * d;
   const float* pe0 = a.pe + (long)ylen * d;
   const int nq = d >> 2;
-  for (int i = tid; i < nq; i += blockDim.x) {
-    const float4 p = *reinterpret_cast<const float4*>(pe0 + i * 4);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  // two columns per thread and pass (d = 2048: the whole row in ONE round trip instead of two dependent ones)
+  for (int i = tid; i < nq; i += 2 * blockDim.x) {
+    const int i2 = i + blockDim.x;
+    const bool two = i2 < nq;
+    const int j2 = two ? i2 : i;
+    const float4 pa = *reinterpret_cast<const float4*>(pe0 + i * 4), pb = *reinterpret_cast<const float4*>(pe0 + j2 * 4);
+    float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vb = va;
 #pragma unroll 1
-    for (int k0 = 0; k0 < K; k0 += 4) {            // four gathers in flight per pass; summed in order k = 0..K-1
-      float4 e[4];
+    for (int k0 = 0; k0 < K; k0 += 4) {            // eight gathers in flight per pass; summed in order k = 0..K-1
+      float4 ea[4], eb[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int kk = (k0 + q < K) ? k0 + q : 0;
-        e[q] = *reinterpret_cast<const float4*>(a.audio_emb + ((long)kk * a.V + s_tok[kk]) * d + i * 4);
+        const float* row = a.audio_emb + ((long)kk * a.V + s_tok[kk]) * d;
+        ea[q] = *reinterpret_cast<const float4*>(row + i * 4);
+        eb[q] = *reinterpret_cast<const float4*>(row + j2 * 4);
       }
 #pragma unroll
       for (int q = 0; q < 4; ++q)
         if (k0 + q < K) {
-          if (k0 + q == 0) v = e[q];
-          else { v.x += e[q].x; v.y += e[q].y; v.z += e[q].z; v.w += e[q].w; }
+          if (k0 + q == 0) { va = ea[q]; vb = eb[q]; }
+          else {
+            va.x += ea[q].x; va.y += ea[q].y; va.z += ea[q].z; va.w += ea[q].w;
+            vb.x += eb[q].x; vb.y += eb[q].y; vb.z += eb[q].z; vb.w += eb[q].w;
+          }
         }
     }
-    v.x += a.alpha_audio * p.x; v.y += a.alpha_audio * p.y; v.z += a.alpha_audio * p.z; v.w += a.alpha_audio * p.w;
-    *reinterpret_cast<float4*>(h0 + i * 4) = v;
+    va.x += a.alpha_audio * pa.x; va.y += a.alpha_audio * pa.y; va.z += a.alpha_audio * pa.z; va.w += a.alpha_audio * pa.w;
+    vb.x += a.alpha_audio * pb.x; vb.y += a.alpha_audio * pb.y; vb.z += a.alpha_audio * pb.z; vb.w += a.alpha_audio * pb.w;
+    *reinterpret_cast<float4*>(h0 + i * 4) = va;
+    if (two) *reinterpret_cast<float4*>(h0 + i2 * 4) = vb;
   }
   if (mode == 3) {   // span switch: [last token, mask_embedding[next span], all-empty column] (voicecraft.py:838-858)
     for (int i = tid; i < nq; i += blockDim.x) {
