@@ -33,39 +33,14 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 
 // ---------------------------------------------------------------- piggyback weight prefetch (decode, one row)
 // At one row per step the attention launch is the only one of a layer that does not saturate HBM (7 MB of K/V in 5 us on
-// half the CUs), and the launches behind it start cold: the same out-projection takes 3.5 us instead of 4.4 when its
-// 8.4 MB are still in L2, the FFN up-projection 5.1 instead of 9.1 (profiles/r03_prefetch_probe.log).  "In L2" means in
-// the L2 of the XCD that will ask: each XCD has its own, and a GEMM workgroup x (= weight tile x) runs on XCD x % 8
-// because the hardware deals workgroups to the XCDs round-robin in launch order.  So the attention launch carries pf_z
-// extra grid.z slices of workgroups; each works out which XCD it landed on from its own launch-order index and reads
-// the leading `len` bytes of that XCD's tiles of up to two matrices (results discarded: the point is the L2 fill).
-// No synchronisation, no extra launch, no second stream (round 1's fork/join per layer and this round's paced
-// side-stream prefetcher both cost more than the misses they removed) - if the dealing order ever
-// differs the only loss is the hit rate.
+// half the CUs), and the launches behind it start cold: the FFN up-projection takes 5.1 us instead of 9.1 when its weights are
+// still in L2 (profiles/r03_prefetch_probe.log).  The launch carries pf_z extra grid.z slices of workgroups that read the
+// leading bytes of up to two matrices' tiles (vc_common.h vc_prefetch_tiles).
 __device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  const unsigned lin0 = gridDim.x * gridDim.y * (unsigned)a.nsplit;        // first prefetch workgroup
-  const unsigned npf = gridDim.x * gridDim.y * (unsigned)a.pf_z;
-  const unsigned xcd = lin & 7u;
-  const unsigned j = (lin - lin0) >> 3, nj = max(npf >> 3, 1u);            // this workgroup among its XCD's prefetchers
-  const unsigned tid = threadIdx.x, nthr = blockDim.x;
-  // The loads land in ONE register quad that stays live ("+v") until the final wait: the compiler treats an asm load as
-  // complete when the statement ends, so a dead "=v" destination is handed to the next address computation while the
-  // data is still in flight (first version: the late write corrupted a later address - memory aperture violation).
-  u32x4 sink = {0u, 0u, 0u, 0u};
-#pragma unroll
-  for (int sgi = 0; sgi < 2; ++sgi) {
-    const PfSeg sg = a.pf[sgi];
-    if (sg.len <= 0) continue;
-    for (unsigned t = j; t < (unsigned)sg.n_tiles / 8u; t += nj) {
-      const char* src = sg.base + (size_t)(xcd + 8u * t) * (size_t)sg.tile_bytes;
-      for (unsigned off = tid * 16u; off < (unsigned)sg.len; off += nthr * 16u) {
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src + off) : "memory");
-      }
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+  vc_prefetch_tiles(a.pf, 2, lin, gridDim.x * gridDim.y * (unsigned)a.nsplit, gridDim.x * gridDim.y * (unsigned)a.pf_z);
 }
+
 template <typename WT>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;

@@ -190,6 +190,43 @@ struct SeqState {
 enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2 };
 enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4 };
 
+// ---------------------------------------------------------------- piggyback weight prefetch
+// A launch that leaves HBM idle (the one-row attention launch, the per-row LayerNorm launches of a several-row step) carries
+// extra workgroups that do none of its work: they pull the head of the NEXT launches' weight tiles into the L2 of the XCD whose
+// workgroups will read them.  "The right L2" is the point: each XCD has its own, and a GEMM workgroup x (= weight tile x)
+// runs on XCD x % 8 because the hardware deals workgroups to the XCDs round-robin in launch order - so a prefetch workgroup
+// derives its XCD from its own launch-order index `lin` and takes that XCD's tiles.  No synchronisation, no extra launch, no
+// second stream (round 1's fork/join per layer and round 3's paced side-stream prefetcher both cost more than the misses
+// they removed); if the dealing order ever differs the only loss is the hit rate.
+struct PfSeg {              // a packed weight matrix whose workgroup x reads tile x (rows_gemm_k: grid.x = tile, XCD = x % 8)
+  const char* base;
+  int n_tiles;              // multiple of 8
+  int tile_bytes;           // bytes between consecutive tiles
+  int len;                  // leading bytes of every tile to fetch (multiple of 8 KB; 0 = segment unused)
+};
+#ifdef __HIPCC__
+// lin0 (a multiple of 8) = launch-order index of the first prefetch workgroup, npf = how many there are
+__device__ __forceinline__ void vc_prefetch_tiles(const PfSeg* segs, int nseg, unsigned lin, unsigned lin0, unsigned npf) {
+  const unsigned xcd = lin & 7u;
+  const unsigned j = (lin - lin0) >> 3, nj = max(npf >> 3, 1u);            // this workgroup among its XCD's prefetchers
+  const unsigned tid = threadIdx.x, nthr = blockDim.x;
+  // The loads land in ONE register quad that stays live ("+v") until the final wait: the compiler treats an asm load as
+  // complete when the statement ends, so a dead "=v" destination is handed to the next address computation while the
+  // data is still in flight (first version: the late write corrupted a later address - memory aperture violation).
+  u32x4 sink = {0u, 0u, 0u, 0u};
+  for (int sgi = 0; sgi < nseg; ++sgi) {
+    const PfSeg sg = segs[sgi];
+    if (sg.len <= 0) continue;
+    for (unsigned t = j; t < (unsigned)sg.n_tiles / 8u; t += nj) {
+      const char* src = sg.base + (size_t)(xcd + 8u * t) * (size_t)sg.tile_bytes;
+      for (unsigned off = tid * 16u; off < (unsigned)sg.len; off += nthr * 16u)
+        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src + off) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+}
+#endif
+
 struct GemmArgs {
   // weights, packed [group][n_tile][k_tile][lane] x 16 bytes
   const uint4* Wp;
@@ -243,14 +280,10 @@ struct GemmArgs {
   long long* dbg_ts;        // shader-clock stamps (diagnostic builds with -DVC_KERNEL_TS only)
   unsigned* progress;       // optional (decode steps): the launch stores progress_val here when it starts - the pace the weight
   unsigned progress_val;    // prefetcher follows (vc_stream.hip); progress_val = index of this launch's matrix in the step, + 1
+  PfSeg pf;                 // ln_rows_k only: pf_blocks extra workgroups prefetch the head of this matrix's tiles (vc_prefetch_tiles); 0 = none
+  int pf_blocks;
 };
 
-struct PfSeg {              // a packed weight matrix whose workgroup x reads tile x (rows_gemm_k: grid.x = tile, XCD = x % 8)
-  const char* base;
-  int n_tiles;              // multiple of 8
-  int tile_bytes;           // bytes between consecutive tiles
-  int len;                  // leading bytes of every tile to fetch (multiple of 8 KB; 0 = segment unused)
-};
 struct AttnArgs {
   const float* q;           // [VC_ROWS][d]
   const void* kcache;

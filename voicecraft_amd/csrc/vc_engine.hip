@@ -93,6 +93,11 @@ struct vc_engine {
   // the out-projection's own matrix gains nothing (that launch waits for the attention partials, not for its weights),
   // 48-64 KB per tile or 4 slices lose (the attention launch ends with its slowest prefetcher).
   int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = 32;
+  // the same for several-row decode steps, carried by the per-row LayerNorm launches (8 workgroups, 4.9 us each, HBM idle):
+  // VC_LN_PF=blocks[,qkv_kb[,w1_kb]] - LN1 prefetches the QKV matrix, LN2 the FFN-up matrix of the same layer; 0 = off
+  // Measured (profiles/r03i_ln_prefetch_sweep.log): whole matrices LOSE (8 rows 0.911 -> 0.924-0.950 ms: the 4.9 us launch grows by
+  // the 5 us the 25 MB take), the first 24 KB of every tile gain 1-2 % (0.857-0.863 -> 0.844).
+  int lpf_blocks = 248, lpf_qkv_kb = 24, lpf_w1_kb = 24;
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
@@ -305,7 +310,13 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.progress_val = 4 * l + 1;
       if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
+        if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_qkv.n_tiles % 8 == 0) {
+          const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * VC_TH_QKV;
+          g.pf = PfSeg{(const char*)ly.Wqkv, e->p_qkv.n_tiles, tile_b, std::min(tile_b, e->lpf_qkv_kb * 1024)};
+          g.pf_blocks = e->lpf_blocks;
+        }
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
+        g.pf_blocks = 0;
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
       } else {
@@ -351,7 +362,13 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.progress_val = 4 * l + 3;
       if (split_ln) {
         g.x_out = e->xn;
+        if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_f1.n_tiles % 8 == 0) {
+          const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * 16;
+          g.pf = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->lpf_w1_kb * 1024)};
+          g.pf_blocks = e->lpf_blocks;
+        }
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
+        g.pf_blocks = 0;
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
       } else {
@@ -1087,6 +1104,13 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));   // 16: decode kernels only
     const char* ls = getenv("VC_LN_SPLIT_ROWS");
     if (ls) e->ln_split_rows = std::max(2, atoi(ls));
+    if (const char* lp = getenv("VC_LN_PF")) {
+      int b = 0, q = e->lpf_qkv_kb, w1 = e->lpf_w1_kb;
+      const int n = sscanf(lp, "%d,%d,%d", &b, &q, &w1);
+      if (n >= 1) e->lpf_blocks = std::max(0, std::min(b, 1024)) & ~7;
+      if (n >= 2) e->lpf_qkv_kb = std::max(0, q);
+      if (n >= 3) e->lpf_w1_kb = std::max(0, w1);
+    }
     if (const char* ap = getenv("VC_ATTN_PF")) {
       int z = 0, wo = e->apf_wo_kb, w1 = e->apf_w1_kb;
       const int n = sscanf(ap, "%d,%d,%d", &z, &wo, &w1);

@@ -1146,6 +1146,11 @@ static hipError_t launch_big(const GemmArgs& a, int ksplit, hipStream_t s) {
 template <typename WT>
 __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   __shared__ float s_sum[4], s_sq[4];
+  if ((int)blockIdx.x >= a.n_rows) {     // piggyback prefetch (several-row decode steps: this launch leaves HBM idle)
+    const unsigned lin0 = ((unsigned)a.n_rows + 7u) & ~7u;
+    if (a.pf_blocks > 0 && blockIdx.x >= lin0) vc_prefetch_tiles(&a.pf, 1, blockIdx.x, lin0, (unsigned)a.pf_blocks);
+    return;
+  }
   const int active = *a.n_active;
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = a.d;
@@ -1202,8 +1207,9 @@ __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
 }
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s) {
   ++vc_launch_counts[VC_LC_LN_ROWS];
-  if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(ln_rows_k<bf16_t>, dim3(a.n_rows), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(ln_rows_k<float>, dim3(a.n_rows), dim3(256), 0, s, a);
+  const int blocks = a.pf_blocks > 0 ? ((a.n_rows + 7) & ~7) + a.pf_blocks : a.n_rows;
+  if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(ln_rows_k<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(ln_rows_k<float>, dim3(blocks), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
