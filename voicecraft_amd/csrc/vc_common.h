@@ -203,6 +203,7 @@ struct PfSeg {              // a packed weight matrix whose workgroup x reads ti
   int n_tiles;              // multiple of 8
   int tile_bytes;           // bytes between consecutive tiles
   int len;                  // leading bytes of every tile to fetch (multiple of 8 KB; 0 = segment unused)
+  int sub;                  // consecutive tiles read by ONE consumer workgroup (rows_gemm_mt_k: 2 or 4; 0 / 1 = one tile each)
 };
 #ifdef __HIPCC__
 // lin0 (a multiple of 8) = launch-order index of the first prefetch workgroup, npf = how many there are
@@ -217,10 +218,13 @@ __device__ __forceinline__ void vc_prefetch_tiles(const PfSeg* segs, int nseg, u
   for (int sgi = 0; sgi < nseg; ++sgi) {
     const PfSeg sg = segs[sgi];
     if (sg.len <= 0) continue;
-    for (unsigned t = j; t < (unsigned)sg.n_tiles / 8u; t += nj) {
-      const char* src = sg.base + (size_t)(xcd + 8u * t) * (size_t)sg.tile_bytes;
-      for (unsigned off = tid * 16u; off < (unsigned)sg.len; off += nthr * 16u)
-        asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src + off) : "memory");
+    const unsigned sub = (unsigned)max(sg.sub, 1);
+    for (unsigned t = j; t < (unsigned)sg.n_tiles / (8u * sub); t += nj) {     // consumer workgroup xcd + 8 t
+      for (unsigned q = 0; q < sub; ++q) {
+        const char* src = sg.base + (size_t)((xcd + 8u * t) * sub + q) * (size_t)sg.tile_bytes;
+        for (unsigned off = tid * 16u; off < (unsigned)sg.len; off += nthr * 16u)
+          asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src + off) : "memory");
+      }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");

@@ -312,7 +312,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         g.x_out = e->xn;
         if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_qkv.n_tiles % 8 == 0) {
           const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * VC_TH_QKV;
-          g.pf = PfSeg{(const char*)ly.Wqkv, e->p_qkv.n_tiles, tile_b, std::min(tile_b, e->lpf_qkv_kb * 1024)};
+          g.pf = PfSeg{(const char*)ly.Wqkv, e->p_qkv.n_tiles, tile_b, std::min(tile_b, e->lpf_qkv_kb * 1024), 1};
           g.pf_blocks = e->lpf_blocks;
         }
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
@@ -339,8 +339,8 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
         const int tile_b = (d / KW) * 64 * 16;                 // out-projection and FFN-up tiles: 16 channels x d
         a.pf_z = e->apf_z;
-        a.pf[0] = PfSeg{(const char*)ly.Wo, e->p_o.n_tiles, tile_b, std::min(tile_b, e->apf_wo_kb * 1024)};
-        a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->apf_w1_kb * 1024)};
+        a.pf[0] = PfSeg{(const char*)ly.Wo, e->p_o.n_tiles, tile_b, std::min(tile_b, e->apf_wo_kb * 1024), 1};
+        a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->apf_w1_kb * 1024), 1};
       }
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -364,7 +364,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         g.x_out = e->xn;
         if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_f1.n_tiles % 8 == 0) {
           const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * 16;
-          g.pf = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->lpf_w1_kb * 1024)};
+          g.pf = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->lpf_w1_kb * 1024), 1};
           g.pf_blocks = e->lpf_blocks;
         }
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
@@ -445,6 +445,8 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.n_parts = (l == 0) ? 0 : e->p_f2.ksplit;
       g.prev_bias = (l == 0) ? ly.bo : e->layers[l - 1].b2; g.has_prev_bias = (l == 0) ? 0 : 1;
       g.x_out = e->xn;
+      // (no piggyback prefetch on the LayerNorm launches of WIDE decode passes: measured at 32 rows with the tiles grouped as
+      // rows_gemm_mt_k reads them, PfSeg.sub = 4 - 1.428-1.437 -> 1.454 ms per step, profiles/r03j_lpf32_ab.log)
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
       g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = mtv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
