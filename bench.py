@@ -397,6 +397,10 @@ def main():
             "roofline": roof, "kernels": kernels,
         }
         out["prefill_roofline"] = mfma
+        # extra workgroups of latency-bound launches that pull the next matrices' tiles into the right L2s (DESIGN.md 4.2 d/e):
+        # additional work inside the timed region, nothing skipped; the switches that were in force
+        out["config"]["piggyback_prefetch"] = {"attention_launch": os.environ.get("VC_ATTN_PF", "8,0,32 (default)"),
+                                               "layernorm_launches": os.environ.get("VC_LN_PF", "248,24,24 (default)")}
         if dist is not None:
             out["collective"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "op": "all_gather of int32 [B,K,T+1] token blocks",
                                  "gather_ms": round(gather_s[0] / args.steps * 1e3, 3)}
