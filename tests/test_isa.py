@@ -1,0 +1,85 @@
+"""CPU: properties of the compiled gfx950 code that the measurements of round 3 depend on (hipcc cross-compiles here; the
+device-only ISA of all translation units takes ~35 s, once per run).
+
+* no hot kernel carries a chain of stores that each wait for the previous one (`s_waitcnt vmcnt(0)` between two stores):
+  the block-GEMM epilogues lost 10-25 us per launch to exactly that before `tile_epilogue`;
+* the decode and prefill kernels use no scratch memory;
+* the instructions a kernel is built around are really there (LDS-DMA and bf16 MFMA in the 256 x 256 GEMM, the LDS
+  transpose-read in the bf16 tile attention, the fp32 MFMA in exact mode, the piggyback prefetch loads in rows_attn_k).
+"""
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import isa_store_scan as isa  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(isa.HIPCC) or shutil.which(isa.HIPCC)), reason="hipcc not available")
+
+
+@pytest.fixture(scope="module")
+def kern(tmp_path_factory):
+    out = {}
+    for stem, text in isa.compile_isa(str(tmp_path_factory.mktemp("isa"))).items():
+        for name, (body, scratch, vgpr) in isa.kernels(text).items():
+            out[isa.demangle(name)] = (body, scratch, vgpr)
+    assert len(out) > 100, len(out)
+    return out
+
+
+def pick(kern, prefix):
+    sel = {n: v for n, v in kern.items() if n.replace("void ", "").startswith(prefix)}
+    assert sel, prefix
+    return sel
+
+
+# opt-in / cold paths that keep a short chain: the persistent stream engine (VC_STREAM=1, measured slower than the launches) and
+# the state-machine tail of best-of-N (one thread, three stores, after the keep decision)
+CHAIN_ALLOWED = ("stream_step_k<", "advance_only_k(")
+
+
+def test_no_serialised_store_chains_in_hot_kernels(kern):
+    bad = {}
+    for name, (body, _, _) in kern.items():
+        n, total = isa.store_chains(body)
+        if n >= 2 and not any(a in name for a in CHAIN_ALLOWED):
+            bad[name] = (n, total)
+    assert not bad, bad
+    # the kernels the rule was found on, explicitly: every store of their epilogues is issued back to back
+    for prefix in ("rows_gemm_big_k<", "rows_gemm_blk_k<bf16_t", "sample_fused_k("):
+        for name, (body, _, _) in pick(kern, prefix).items():
+            assert isa.store_chains(body)[0] <= 1, name
+
+
+# 1024-thread forms of the wide-decode kernel run at the 128-register cap and spill three dwords of epilogue operands
+SCRATCH_ALLOWED = ("rows_gemm_mt_k<bf16_t, 16, 1, 4, 4>", "rows_gemm_mt_k<bf16_t, 16, 1, 0, 4>", "rows_gemm_mt_k<float, 16, 1, 4, 4>",
+                   "rows_gemm_mt_k<float, 16, 1, 0, 4>", "stream_step_k<4>")
+
+
+def test_kernels_use_no_scratch(kern):
+    spilled = {n: s for n, (_, s, _) in kern.items() if s > 0 and not any(a in n for a in SCRATCH_ALLOWED)}
+    assert not spilled, spilled
+    for n, (_, s, _) in kern.items():
+        if any(a in n for a in SCRATCH_ALLOWED):
+            assert s <= 96, (n, s)
+
+
+def test_kernels_are_built_around_the_intended_instructions(kern):
+    for name, (body, _, vgpr) in pick(kern, "rows_gemm_big_k<").items():
+        assert body.count("global_load_lds_dwordx4") >= 4 and body.count("v_mfma_f32_16x16x32_bf16") >= 32, name
+        assert "s_waitcnt vmcnt(8)" in body and vgpr <= 256, name        # counted wait of the 4-stage ring; two waves per SIMD
+    for name, (body, _, vgpr) in pick(kern, "tile_attn_k<bf16_t, 128").items():
+        assert body.count("ds_read_b64_tr_b16") == 16 and body.count("v_mfma_f32_16x16x32_bf16") == 16, name
+        assert body.count("v_exp_f32") >= 8 and vgpr <= 256, name
+    for name, (body, _, _) in pick(kern, "tile_attn_k<float, 128").items():
+        assert "ds_read_b64_tr_b16" not in body and body.count("v_mfma_f32_16x16x4_f32") >= 64, name
+    for name, (body, _, _) in pick(kern, "rows_attn_k<").items():
+        assert ";;#ASMSTART" in body and "global_load_dwordx4" in body.split(";;#ASMSTART")[1].split(";;#ASMEND")[0], name
+    for name, (body, _, _) in pick(kern, "ln_rows_k<").items():
+        assert ";;#ASMSTART" in body, name                                # the prefetch role of several-row decode steps
+    decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2>")                  # FFN-up of a one-row step
+    for name, (body, _, _) in decode.items():
+        assert body.count("v_mfma_f32_16x16x32_bf16") >= 2 and " nt" in body, name     # non-temporal weight stream
