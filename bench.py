@@ -50,6 +50,15 @@ def parse():
     p.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads for the CPU baseline (capped at the core count)")
     p.add_argument("--no-codec", action="store_true", help="skip the EnCodec encode/decode timing block")
     p.add_argument("--dump", default=None, help="rank 0 writes the token blocks gathered in the last step to this .npz (tests)")
+    p.add_argument("--cpu-baseline-only", action="store_true",
+                   help="time only the CPU leg (the port, and the unmodified reference when VC_REFERENCE_ROOT names its tree); needs no GPU")
+    p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                   help="collective backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host collectives, usable when "
+                        "several ranks share ONE GPU (VC_RANKS_SHARE_DEVICE=1: the single-GPU test of the N > 1 code path)")
+    p.add_argument("--ab", default=None, metavar="KNOB=A:B",
+                   help="in-process A/B of one engine option (vc_set_option), e.g. attn_pf=0:8,0,32 - interleaved pairs of whole calls, "
+                        "reported as the `ab` object of the JSON line")
+    p.add_argument("--ab-pairs", type=int, default=7)
     return p.parse_args()
 
 
@@ -67,6 +76,21 @@ def pmc_traffic(kernel, args):
         return int(j["kernels"][kernel]["fetch_bytes_per_launch"])
     except Exception:
         return None
+
+
+def reference_ratio_note(args):
+    """The port timed against the UNMODIFIED reference (same windows, same threads) in the build container, where the
+    reference tree exists: profiles/cpu_reference_vs_port.json, written by `bench.py --cpu-baseline-only` under
+    VC_REFERENCE_ROOT (log: profiles/r04_cpu_reference_vs_port.log)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "cpu_reference_vs_port.json")) as f:
+            j = json.load(f)
+        key = f"{args.preset}/lx{args.lx}/t{args.prompt_frames}/k{args.top_k}"
+        r = j.get(key) or j[j["default"]]
+        return (f"measured against the unmodified reference on the build box ({r['cores']} threads, {r['key']}): port {r['port']} tok/s, "
+                f"reference {r['reference']} tok/s = {r['ratio']}x (profiles/r04_cpu_reference_vs_port.log)")
+    except Exception:
+        return "not timed against the unmodified reference in this tree"
 
 
 def cpu_baseline(args, sd, a, x, x_lens, y):
@@ -113,11 +137,12 @@ def cpu_baseline(args, sd, a, x, x_lens, y):
     tokens = K * (10 * args.lx - args.prompt_frames)
     out = {
         "value": round(tokens / est, 2), "unit": "codec-tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+        "prefill_s": round(t_prefill, 2), "ms_per_step": [round(v * 1e3) for v in per], "whole_run_s": round(est, 1),
         "sample": (f"{args.preset} fp32, Lx={args.lx}, {args.prompt_frames} prompt frames: prefill {t_prefill:.2f} s; {n} decode steps at the "
                    f"start / middle / end of the run's context ({', '.join(str(args.lx + args.prompt_frames + 1 + w) for w in windows)} positions): "
                    f"{per[0] * 1e3:.0f} / {per[1] * 1e3:.0f} / {per[2] * 1e3:.0f} ms per step (stamped inside one call each); whole run of {total_steps} steps by Simpson's rule = {est:.1f} s. "
-                   "The oracle is a port of the reference's CPU path (1.3-1.5x faster than the unmodified reference on the build box); "
-                   "the reference itself measured 27.1 tok/s on 8 cores (BASELINE.md §2)"),
+                   "The oracle is a port of the reference's CPU path; " + reference_ratio_note(args) +
+                   "; the reference itself measured 27.1 tok/s on 8 cores (BASELINE.md §2)"),
     }
     ref_root = os.environ.get("VC_REFERENCE_ROOT", "")
     if ref_root and os.path.isfile(os.path.join(ref_root, "models", "voicecraft.py")):
@@ -146,8 +171,10 @@ def cpu_baseline(args, sd, a, x, x_lens, y):
                     pass
                 finally:
                     vc.topk_sampling = orig
-            _, rper, rest = sample(run_ref)
-            out["reference"] = {"value": round(tokens / rest, 2), "kind": "reference", "ms_per_step": [round(v * 1e3) for v in rper]}
+            rpre, rper, rest = sample(run_ref)
+            out["reference"] = {"value": round(tokens / rest, 2), "kind": "reference", "prefill_s": round(rpre, 2),
+                                "ms_per_step": [round(v * 1e3) for v in rper], "whole_run_s": round(rest, 1),
+                                "port_speed_over_reference": round((tokens / est) / (tokens / rest), 3)}
         except Exception as e:      # reporting only
             out["reference"] = {"error": str(e)}
     return out
@@ -248,8 +275,36 @@ def one_sample_block(eng, a, dev, args):
             "codec_tokens_per_sec_end_to_end": round(4 * best["gen_frames"] / best["total_s"], 1)}
 
 
+def cpu_only(args):
+    """`--cpu-baseline-only`: the CPU leg alone (no GPU, no engine).  With VC_REFERENCE_ROOT set (build container) the
+    unmodified reference is timed on the same windows; the measured ratio is also merged into
+    profiles/cpu_reference_vs_port.json, which the GPU box's bench line quotes."""
+    from voicecraft_amd import synth
+    a = synth.make_args(args.preset)
+    sd = synth.make_state_dict(a, seed=0, perturb=False, mute_eos=True, fast=True)
+    x, xl, y = synth.random_prompt(a, args.lx, args.prompt_frames, seed=1)
+    out = cpu_baseline(args, sd, a, x, xl, y)
+    key = f"{args.preset}/lx{args.lx}/t{args.prompt_frames}/k{args.top_k}"
+    print(json.dumps({"config": key, "cpu_baseline": out}), flush=True)
+    ref = out.get("reference") or {}
+    if ref.get("value"):
+        path = os.path.join(ROOT, "profiles", "cpu_reference_vs_port.json")
+        try:
+            with open(path) as f:
+                j = json.load(f)
+        except Exception:
+            j = {}
+        j[key] = {"key": key, "cores": out["cores"], "port": out["value"], "reference": ref["value"],
+                  "ratio": ref["port_speed_over_reference"], "port_ms_per_step": out["ms_per_step"], "reference_ms_per_step": ref["ms_per_step"]}
+        j.setdefault("default", key)
+        with open(path, "w") as f:
+            json.dump(j, f, indent=1, sort_keys=True)
+
+
 def main():
     args = parse()
+    if args.cpu_baseline_only:
+        return cpu_only(args)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
