@@ -197,9 +197,8 @@ def conv_flops_encode(n_samples, F=64, ratios=(8, 5, 4, 2), hidden=128, k=7, rk=
 
 def codec_block(dev):
     """EnCodec encode / decode of 16 s of audio (synthetic weights at the VoiceCraft codec shape, fp32 MFMA), SURVEY §8d
-    'report codec encode/decode separately'.  Two roofline objects: the LSTM recurrence (persistent launch: the weights
-    live in registers, a step is one hand-off round - priced against the bytes a launch-per-step form would stream) and
-    the implicit-GEMM convolutions (conv_gemm_k, fp32 MFMA) taken together."""
+    'report codec encode/decode separately'.  The implicit-GEMM convolutions (conv_gemm_k, fp32 MFMA) carry an MFMA roofline
+    object; the LSTM recurrence is reported as what bounds it (persistent launch: hand-off latency per step)."""
     from voicecraft_amd import synth
     from voicecraft_amd.codec import AudioTokenizer
     tok = AudioTokenizer(synth.make_codec_state_dict(0), device=dev, max_seconds=16.5, max_batch=1)
@@ -227,14 +226,16 @@ def codec_block(dev):
     conv_ms = max(1e-6, e_ms - lstm_ms)
     return {"audio_s": 16.0, "frames": T, "encode_ms": round(e_ms, 2), "decode_ms": round(d_ms, 2),
             "rtf_encode": round(e_ms / 16e3, 6), "rtf_decode": round(d_ms / 16e3, 6), "dtype": "f32", "parity": "unpinned (audiocraft not vendored)",
-            "roofline": {"bound": "hbm", "kernel": ("lstm_persist_k (ONE persistent launch; per recurrence step of both layers)" if persistent
-                                                    else "lstm_wave_k (one launch per recurrence step of both LSTM layers)"),
-                         "achieved": round(lstm_bytes / (step_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(lstm_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
-                         "bytes_per_launch": lstm_bytes, "avg_launch_us": round(step_us, 2),
-                         "note": ("the recurrence weights (50 MB fp32) are register-resident for the whole sequence: 'achieved' is the rate a launch-per-step "
-                                  "form would need to match this step time, not bytes moved" if persistent else
-                                  "weights are cache-resident (50 MB < 256 MB Infinity Cache): priced against HBM as the conservative bound")},
+            # the persistent LSTM keeps its weights in registers: nothing is streamed per step, so there is no HBM roofline to
+            # quote - a step IS one all-to-all hand-off of the hidden vector between the workgroups, and that latency is the bound
+            "lstm": ({"kernel": "lstm_persist_k (ONE persistent launch for the whole sequence, both layers)", "bound": "hand-off latency",
+                      "us_per_recurrence_step": round(step_us, 2), "steps": T,
+                      "note": "one {value, epoch} granule hand-off round per step; the launch-per-step form re-reads 50 MB of weights per step (8.8 us)"}
+                     if persistent else
+                     {"kernel": "lstm_wave_k (one launch per recurrence step of both LSTM layers)", "bound": "hbm",
+                      "us_per_recurrence_step": round(step_us, 2), "steps": T, "bytes_per_launch": lstm_bytes,
+                      "achieved": round(lstm_bytes / (step_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": round(lstm_bytes / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None}),
             "conv_roofline": {"bound": "mfma", "kernel": "conv_gemm_k (every implicit-GEMM convolution of one encode, fp32 MFMA)",
                               "achieved": round(conv_fl / (conv_ms * 1e-3) / 1e12, 2), "peak": MFMA_PEAK_TF["fp32"], "unit": "TFLOP/s",
                               "frac": round(conv_fl / (conv_ms * 1e-3) / 1e12 / MFMA_PEAK_TF["fp32"], 4), "traffic": None,
@@ -243,13 +244,14 @@ def codec_block(dev):
 
 
 def one_sample_block(eng, a, dev, args):
-    """The whole `inference_one_sample` chain (inference_tts_scale.py:42-105) on the bench's model: encode a 3 s synthetic
-    voice prompt, generate to the reference's length cap, decode the concatenation and the generated part.  The model's
-    special-token logits are NOT muted here (the bench checkpoint only mutes the terminator), so generated frames may
-    hold a special id once in a while; they are mapped to code 0 before the codec, which times the same work."""
+    """One whole TTS request on the bench's model (what inference_tts_scale.py:42-105 does between its phonemizer and its file
+    writer): encode a 3 s synthetic voice prompt, generate to the reference's length cap, decode prompt + generated and the
+    generated part.  The model's special-token logits are NOT muted here (the bench checkpoint only mutes the terminator), so
+    generated frames may hold a special id once in a while; they are mapped to code 0 before the codec, which times the same work."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from one_sample_chain import OneSampleChain
     from voicecraft_amd import synth
     from voicecraft_amd.codec import AudioTokenizer
-    from voicecraft_amd.pipeline import inference_one_sample
 
     class _Codes0(AudioTokenizer):
         def decode(self, frames):
@@ -261,18 +263,49 @@ def one_sample_block(eng, a, dev, args):
     text = synth.random_prompt(a, args.lx, 1, seed=1)[0][0]
     cfg = dict(top_k=args.top_k, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1, codec_sr=50,
                silence_tokens=[1388, 1898, 131], sample_batch_size=1)
+    chain = OneSampleChain(eng, tok, a.n_codebooks, dev)
     best = None
     for _ in range(3):
-        tm = {}
-        concat, gen = inference_one_sample(eng, a, text, tok, wav, dev, cfg, -1, timings=tm)
-        if best is None or tm["total_s"] < best["total_s"]:
-            best = tm
-    gen_s = best["gen_frames"] / 50.0
-    return {"prompt_frames": best["prompt_frames"], "gen_frames": best["gen_frames"], "encode_ms": round(best["encode_s"] * 1e3, 2),
-            "model_ms": round(best["model_s"] * 1e3, 2), "decode_concat_and_gen_ms": round(best["decode_s"] * 1e3, 2),
-            "total_ms": round(best["total_s"] * 1e3, 2), "rtf_end_to_end": round(best["total_s"] / gen_s, 4),
-            "rtf_model_only": round(best["model_s"] / gen_s, 4),
-            "codec_tokens_per_sec_end_to_end": round(4 * best["gen_frames"] / best["total_s"], 1)}
+        r = chain.run(text, wav, cfg)
+        if best is None or r.seconds["total"] < best.seconds["total"]:
+            best = r
+    gen_frames = int(best.new_codes.shape[-1])
+    gen_s, sec = gen_frames / 50.0, best.seconds
+    return {"prompt_frames": int(best.prompt_codes.shape[1]), "gen_frames": gen_frames, "encode_ms": round(sec["encode"] * 1e3, 2),
+            "model_ms": round(sec["model"] * 1e3, 2), "decode_concat_and_gen_ms": round(sec["decode"] * 1e3, 2),
+            "total_ms": round(sec["total"] * 1e3, 2), "rtf_end_to_end": round(sec["total"] / gen_s, 4),
+            "rtf_model_only": round(sec["model"] / gen_s, 4),
+            "codec_tokens_per_sec_end_to_end": round(4 * gen_frames / sec["total"], 1)}
+
+
+def ab_block(eng, one_step, spec, pairs):
+    """In-process A/B of ONE engine option (vc_set_option): the same engine, the same process, the same box.  Whole calls
+    are timed in interleaved pairs (A B, B A, A B ...: drift cancels), each arm's captured graph already warm; the figure
+    compared is the device-timed decode loop per step taken.  `median_delta_pct` = median over pairs of (B - A) / A;
+    `spread_pct` = half the range of those per-pair deltas (the noise a single pair carries).  An option only earns a
+    default when |median_delta_pct| > spread_pct in a driver-run line."""
+    knob, vals = spec.split("=", 1)
+    va, vb = vals.split(":", 1)
+
+    def timed(v, seed):
+        eng.set_option(knob, v)
+        one_step(seed)
+        return eng.last_timing_ms()["decode_ms"] / max(1, eng.last_steps)
+    for v in (va, vb, va, vb):        # capture + warm both states
+        timed(v, 7)
+    a_ms, b_ms, deltas = [], [], []
+    for i in range(pairs):
+        order = (va, vb) if i % 2 == 0 else (vb, va)
+        t = {v: timed(v, 2000 + i) for v in order}
+        a_ms.append(t[va]); b_ms.append(t[vb])
+        deltas.append((t[vb] - t[va]) / t[va] * 100.0)
+    eng.set_option(knob, vb)
+    med = lambda xs: sorted(xs)[len(xs) // 2]
+    return {"knob": knob, "A": va, "B": vb, "pairs": pairs, "metric": "decode ms per step taken (device events around the loop)",
+            "A_ms_median": round(med(a_ms), 5), "B_ms_median": round(med(b_ms), 5),
+            "median_delta_pct": round(med(deltas), 3), "spread_pct": round((max(deltas) - min(deltas)) / 2.0, 3),
+            "deltas_pct": [round(d, 3) for d in deltas],
+            "verdict": ("B faster" if med(deltas) < 0 else "B slower") + (" beyond the spread" if abs(med(deltas)) > (max(deltas) - min(deltas)) / 2.0 else " (inside the spread: not shown)")}
 
 
 def cpu_only(args):
@@ -308,17 +341,24 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # VC_RANKS_SHARE_DEVICE=1: every rank drives cuda:0 (the single-GPU test of this N > 1 code path; RCCL refuses two ranks on
+    # one device, so that run takes --dist-backend gloo).  The job is otherwise identical: sharding, barriers, reductions, gather.
+    share = os.environ.get("VC_RANKS_SHARE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if share else local_rank)
+    torch.cuda.set_device(dev)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            assert not share, "RCCL needs one GPU per rank: use --dist-backend gloo with VC_RANKS_SHARE_DEVICE=1"
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
     else:
         dist = None
+    cdev = dev if (dist is None or args.dist_backend == "nccl") else torch.device("cpu")      # where the reductions' tensors live
     n_gpus = world
     assert args.gpus == n_gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    dev = torch.device("cuda", local_rank)
-    torch.cuda.set_device(dev)
 
     from voicecraft_amd import dist as vdist
     from voicecraft_amd import synth
@@ -385,10 +425,10 @@ def main():
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if dist is not None:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        tot = torch.tensor([tokens], dtype=torch.int64, device=dev)
+        tot = torch.tensor([tokens], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         tokens = int(tot.item())
 
@@ -433,7 +473,9 @@ def main():
         mfma["at_run_rows"] = mfma_obj("pf_ffn1", own_rows, f"rows_gemm_blk_k<ReLU> (prefill FFN up-projection, this run's {own_rows}-row pass)")
         mfma["at_2048_rows"] = mfma_obj("pf_ffn1", 2048, "rows_gemm_big_k<ReLU> (prefill FFN up-projection, a 2048-row stream: 256 x 256 tiles, LDS-DMA)")
         mfma["attention"] = mfma_obj("pf_attn", 512, "tile_attn_k (prefill attention, 512 causal rows of one sequence, all heads)")
-        dec_step_ms = dec_ms / max(1, steps_launched or steps_run)     # the timed region covers every LAUNCHED step (graph-rounded)
+        # per step TAKEN: the timed region also covers the (graph-rounded) tail of replayed no-op steps after the last sequence
+        # retired, so this slightly OVERstates the step (never understates it); the launched count is kept as an annotation
+        dec_step_ms = dec_ms / max(1, steps_run)
         out = {
             "metric": "codec_tokens_per_sec", "value": round(value, 1), "unit": "codec-tokens/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
@@ -452,18 +494,19 @@ def main():
             "roofline": roof, "kernels": kernels,
         }
         out["prefill_roofline"] = mfma
-        # extra workgroups of latency-bound launches that pull the next matrices' tiles into the right L2s (DESIGN.md 4.2 d/e):
-        # additional work inside the timed region, nothing skipped; the switches that were in force
-        out["config"]["piggyback_prefetch"] = {"attention_launch": os.environ.get("VC_ATTN_PF", "8,0,32 (default)"),
-                                               "layernorm_launches": os.environ.get("VC_LN_PF", "248,24,24 (default)")}
+        # launch-shape options in force (prefetch roles of latency-bound launches, finished-row form, ...): additional work
+        # inside the timed region where they add any, nothing skipped
+        out["config"]["engine_options"] = eng.options()
         if dist is not None:
             out["collective"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "op": "all_gather of int32 [B,K,T+1] token blocks",
-                                 "gather_ms": round(gather_s[0] / args.steps * 1e3, 3)}
+                                 "gather_ms": round(gather_s[0] / args.steps * 1e3, 3), "ranks_share_one_device": share}
         if n_gpus == 1 and B == 1 and not edit and not args.no_codec:
             try:
                 out["one_sample"] = one_sample_block(eng, a, dev, args)
             except Exception as e:   # reporting only
                 out["one_sample"] = {"error": str(e)}
+        if n_gpus == 1 and args.ab:
+            out["ab"] = ab_block(eng, one_step, args.ab, max(3, args.ab_pairs))
         if n_gpus == 1 and not args.no_codec:
             try:
                 out["codec"] = codec_block(dev)

@@ -93,6 +93,16 @@ void vc_destroy(vc_engine* e);
 const char* vc_last_error(const vc_engine* e); /* e may be NULL: last vc_create error */
 const char* vc_version(void);
 
+/* Run-time options of a finalized engine: launch-shape knobs of the decode step, the same ones the VC_* environment
+ * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  name / value:
+ *   "attn_pf"      "slices[,out-proj KB[,FFN-up KB]]"   prefetch role of the one-row attention launch, 0 = off
+ *   "ln_pf"        "workgroups[,QKV KB[,FFN-up KB]]"    prefetch role of the LayerNorm launches of several-row steps, 0 = off
+ *   "graph_steps"  decode steps captured per hipGraph;  "ln_split_rows", "attn_blocks", "attn_blocks1", "nt", "prefill_rows",
+ *   "finished_rows" (rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs, 0 = off)
+ * Results never depend on an option (tests/test_gpu_options.py).  Captured decode graphs are kept per option state, so an
+ * in-process A/B (bench.py --ab) pays for capture once per state.  Unknown names / malformed values: VC_EINVAL. */
+int vc_set_option(vc_engine* e, const char* name, const char* value);
+
 /* ---- weights: replaces get_model()/load_state_dict (inference_tts_scale.py:107-125).
  * `key` is the reference state_dict key; data is fp32 (or int64 for
  * eog/eos, ignored).  `on_device` tells whether `data` is a host or device pointer.

@@ -1,0 +1,105 @@
+"""-m gpu: run-time options (vc_set_option) never change results, and the finished-row form of several-row decode steps
+(2..8 rows in bf16, 2..4 in the exact fp32 mode: out-projection / FFN-down own whole rows on 8-channel tiles, QKV / FFN-up /
+heads fold the LayerNorm of finished rows one wave per row - no split-K slabs, no LayerNorm launch) against the oracle,
+with the launch census telling which form ran."""
+import numpy as np
+import pytest
+import torch
+
+from test_gpu_model import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+def _delta(after, before):
+    return {k: after[k] - before[k] for k in after}
+
+
+def _oracle_traces(a, sd, prompts):
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    orc = VoiceCraftOracle(a, sd)
+    traces, want_res = [], []
+    for (xx, xl, yy) in prompts:
+        tr = []
+        want_res.append(orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3, trace=tr)[0].numpy())
+        traces.append(tr)
+    return traces, want_res
+
+
+@pytest.mark.parametrize("preset,B", [("tiny_h16", 2), ("tiny_h16", 3), ("tiny_h16", 5), ("tiny_h16", 8), ("tiny128", 4), ("tiny128", 7), ("tiny", 8)])
+def test_finished_row_form_bf16_per_sequence_logits(preset, B):
+    """Every sequence of a ragged batch teacher-forced on its own oracle trajectory: per-step head logits within 2e-2 of the
+    fp32 oracle in the finished-row form (census: rows_gemm_fr launches, no LayerNorm launch in the decode steps), and again
+    with the form switched off at run time (census: none) - head_dim 32 / 128 / 64, attention merges of 8 / 4 / 2 partials."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args(preset)
+    sd = synth.make_state_dict(a, seed=4)
+    prompts = [synth.random_prompt(a, 4 + (u % 5), 9 + 3 * (u % 7), seed=300 + u) for u in range(B)]
+    traces, want_res = _oracle_traces(a, sd, prompts)
+    n = max(len(t) for t in traces)
+    forced = np.zeros((n, B, 4), dtype=np.int64)
+    for b, tr in enumerate(traces):
+        forced[: len(tr), b] = torch.stack([t["tokens"] for t in tr]).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256, use_graph=False)
+    L = a.num_decoder_layers
+    got = {}
+    for mode in ("on", "off"):
+        eng.set_option("finished_rows", 8 if mode == "on" else 0)
+        assert ("fr8" if mode == "on" else "fr0") in eng.options()
+        c0 = eng.launch_counts()
+        outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3,
+                                           _forced=forced, _logit_steps=n)
+        c = _delta(eng.launch_counts(), c0)
+        if mode == "on":
+            assert c["rows_gemm_fr"] >= 2 * L * (n - 1), c           # (the first of the n samples comes from the prefill's logits)
+        else:
+            assert c["rows_gemm_fr"] == 0 and (B < 3 or c["ln_rows"] >= 2 * L * (n - 1)), c
+        lg = lg.cpu().numpy()
+        worst = 0.0
+        for b, tr in enumerate(traces):
+            assert np.array_equal(outs[b][0].cpu().numpy(), want_res[b])
+            want = torch.stack([t["logits"][0] for t in tr]).numpy()
+            worst = max(worst, float(rel_l2(lg[: len(tr), b], want).max()))
+        assert worst <= 2e-2, (mode, worst)
+        got[mode] = lg
+    assert np.abs(got["on"] - got["off"])[np.abs(got["off"]) < 1e3].max() < 0.25      # two roundings of the same numbers
+
+
+@pytest.mark.parametrize("preset,B", [("tiny_h16", 2), ("tiny_h16", 4), ("tiny128", 3)])
+def test_finished_row_form_fp32_tokens_equal_the_oracle(preset, B):
+    """Exact mode: greedy FREE-running tokens of every utterance equal the oracle's, on the captured graph (2..4 rows take the
+    finished-row form there: X of the FFN down-projection is 4 x 4d fp32 values)."""
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args(preset)
+    sd = synth.make_state_dict(a, seed=4)
+    prompts = [synth.random_prompt(a, 4 + (u % 5), 9 + 3 * (u % 7), seed=300 + u) for u in range(B)]
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=B, max_positions=256)
+    c0 = eng.launch_counts()
+    outs = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3)
+    assert _delta(eng.launch_counts(), c0)["rows_gemm_fr"] > 0
+    orc = VoiceCraftOracle(a, sd)
+    for (xx, xl, yy), (res, gen) in zip(prompts, outs):
+        want = orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3)[0].numpy()
+        assert np.array_equal(res.cpu().numpy(), want)
+
+
+def test_options_do_not_change_tokens_and_bad_options_are_refused():
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args("tiny128")
+    sd = synth.make_state_dict(a, seed=3)
+    x, xl, y = synth.random_prompt(a, 6, 21, seed=11)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=2, max_positions=256)
+    base = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
+    for name, value in [("attn_pf", "0"), ("attn_pf", "8,0,32"), ("attn_pf", "4,16,16"), ("graph_steps", "3"), ("attn_blocks1", "64"),
+                        ("nt", "0"), ("ln_split_rows", "2"), ("graph_steps", "8")]:
+        eng.set_option(name, value)
+        got = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
+        assert np.array_equal(got, base), (name, value)
+    with pytest.raises(AssertionError):
+        eng.set_option("no_such_option", "1")
+    with pytest.raises(AssertionError):
+        eng.set_option("attn_pf", "many")

@@ -1,6 +1,7 @@
-"""-m gpu: the whole `inference_one_sample` chain (inference_tts_scale.py:42-105) on the engine - AudioTokenizer.encode ->
-VoiceCraftEngine.inference_tts / inference_tts_batch -> AudioTokenizer.decode of the concatenation and of the generated
-part - with integer phoneme ids and a synthetic waveform in place of the phonemizer / file loader (out of scope)."""
+"""-m gpu: the engine stages of one TTS request chained (what `inference_tts_scale.inference_one_sample`, :42-105, does between
+its phonemizer and its file writer) - AudioTokenizer.encode -> VoiceCraftEngine.inference_tts / inference_tts_batch ->
+AudioTokenizer.decode of prompt + generated and of the generated part - through tests/one_sample_chain.py, with integer
+phoneme ids and a synthetic waveform in place of the two front-ends (out of scope)."""
 import numpy as np
 import pytest
 import torch
@@ -29,16 +30,17 @@ def test_one_sample_chain_equals_its_three_stages_and_the_oracle(parts):
     equal the CPU oracle on the SAME encoded prompt (fp32, greedy), and the lengths must follow the reference's
     identities (voicecraft.py:1146-1147: concat = prompt + generated; 320 samples per frame)."""
     from oracle.voicecraft_oracle import VoiceCraftOracle
-    from voicecraft_amd.pipeline import inference_one_sample
+    from one_sample_chain import OneSampleChain
     a, sd, eng, tok = parts
     torch.manual_seed(0)
     wav = torch.randn(1, 16000 * 3 + 123) * 0.1                 # 3 s + a ragged tail; the prompt is the first 2 s
     text = np.random.RandomState(1).randint(0, 100, size=(12,))
-    timings = {}
-    concat, gen = inference_one_sample(eng, a, text, tok, wav, "cuda:0", CFG, prompt_end_frame=32000, timings=timings)
+    out = OneSampleChain(eng, tok, a.n_codebooks, "cuda:0").run(text, wav, CFG, n_prompt_samples=32000)
+    concat, gen = out.wave_all, out.wave_new
     T = 100                                                      # 32000 samples / 320
-    assert timings["prompt_frames"] == T and timings["gen_frames"] == 12 * 10 - T      # the length cap (10 frames per phoneme)
-    Tg = timings["gen_frames"]
+    assert out.prompt_codes.shape[1] == T and out.new_codes.shape[-1] == 12 * 10 - T   # the length cap (10 frames per phoneme)
+    assert set(out.seconds) == {"encode", "model", "decode", "total"}
+    Tg = int(out.new_codes.shape[-1])
     assert concat.shape == (1, 1, 320 * (T + Tg)) and gen.shape == (1, 1, 320 * Tg)
     assert torch.isfinite(concat).all() and torch.isfinite(gen).all()
     # stage by stage
@@ -54,10 +56,11 @@ def test_one_sample_chain_equals_its_three_stages_and_the_oracle(parts):
 
 
 def test_one_sample_chain_best_of_n(parts):
-    from voicecraft_amd.pipeline import inference_one_sample
+    from one_sample_chain import OneSampleChain
     a, sd, eng, tok = parts
     torch.manual_seed(1)
     wav = torch.randn(16000 * 2) * 0.1
     cfg = dict(CFG, top_k=40, sample_batch_size=3, silence_tokens=[1388, 1898, 131])
-    concat, gen = inference_one_sample(eng, a, torch.arange(15), tok, wav, "cuda:0", cfg, prompt_end_frame=-1)
+    out = OneSampleChain(eng, tok, a.n_codebooks, "cuda:0").run(torch.arange(15), wav, cfg)
+    concat, gen = out.wave_all, out.wave_new
     assert concat.shape[-1] - gen.shape[-1] == 32000 and gen.shape[-1] % 320 == 0 and gen.shape[-1] > 0

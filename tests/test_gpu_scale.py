@@ -77,7 +77,8 @@ def test_c4_editing_shape_792_row_prefill(giga):
 
 def test_c5_share_eight_utterances_one_prefill_stream(giga):
     """BASELINE config 5's per-GPU share: 8 x (Lx 80, 150 frames) prefilled as ONE row stream (8 x 240 = 1 920 rows in a
-    single pass: QKV / FFN-up / FFN-down on the 256 x 256 LDS-DMA GEMM) and decoded 8 rows per step for 654 steps; per-sequence bf16 logits at step 0 for every sequence and at
+    single pass: QKV / FFN-up / FFN-down on the 256 x 256 LDS-DMA GEMM) and decoded 8 rows per step for 654 steps (finished-row
+    form: out-projection / FFN-down on 8-channel tiles over K = 2048 / 8192, 128 KB of X in LDS); per-sequence bf16 logits at step 0 for every sequence and at
     steps 300 / 653 for sequences 0, 3 and 7 (each an 884-position one-pass oracle evaluation)."""
     from voicecraft_amd import synth
     from voicecraft_amd.engine import VoiceCraftEngine
@@ -93,6 +94,7 @@ def test_c5_share_eight_utterances_one_prefill_stream(giga):
     L = a.num_decoder_layers
     assert c["big256"] == 3 * L and c["blk128_sbs"] == L and c["tile_attn"] == L, c   # one 1 920-row pass; the out-projection stays on 128 x 128
     assert c["rows_gemm"] > 0 and c["mt2"] + c["mt4"] == 0, c                 # 8-row decode: the rows-GEMM, not the wide form
+    assert c["rows_gemm_fr"] > 0 and c["ln_rows"] == 2 * L, c                 # ... in the finished-row form: the only LayerNorm launches are the prefill pass's
     lg = lg.cpu().numpy()
     worst = {}
     for u in range(B):
@@ -127,3 +129,108 @@ def test_thirty_two_row_decode_on_the_weight_stationary_kernel(giga):
         worst = max(worst, float(rel_l2(lg[steps, u], want).max()))
         assert outs[u][1].shape[2] == n - a.n_codebooks
     assert worst <= 2e-2, worst
+
+
+# ------------------------------------------------------------------------------------------ giga330M (BASELINE configs 1 and 2)
+# d = 1024, 16 heads of 64, 24 layers (the shape SURVEY.md §8 assumes for the 330M checkpoint).  make_plan picks other
+# launch shapes from d than at d = 2048 (FFN-down split-K 4 over 64 tiles, out-projection unsplit, k-tiles per wave 8 / 16),
+# head_dim 64 spreads a cached row over 8 lanes, and the 8-sequence decode takes the finished-row form at K = 4096.
+@pytest.fixture(scope="module")
+def giga330():
+    from oracle.voicecraft_oracle import VoiceCraftOracle
+    from voicecraft_amd import synth
+    a = synth.make_args("giga330M")
+    sd = synth.make_state_dict(a, seed=0, fast=True)
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
+    return a, sd, VoiceCraftOracle(a, sd)
+
+
+def test_c2_giga330M_16s_decode_bf16_and_fp32_first_step(giga330):
+    """BASELINE config 2 (giga330M, batch 1, Lx 80, 150 -> 650 frames, the bench's `--preset giga330M` workload): bf16
+    teacher-forced head logits at the first / middle / last decode step (231 / 531 / 884 cached positions) against the oracle's
+    one-pass evaluation, on the captured graph; then the first step in fp32 (<= 1e-3, same arg-max)."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga330
+    x, xl, y = synth.random_prompt(a, 80, 150, seed=1)
+    n = 654
+    toks = forced_trajectory(a, n, seed=12, term=a.eos)
+    steps = [0, 300, n - 1]
+    want = orc.tts_logits_for_trajectory(x, y, toks, steps=steps).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024)
+    c0 = eng.launch_counts()
+    res, gen, lg = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, stop_repetition=3, _forced=toks, _logit_steps=n)
+    c = delta(eng.launch_counts(), c0)
+    L = a.num_decoder_layers
+    assert gen.shape == (1, a.n_codebooks, 650)
+    assert c["rows_gemm"] >= 4 * L + 2 and c["rows_attn"] >= L and c["mt2"] + c["mt4"] + c["rows_gemm_fr"] == 0, c   # (a captured graph launches nothing the census sees)
+    assert c["blk64"] + c["blk128_sbs"] == 4 * L and c["tile_attn"] == L, c           # the 240-row prefill pass
+    rel = rel_l2(lg.cpu().numpy()[steps], want)
+    assert rel.max() <= 2e-2, dict(zip(steps, rel.tolist()))
+    del eng
+    e32 = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=1, max_positions=1024)
+    _, _, lg32 = e32.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, stop_repetition=3, _forced=toks[:8], _logit_steps=1)
+    got = lg32.cpu().numpy()[0]
+    live = np.abs(want[0]) < 1e3
+    assert np.abs((got - want[0]) * live).max() <= 1e-3, float(np.abs((got - want[0]) * live).max())
+    assert np.array_equal(np.where(live, got, -1e9).argmax(-1), np.where(live, want[0], -1e9).argmax(-1))
+
+
+def test_c1_giga330M_greedy_free_running_equals_the_oracle_fp32(giga330):
+    """BASELINE config 1 (the reference's CPU-runnable case: giga330M, greedy, 3 s prompt -> 5 s, Lx 40, 150 -> 250 frames):
+    the engine in exact mode, FREE-running, must produce the oracle's token ids for all 254 steps - graph and eager."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga330
+    x, xl, y = synth.random_prompt(a, 40, 150, seed=1)
+    want_res, want_gen = orc.inference_tts(x, xl, y, top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1)
+    assert want_gen.shape == (1, a.n_codebooks, 250)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=1, max_positions=512)
+    for graph in (True, False):
+        eng.use_graph = graph
+        res, gen = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1)
+        assert eng.last_steps == 254
+        assert np.array_equal(res.cpu().numpy(), want_res.numpy()), graph
+
+
+def test_giga330M_eight_utterances_and_a_576_row_editing_prefill(giga330):
+    """d = 1024 on the several-row paths: (a) 8 utterances decoded together (one 1 920-row prefill stream, then 8-row
+    decode steps in the finished-row form: out-projection / FFN-down on 8-channel tiles over K = 1024 / 4096) with
+    per-sequence bf16 logits; (b) an editing call whose rearranged prompt is one 576-row pass."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga330
+    L, K = a.num_decoder_layers, a.n_codebooks
+    B, n = 8, 60
+    prompts = [synth.random_prompt(a, 80, 150, seed=1 + u) for u in range(B)]
+    forced = np.stack([forced_trajectory(a, n, seed=70 + u, term=a.eos) for u in range(B)], axis=1)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=1024, use_graph=False)
+    c0 = eng.launch_counts()
+    outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
+                                       _forced=forced, _logit_steps=n)
+    c = delta(eng.launch_counts(), c0)
+    assert c["rows_gemm_fr"] >= 2 * L * (n - 1) and c["tile_attn"] == L, c    # eager: every decode launch is counted
+    lg = lg.cpu().numpy()
+    worst = {}
+    for u in (0, 3, 7):
+        steps = [0, 30, n - 1]
+        want = orc.tts_logits_for_trajectory(prompts[u][0], prompts[u][2], forced[:, u], steps=steps).numpy()
+        worst[u] = float(rel_l2(lg[steps, u], want).max())
+        assert outs[u][1].shape == (1, K, n - K)
+    assert max(worst.values()) <= 2e-2, worst
+    del eng
+    # (b) editing: Lx 60, 600-frame utterance, span [200,300): 60 + 500 + 2 (K + 1) + 2 + 1 = 573 rows -> one 576-row pass
+    x, xl, y = synth.random_prompt(a, 60, 600, seed=3)
+    mi = torch.tensor([[[200, 300]]], dtype=torch.int64)
+    n = 40
+    toks = forced_trajectory(a, n, seed=5, term=a.eog)
+    steps = [0, 20, n - 1]
+    want = orc.edit_logits_for_trajectory(x, y, mi, toks, steps=steps).numpy()
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024)
+    c0 = eng.launch_counts()
+    res, lg = eng.inference(x.cuda(), xl.cuda(), y.cuda(), mi, top_k=40, _forced=toks, _logit_steps=n)
+    c = delta(eng.launch_counts(), c0)
+    assert c["blk64"] + c["blk128_sbs"] + c["big256"] == 4 * L and c["tile_attn"] == L and c["ln_rows"] == 2 * L, c
+    assert res.shape == (1, K, 600 - 100 + (n - K))
+    rel = rel_l2(lg.cpu().numpy()[steps], want)
+    assert rel.max() <= 2e-2, dict(zip(steps, rel.tolist()))

@@ -35,6 +35,7 @@ PROTOTYPES = {
     "vc_destroy": (None, [C.c_void_p]),
     "vc_last_error": (C.c_char_p, [C.c_void_p]),
     "vc_version": (C.c_char_p, []),
+    "vc_set_option": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "vc_load_tensor": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int64), C.c_int]),
     "vc_finalize_weights": (C.c_int, [C.c_void_p, C.c_int]),
     "vc_tts": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.POINTER(SampleCfg), C.c_int,

@@ -187,8 +187,11 @@ struct SeqState {
 };
 
 // ---------------------------------------------------------------- kernel argument blocks
-enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2 };
-enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4 };
+enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2, PRO_LNW = 3 };      // PRO_LNW: LayerNorm fold of 2..8 FINISHED rows, one wave per row
+enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4, EPI_RES = 5 };   // EPI_RES: h_out = h_in + bias + W x (whole rows)
+#define VC_TH_RES 8         // output channels per weight tile of the finished-row producers (rows_gemm_fr_k): d/8 workgroups
+#define VC_FR_WAVES 8       // waves of a finished-row producer workgroup (each streams K/8 of its 8 channels in ONE burst)
+#define VC_FR_MAX_ROWS 8    // rows a finished-row pass may carry (X of the FFN down-projection: rows x 4d elements in LDS)
 
 // ---------------------------------------------------------------- piggyback weight prefetch
 // A launch that leaves HBM idle (the one-row attention launch, the per-row LayerNorm launches of a several-row step) carries
@@ -282,8 +285,6 @@ struct GemmArgs {
   float* part_out;          // PART: [ksplit][rows_cap][N]
   void* x_out;              // ln_rows_k: normalised rows, WT [rows][d]
   long long* dbg_ts;        // shader-clock stamps (diagnostic builds with -DVC_KERNEL_TS only)
-  unsigned* progress;       // optional (decode steps): the launch stores progress_val here when it starts - the pace the weight
-  unsigned progress_val;    // prefetcher follows (vc_stream.hip); progress_val = index of this launch's matrix in the step, + 1
   PfSeg pf;                 // ln_rows_k only: pf_blocks extra workgroups prefetch the head of this matrix's tiles (vc_prefetch_tiles); 0 = none
   int pf_blocks;
 };
@@ -404,12 +405,14 @@ hipError_t vc_launch_fold_vecs(const float* W, const float* gamma, const float* 
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s);
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
+hipError_t vc_launch_gemm_fr(const GemmArgs& a, int dtype, int pro, hipStream_t s);   // finished-row producers (vc_gemm.hip)
+size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype);
 extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production
 // Launch census (process-wide, host side): which kernel FORM each launcher picked.  Read through
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one
 // they compared with the oracle.
 enum { VC_LC_ROWS_GEMM = 0, VC_LC_MT2 = 1, VC_LC_MT4 = 2, VC_LC_BLK64 = 3, VC_LC_BLK128_SBS = 4, VC_LC_BLK128_2X2 = 5,
-       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_PERSIST = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_N = 16 };
+       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_N = 16 };
 extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);

@@ -18,7 +18,6 @@
 #include <vector>
 
 #include "vc_common.h"
-#include "vc_stream.h"
 
 namespace {
 
@@ -32,6 +31,7 @@ struct RawTensor {
 
 struct Layer {
   uint4 *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;
+  uint4 *Wo8 = nullptr, *W28 = nullptr;                                 // Wo / W2 once more in 8-channel tiles (finished-row producers, vc_gemm.hip)
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;   // bqkv / b1 hold the FOLDED biases (W beta + b)
   float *wg_qkv = nullptr, *wg_1 = nullptr;                             // row sums of the folded weights W . gamma
   void *kc = nullptr, *vc = nullptr;   // KV cache of this layer: WT [max_seqs][H][S_max][hd]
@@ -82,7 +82,9 @@ struct vc_engine {
   int *h_flag = nullptr;                // [0] error/poll word, [1] staging, [8] "sequences still active" written by the device
   SampleDyn *h_dyn = nullptr, *d_dyn = nullptr;   // per-call sampler values (vc_common.h)
   // captured decode steps, kept across calls: key = (sequences, rows per sequence, best-of-N)
-  std::map<std::tuple<int, int, int>, hipGraphExec_t> graphs;
+  // ... and by the option state they were captured under (vc_set_option): toggling an option back and forth reuses the captures
+  std::map<std::pair<std::tuple<int, int, int>, std::string>, hipGraphExec_t> graphs;
+  std::string opt_state;                // canonical text of every option that shapes a decode step
   int steps_per_graph = 8;              // VC_GRAPH_STEPS: decode steps captured into one graph launch
   hipEvent_t ev_pace[2]{};
 
@@ -99,30 +101,15 @@ struct vc_engine {
   // the 5 us the 25 MB take), the first 24 KB of every tile gain 1-2 % (0.857-0.863 -> 0.844).
   int lpf_blocks = 248, lpf_qkv_kb = 24, lpf_w1_kb = 24;
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
+  // finished-row form of decode passes of 2..fr_rows rows (forward_rows_fr): 0 = off.  VC_FINISHED_ROWS / option "finished_rows"
+  int fr_rows = VC_FR_MAX_ROWS;
+  int attn_blocks_multi = 512, attn_blocks_one = 256;   // VC_ATTN_BLOCKS / VC_ATTN_BLOCKS1: attention workgroups aimed at (several rows / one row)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
   float ms[3]{0, 0, 0};
   double host_ms[8]{};                  // host wall clock of the last call's phases (vc_debug_read "host_ms")
   double bytes_total = 0;               // HBM bytes owned by the engine
-  // stream engine (vc_stream.hip): the batch-1 decode step as one persistent launch; off unless VC_STREAM=1 and the
-  // model / device fit it (finalize)
-  bool stream_on = false;
-  int sG = 0;                           // workgroups = d / 8
-  uint4* sW = nullptr;                  // stream-layout weights [L][G][spl][16 KB]
-  StreamLayerDev* sLayers = nullptr;    // device table
-  unsigned long long* sGran = nullptr;  // granule arena
-  unsigned* sCtl = nullptr;             // [0] epoch, [1] error
-  long long* sTs = nullptr;             // VC_STREAM_DBG=1: [3][L][16] phase stamps
-  float* sDbg = nullptr;                // VC_STREAM_DBG=1: [L][5][4d] inputs of every op as the kernel saw them
-  bool heads_finished_h = false;        // run_heads16: hB holds the finished residual (no slabs, no pending bias)
-  // weight prefetcher of the launch path (weight_prefetch_k): one persistent side-stream launch per call (VC_PREFETCH=<matrices ahead>, default off)
-  int pf_ahead = 0;                     // 0 = off; else matrices it may run ahead of the decode launches
-  hipStream_t pf_stream = nullptr;
-  hipEvent_t pf_ev = nullptr;
-  PrefetchSeg* pf_segs = nullptr;
-  unsigned* pf_prog = nullptr;
-  bool pf_running = false;
-  int pf_G = 0;
+  bool finished_rows_h = false;         // run_heads16: hB holds the finished residual (no slabs, no pending bias)
   // training objective (vc_eval_forward), allocated on first use
   int *ce_tgt = nullptr, *ce_hit = nullptr;
   float *ce_nll = nullptr;
@@ -274,22 +261,93 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
-  g.progress = (rs.n_active != nullptr && e->pf_ahead > 0 && rs.n_rows <= VC_ROWS) ? e->pf_prog : nullptr;   // decode steps pace the prefetcher
   return g;
 }
 
 int attn_nsplit(vc_engine* e, int rows) {
   // 8-wave blocks: one decode row is covered by ~256 of them; several rows get ~512 (two per CU), which
   // halves the positions each block walks while the merge in the out-projection stays <= 4 partials
-  static const int blocks_multi = getenv("VC_ATTN_BLOCKS") ? atoi(getenv("VC_ATTN_BLOCKS")) : 512;
-  static const int blocks_one = getenv("VC_ATTN_BLOCKS1") ? atoi(getenv("VC_ATTN_BLOCKS1")) : 256;   // sweep knob: fewer splits = a cheaper merge in the out-projection
-  int ns = (rows > 1 ? blocks_multi : blocks_one) / std::max(1, rows * e->H);
+  int ns = (rows > 1 ? e->attn_blocks_multi : e->attn_blocks_one) / std::max(1, rows * e->H);   // (fewer splits = a cheaper merge in the out-projection)
   return std::max(1, std::min(ns, VC_MAX_NSPLIT));
+}
+
+// Rows a pass may carry in the finished-row form: X of the FFN down-projection (rows x 4d elements) has to fit the LDS
+// of one workgroup, and the out-projection merges rows x nsplit <= 16 attention partials per thread in one batch.
+int fr_max_rows(const vc_engine* e) {
+  int r = std::min(e->fr_rows, VC_FR_MAX_ROWS);
+  while (r >= 2 && vc_gemm_fr_lds_bytes(r, 4 * e->d, e->dtype) > 150 * 1024) --r;
+  return r >= 2 ? r : 0;
+}
+int fr_nsplit(vc_engine* e, int rows) {
+  int ns = std::min(attn_nsplit(e, rows), 16 / rows);
+  int p = 1;
+  while (p * 2 <= ns) p *= 2;
+  return std::max(2, p);
+}
+
+// The same pass in the finished-row form (2..fr_max_rows rows): five launches per layer, no split-K slabs, no LayerNorm
+// launch.  The residual stream is a whole row at every launch boundary: QKV and FFN-up fold the LayerNorm of finished rows
+// (PRO_LNW, one wave per row), the out-projection and the FFN down-projection own 8 output channels over the whole K and
+// add residual + bias in their epilogue (rows_gemm_fr_k).  Leaves the finished rows in hB.
+int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
+  const int d = e->d;
+  for (int l = 0; l < e->L; ++l) {
+    Layer& ly = e->layers[l];
+    const float* h_res = (l == 0) ? rs.h_in : e->hB;      // residual entering the layer
+    {  // q,k,v = Wqkv LN1(h) + b ; K/V go straight into the cache
+      GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
+      g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.wg = ly.wg_qkv;
+      g.h_in = h_res;
+      g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
+    }
+    {
+      AttnArgs a;
+      memset(&a, 0, sizeof a);
+      a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc;
+      a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit;
+      a.scale = 1.0f / sqrtf((float)e->hd);
+      a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
+      a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
+      a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
+      HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
+    }
+    {  // h' = h + bo + Wo merge(attention partials of all heads)
+      GemmArgs g = base_args(e, rs, e->p_o, d, d);
+      g.Wp = ly.Wo8; g.bias = ly.bo;
+      g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
+      g.h_in = h_res; g.h_out = e->hA;
+      HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s));
+    }
+    {  // a = relu(W1 LN2(h') + b1)
+      GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
+      g.Wp = ly.W1; g.bias = ly.b1; g.wg = ly.wg_1;
+      g.h_in = e->hA;
+      g.out = e->act; g.out_ld = 4 * d;
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
+    }
+    {  // h'' = h' + b2 + W2 a
+      GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
+      g.Wp = ly.W28; g.bias = ly.b2;
+      g.x_in = e->act; g.x_ld = 4 * d;
+      g.h_in = e->hA; g.h_out = e->hB;
+      HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
+    }
+  }
+  return VC_OK;
 }
 
 // One pass of up to 16 rows through every layer (decode step, 3-row span switch, short prompts).
 int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
+  e->finished_rows_h = false;
+  if (rs.n_rows >= 2 && rs.n_rows <= fr_max_rows(e)) {
+    RowSrc fr = rs;
+    fr.nsplit = fr_nsplit(e, rs.n_rows);
+    e->finished_rows_h = true;            // tells run_heads16 (the caller's next step) that hB holds finished rows
+    return forward_rows_fr(e, fr, s);
+  }
   // The in-GEMM LayerNorm prologue walks the rows one after the other (each a dependent round trip
   // in every one of the 384-512 workgroups): from ln_split_rows rows on, a per-row LayerNorm launch
   // plus the plain prologue is cheaper (measured: 8 rows 20 us -> ~12 us per GEMM).
@@ -307,7 +365,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.has_prev_bias = (l == 0) ? 0 : 1;
       g.wg = ly.wg_qkv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      g.progress_val = 4 * l + 1;
       if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
         if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_qkv.n_tiles % 8 == 0) {
@@ -349,7 +406,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wo;
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
-      g.progress_val = 4 * l + 2;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
@@ -359,7 +415,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.wg = ly.wg_1;
       g.out = e->act; g.out_ld = 4 * d;
-      g.progress_val = 4 * l + 3;
       if (split_ln) {
         g.x_out = e->xn;
         if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_f1.n_tiles % 8 == 0) {
@@ -380,7 +435,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.W2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.part_out = e->parts;
-      g.progress_val = 4 * l + 4;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     }
   }
@@ -398,11 +452,12 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
     g.Wp = e->Wh1; g.bias = e->bh1;
     g.h_in = e->hB + (size_t)in_row0 * e->d; g.h_out = nullptr;
     g.parts = e->parts + (size_t)in_row0 * e->d; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
-    if (e->heads_finished_h) { g.n_parts = 0; g.has_prev_bias = 0; }      // the stream engine left the finished residual in hB
+    if (e->finished_rows_h) { g.n_parts = 0; g.has_prev_bias = 0; }       // the finished-row form left the whole residual in hB
     g.wg = e->wg_h1; g.gather_rows = gather;
-    g.progress_val = 4 * e->L + 1;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
-    if (!gather && n >= e->ln_split_rows) {
+    if (e->finished_rows_h && !gather && n >= 2 && n <= VC_FR_MAX_ROWS) {     // finished rows: LayerNorm fold per wave, no extra launch
+      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_GELU, 1, 1, s));
+    } else if (!gather && n >= e->ln_split_rows) {
       g.x_out = e->xn;
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
       g.x_in = e->xn; g.x_ld = e->d;
@@ -417,7 +472,6 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
     g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
     g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits + (size_t)out_row0 * e->K * e->V;
-    g.progress_val = 4 * e->L + 2;
     HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
   }
   return VC_OK;
@@ -434,6 +488,7 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
 // multi-tile rows-GEMM (weights streamed once per pass).  Same buffers and slabs as the decode pass.
 int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
+  e->finished_rows_h = false;           // this pass leaves h + split-K slabs
   // prefill passes run on the block GEMM (mt = 1); decode passes of 17..64 rows (n_active set) are still weight
   // streams: they take the weight-stationary multi-tile kernel (mt = 2), which reads every weight once at the decode rate
   const int mtv = (rs.n_active != nullptr && rs.n_rows <= VC_MAX_SEQS && !getenv("VC_WIDE_BLK")) ? 2 : 1;
@@ -589,52 +644,12 @@ int push_sample_dyn(vc_engine* e, const vc_sample_cfg* sc, const int64_t* forced
   return VC_OK;
 }
 
-StreamArgs stream_args(vc_engine* e) {
-  StreamArgs a;
-  memset(&a, 0, sizeof a);
-  a.Ws = e->sW; a.layers = e->sLayers; a.gran = e->sGran; a.ctl = e->sCtl;
-  a.h_in = e->dec_h; a.h_out = e->hB;
-  a.n_active = e->n_active; a.row_pos = e->dec_row_pos; a.row_seq = e->dec_row_seq;
-  a.d = e->d; a.H = e->H; a.hd = e->hd; a.L = e->L; a.G = e->sG; a.NS = e->sG / e->H; a.S_max = e->S_max;
-  a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
-  a.rpc = e->d / 512;
-  a.sq = (6 * a.rpc + 3) / 4; a.so = (2 * a.rpc + 3) / 4; a.s1 = 2 * a.rpc; a.s2 = 2 * a.rpc;
-  a.spl = a.sq + a.so + a.s1 + a.s2;
-  a.gran_layer_stride = sg_gran_per_layer(a);
-  a.scale = 1.0f / sqrtf((float)e->hd);
-  a.dbg = e->sDbg;
-  a.ts = e->sTs;
-  return a;
-}
-
-int stream_step(vc_engine* e, hipStream_t s) {
-  HIPCHK(e, vc_stream_launch(stream_args(e), s));
-  return VC_OK;
-}
-
-// after a synchronise: a bounded wait of the stream engine that gave up (sCtl[1]); the epoch is moved on so that the
-// granules of the broken step cannot be taken for the next step's
-int check_stream_flag(vc_engine* e) {
-  if (!e->stream_on) return VC_OK;
-  unsigned w[2] = {0, 0};
-  HIPCHK(e, hipMemcpy(w, e->sCtl, 8, hipMemcpyDeviceToHost));
-  if (w[1]) {
-    const unsigned fresh[2] = {w[0] + 2u ? w[0] + 2u : 1u, 0u};
-    (void)hipMemcpy(e->sCtl, fresh, 8, hipMemcpyHostToDevice);
-    return fail(e, VC_EHIP, "stream engine: a hand-off wait exceeded its bound (code 0x%x; workgroups not co-resident?)", w[1]);
-  }
-  return VC_OK;
-}
-
 int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, hipStream_t s) {
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = B * rps; rs.nsplit = attn_nsplit(e, B * rps); rs.n_active = e->n_active;
   int rc;
-  const bool stream = e->stream_on && B == 1 && rps == 1 && !grouped;
-  if (stream) {                   // one sequence, one row: ALL layers as one persistent launch (vc_stream.hip)
-    rc = stream_step(e, s);
-  } else if (rs.n_rows > VC_ROWS) {      // more than one MFMA row tile: the step runs on the block GEMM (per-row LayerNorm launch,
+  if (rs.n_rows > VC_ROWS) {             // more than one MFMA row tile: the step runs on the block GEMM (per-row LayerNorm launch,
     rs.nsplit = 1;                // attention one workgroup per (row, head), no split partials)
     rc = prefill_rows(e, rs, s);
   } else {
@@ -642,34 +657,10 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   }
   if (rc) return rc;
   // rps == 1: logit_row[b] == b (vc_tokens.hip advance_phase); the 3-row span switch is single-sequence
-  e->heads_finished_h = stream;
   rc = run_heads(e, rps == 1 ? nullptr : e->logit_row, B, 0, e->n_active, s);
-  e->heads_finished_h = false;
   if (rc) return rc;
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
   return VC_OK;
-}
-
-// The weight prefetcher runs beside the decode loop of ONE call (vc_stream.hip, weight_prefetch_k).
-int prefetch_start(vc_engine* e, int n_rows, hipStream_t s) {
-  if (e->pf_ahead <= 0 || n_rows > VC_ROWS || e->pf_running) return VC_OK;
-  e->h_flag[12] = 0;                                            // stop word (pinned)
-  HIPCHK(e, hipMemsetAsync(e->pf_prog, 0, sizeof(unsigned), s));
-  HIPCHK(e, hipEventRecord(e->pf_ev, s));
-  HIPCHK(e, hipStreamWaitEvent(e->pf_stream, e->pf_ev, 0));
-  PrefetchArgs a;
-  memset(&a, 0, sizeof a);
-  a.segs = e->pf_segs; a.n_seg = 4 * e->L + 2; a.prog = e->pf_prog; a.n_active = e->n_active; a.stop = e->h_flag + 12;
-  a.ahead = e->pf_ahead; a.G = e->pf_G;
-  HIPCHK(e, vc_prefetch_launch(a, e->pf_stream));
-  e->pf_running = true;
-  return VC_OK;
-}
-void prefetch_stop(vc_engine* e) {
-  if (!e->pf_running) return;
-  __atomic_store_n(e->h_flag + 12, 1, __ATOMIC_RELEASE);
-  (void)hipStreamSynchronize(e->pf_stream);
-  e->pf_running = false;
 }
 
 // The decode loop: every step is the same launch sequence (all step-dependent values live in HBM, the
@@ -686,7 +677,7 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   const double t0 = now_ms();
   e->host_ms[1] = e->host_ms[2] = 0;
   if (sc->use_graph) {
-    const auto key = std::make_tuple(B, rps, grouped ? 1 : 0);
+    const auto key = std::make_pair(std::make_tuple(B, rps, grouped ? 1 : 0), e->opt_state);
     auto it = e->graphs.find(key);
     if (it != e->graphs.end()) {
       exec = it->second;
@@ -709,7 +700,6 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   const double t1 = now_ms();
   volatile int* live = e->h_flag + 8;
   int launched = 0, rc = VC_OK, batch = 0;
-  if (!(e->stream_on && B == 1 && rps == 1 && !grouped)) rc = prefetch_start(e, B * rps, s);
   while (launched < max_steps && rc == VC_OK) {
     if (batch >= 2) {   // pace: at most two batches in flight; the older one must have ended before a third is queued
       hipError_t we = hipEventSynchronize(e->ev_pace[batch & 1]);
@@ -727,10 +717,6 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
     hipError_t re = hipEventRecord(e->ev_pace[batch & 1], s);
     if (re != hipSuccess) { rc = fail(e, VC_EHIP, "hipEventRecord: %s", hipGetErrorString(re)); break; }
     ++batch;
-  }
-  if (e->pf_running) {              // the prefetcher ends by itself when the last sequence retires; a call that ends
-    (void)hipStreamSynchronize(s);  // otherwise (step budget, error) stops it - after the steps it serves
-    prefetch_stop(e);
   }
   e->host_ms[3] = now_ms() - t1;
   e->host_ms[4] = 0;
@@ -778,9 +764,51 @@ int check_err_flag(vc_engine* e, hipStream_t s) {
   return VC_OK;
 }
 
+// One option by name (vc_set_option, and the VC_* environment variables at creation).
+int apply_option(vc_engine* e, const std::string& name, const char* value) {
+  int v0 = 0, v1 = 0, v2 = 0;
+  const int n = sscanf(value ? value : "", "%d,%d,%d", &v0, &v1, &v2);
+  if (n < 1) return fail(e, VC_EINVAL, "option '%s': '%s' is not a number list", name.c_str(), value ? value : "(null)");
+  if (name == "attn_pf") {            // slices[,out-projection KB[,FFN-up KB]] of the one-row attention launch's prefetch role; 0 = off
+    e->apf_z = std::max(0, std::min(v0, 16));
+    if (n >= 2) e->apf_wo_kb = std::max(0, v1);
+    if (n >= 3) e->apf_w1_kb = std::max(0, v2);
+  } else if (name == "ln_pf") {       // workgroups[,QKV KB[,FFN-up KB]] of the LayerNorm launches' prefetch role (several-row steps); 0 = off
+    e->lpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
+    if (n >= 2) e->lpf_qkv_kb = std::max(0, v1);
+    if (n >= 3) e->lpf_w1_kb = std::max(0, v2);
+  } else if (name == "graph_steps") { e->steps_per_graph = std::max(1, std::min(64, v0));
+  } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
+  } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
+  } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
+  } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_FR_MAX_ROWS));
+  } else if (name == "nt") { e->nt_decode = v0 ? 1 : 0;
+  } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
+  } else {
+    return fail(e, VC_EINVAL, "unknown option '%s'", name.c_str());
+  }
+  return VC_OK;
+}
+
+void refresh_opt_state(vc_engine* e) {
+  char buf[256];
+  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d|fr%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
+           e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi, e->attn_blocks_one, e->nt_decode, e->fr_rows);
+  e->opt_state = buf;
+}
+
 }  // namespace
 
 // =====================================================================================  C ABI
+extern "C" int vc_set_option(vc_engine* e, const char* name, const char* value) {
+  int rc = check_ready(e);
+  if (rc) return rc;
+  if (!name || !value) return fail(e, VC_EINVAL, "null argument to vc_set_option");
+  rc = apply_option(e, name, value);
+  refresh_opt_state(e);
+  return rc;
+}
+
 extern "C" const char* vc_version(void) { return "vcengine 0.1 (gfx950)"; }
 
 extern "C" const char* vc_last_error(const vc_engine* e) { return e ? e->err.c_str() : g_create_err.c_str(); }
@@ -820,10 +848,7 @@ extern "C" int vc_create(const vc_model_cfg* c, int hip_device, vc_engine** out)
 extern "C" void vc_destroy(vc_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->device);
-  prefetch_stop(e);
   (void)hipDeviceSynchronize();
-  if (e->pf_stream) (void)hipStreamDestroy(e->pf_stream);
-  if (e->pf_ev) (void)hipEventDestroy(e->pf_ev);
   for (auto& kv : e->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->h_st) (void)hipHostFree(e->h_st);
@@ -899,20 +924,6 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     }
     HIPCHK(e, hipMemcpy(e->pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
   }
-  // ---- stream engine (vc_stream.hip): opt-in (VC_STREAM=1); needs bf16, d a multiple of 512, one workgroup per 8
-  // model channels resident at once (G = d / 8 <= CUs), a whole number of workgroups per head, head_dim 32 / 64 / 128
-  {
-    const char* sv = getenv("VC_STREAM");
-    hipDeviceProp_t prop;
-    HIPCHK(e, hipGetDeviceProperties(&prop, e->device));
-    const int G = d / 8;
-    e->stream_on = sv && atoi(sv) != 0 && e->dtype == VC_DTYPE_BF16 && d % 512 == 0 && G <= prop.multiProcessorCount &&
-                   G % e->H == 0 && (e->hd == 32 || e->hd == 64 || e->hd == 128);
-    if (e->stream_on) {
-      e->sG = G;
-      if ((rc = dalloc(e, (char**)&e->sW, (size_t)L * vc_stream_layer_bytes(d, G)))) return rc;
-    }
-  }
   // ---- decoder layers
   e->layers.resize(L);
   for (int l = 0; l < L; ++l) {
@@ -925,23 +936,14 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if ((rc = pack_folded(e, pre + "linear1.weight", pre + "linear1.bias", pre + "norm2.", 4 * d, d,
                           &ly.W1, &ly.wg_1, &ly.b1))) return rc;
     if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W2))) return rc;
+    if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo8, VC_TH_RES))) return rc;
+    if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W28, VC_TH_RES))) return rc;
     if ((rc = keep_vec(e, pre + "linear2.bias", d, &ly.b2))) return rc;
     const size_t cache_bytes = (size_t)e->B_max * e->H * e->S_max * e->hd * e->esz;
     char* kc; char* vc;
     if ((rc = dalloc(e, &kc, cache_bytes))) return rc;
     if ((rc = dalloc(e, &vc, cache_bytes))) return rc;
     ly.kc = kc; ly.vc = vc;
-    if (e->stream_on) {   // the same four matrices once more, in the stream layout (LayerNorm gammas folded as in pack_folded)
-      const RawTensor *tq, *to, *t1, *t2, *tg1, *tg2;
-      if ((rc = need(e, pre + "self_attn.in_proj_weight", {3 * d, d}, &tq))) return rc;
-      if ((rc = need(e, pre + "self_attn.out_proj.weight", {d, d}, &to))) return rc;
-      if ((rc = need(e, pre + "linear1.weight", {4 * d, d}, &t1))) return rc;
-      if ((rc = need(e, pre + "linear2.weight", {d, 4 * d}, &t2))) return rc;
-      if ((rc = need(e, pre + "norm1.weight", {d}, &tg1))) return rc;
-      if ((rc = need(e, pre + "norm2.weight", {d}, &tg2))) return rc;
-      HIPCHK(e, vc_stream_pack_layer(tq->dev, to->dev, t1->dev, t2->dev, tg1->dev, tg2->dev,
-                                     (char*)e->sW + (size_t)l * vc_stream_layer_bytes(d, e->sG), d, e->sG, 0));
-    }
     // free the staging copies of this layer right away (3.3 GB for the 830M shape otherwise)
     for (const char* k2 : {"self_attn.in_proj_weight", "self_attn.out_proj.weight", "linear1.weight", "linear2.weight"}) {
       auto it = e->raw.find(pre + k2);
@@ -989,61 +991,6 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipDeviceSynchronize());
   for (auto& kv : e->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
   e->raw.clear();
-  if (e->stream_on) {
-    std::vector<StreamLayerDev> tab(L);
-    for (int l = 0; l < L; ++l) {
-      const Layer& ly = e->layers[l];
-      tab[l] = StreamLayerDev{ly.wg_qkv, ly.bqkv, ly.bo, ly.wg_1, ly.b1, ly.b2, ly.kc, ly.vc};
-    }
-    if ((rc = dalloc(e, &e->sLayers, (size_t)L))) return rc;
-    HIPCHK(e, hipMemcpy(e->sLayers, tab.data(), sizeof(StreamLayerDev) * L, hipMemcpyHostToDevice));
-    StreamArgs probe;
-    memset(&probe, 0, sizeof probe);
-    probe.d = d; probe.G = e->sG; probe.hd = e->hd;
-    const size_t ng = (size_t)sg_gran_per_layer(probe) * L;
-    if ((rc = dalloc(e, &e->sGran, ng))) return rc;
-    HIPCHK(e, hipMemset(e->sGran, 0, ng * 8));           // tag 0 is never a live epoch
-    if ((rc = dalloc(e, &e->sCtl, (size_t)4))) return rc;
-    { const unsigned init[4] = {1u, 0u, 0u, 0u}; HIPCHK(e, hipMemcpy(e->sCtl, init, 16, hipMemcpyHostToDevice)); }
-    if (getenv("VC_STREAM_DBG")) {
-      if ((rc = dalloc(e, &e->sDbg, (size_t)L * 5 * 4 * d))) return rc;
-      HIPCHK(e, hipMemset(e->sDbg, 0, (size_t)L * 5 * 4 * d * 4));
-      if ((rc = dalloc(e, &e->sTs, (size_t)3 * L * 16 + (size_t)e->sG * 4))) return rc;
-      HIPCHK(e, hipMemset(e->sTs, 0, ((size_t)3 * L * 16 + (size_t)e->sG * 4) * 8));
-    }
-  }
-  // ---- weight prefetcher of the launch path: the matrices of a decode step in launch order
-  {
-    const char* pv = getenv("VC_PREFETCH");
-    // off by default: measured a LOSS (B = 1 step 0.59 -> 0.69 ms at 4 matrices ahead, profiles/r03_prefetch_sweep.log).  A launch
-    // whose matrix was streamed just before by another kernel runs 7.7 us against 9.1 cold and 5.1 "hot" (tools/pf_probe.py): what
-    // makes the hot launch fast is the XCD's own L2 (it re-reads what its CUs read last time), which one matrix already fills;
-    // the Infinity Cache alone is worth ~1.4 us, less than the bandwidth the prefetcher takes from the running launch.
-    e->pf_ahead = pv ? atoi(pv) : 0;                  // matrices ahead (4 = one layer, ~100 MB of the 256 MB Infinity Cache); 0 = off
-    hipDeviceProp_t prop;
-    HIPCHK(e, hipGetDeviceProperties(&prop, e->device));
-    e->pf_G = prop.multiProcessorCount;
-    if (e->pf_ahead > 0) {
-      const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
-      auto image = [&](int N, int Kd, int th) { return (size_t)((N + th - 1) / th) * (Kd / KW) * 4 * th * 16; };
-      std::vector<PrefetchSeg> segs;
-      for (int l = 0; l < L; ++l) {
-        const Layer& ly = e->layers[l];
-        segs.push_back({(const char*)ly.Wqkv, image(3 * d, d, VC_TH_QKV)});
-        segs.push_back({(const char*)ly.Wo, image(d, d, 16)});
-        segs.push_back({(const char*)ly.W1, image(4 * d, d, 16)});
-        segs.push_back({(const char*)ly.W2, image(d, 4 * d, 16)});
-      }
-      segs.push_back({(const char*)e->Wh1, image(K * P, d, 16)});
-      segs.push_back({(const char*)e->Wh2, (size_t)e->wh2_group_stride * 16 * K});
-      if ((rc = dalloc(e, &e->pf_segs, segs.size()))) return rc;
-      HIPCHK(e, hipMemcpy(e->pf_segs, segs.data(), segs.size() * sizeof(PrefetchSeg), hipMemcpyHostToDevice));
-      if ((rc = dalloc(e, &e->pf_prog, (size_t)4))) return rc;
-      HIPCHK(e, hipMemset(e->pf_prog, 0, 16));
-      HIPCHK(e, hipStreamCreateWithFlags(&e->pf_stream, hipStreamNonBlocking));
-      HIPCHK(e, hipEventCreateWithFlags(&e->pf_ev, hipEventDisableTiming));
-    }
-  }
   // ---- launch plans
   e->p_qkv = make_plan(3 * d, d, e->dtype, false, nullptr, VC_TH_QKV);
   e->p_o = make_plan(d, d, e->dtype, true, "VC_KSPLIT_O");
@@ -1099,30 +1046,14 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (auto& ev : e->ev) HIPCHK(e, hipEventCreate(&ev));
   // a blocking stream: implicitly ordered after work the caller queued on the null stream
   HIPCHK(e, hipStreamCreate(&e->own_stream));
-  {
-    const char* nv = getenv("VC_NT");
-    e->nt_decode = nv ? atoi(nv) : 1;
-    const char* pr = getenv("VC_PREFILL_ROWS");
-    if (pr) e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, atoi(pr) / VC_ROWS * VC_ROWS));   // 16: decode kernels only
-    const char* ls = getenv("VC_LN_SPLIT_ROWS");
-    if (ls) e->ln_split_rows = std::max(2, atoi(ls));
-    if (const char* lp = getenv("VC_LN_PF")) {
-      int b = 0, q = e->lpf_qkv_kb, w1 = e->lpf_w1_kb;
-      const int n = sscanf(lp, "%d,%d,%d", &b, &q, &w1);
-      if (n >= 1) e->lpf_blocks = std::max(0, std::min(b, 1024)) & ~7;
-      if (n >= 2) e->lpf_qkv_kb = std::max(0, q);
-      if (n >= 3) e->lpf_w1_kb = std::max(0, w1);
-    }
-    if (const char* ap = getenv("VC_ATTN_PF")) {
-      int z = 0, wo = e->apf_wo_kb, w1 = e->apf_w1_kb;
-      const int n = sscanf(ap, "%d,%d,%d", &z, &wo, &w1);
-      if (n >= 1) e->apf_z = std::max(0, std::min(z, 16));
-      if (n >= 2) e->apf_wo_kb = std::max(0, wo);
-      if (n >= 3) e->apf_w1_kb = std::max(0, w1);
-    }
-    const char* gs = getenv("VC_GRAPH_STEPS");
-    if (gs) e->steps_per_graph = std::max(1, std::min(64, atoi(gs)));
-  }
+  // ---- options: the VC_* environment variables preset them, vc_set_option changes them at run time
+  for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), std::make_pair("VC_LN_SPLIT_ROWS", "ln_split_rows"),
+                         std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
+                         std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
+                         std::make_pair("VC_FINISHED_ROWS", "finished_rows")})
+    if (const char* v = getenv(kv.first))
+      if ((rc = apply_option(e, kv.second, v))) return rc;
+  refresh_opt_state(e);
   HIPCHK(e, hipDeviceSynchronize());
   e->finalized = true;
   return VC_OK;
@@ -1217,7 +1148,6 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
-  if ((rc = check_stream_flag(e))) return rc;
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];
@@ -1632,9 +1562,11 @@ extern "C" int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int
   else if (n == "sampler_ts") { src = e->dbg_ts; avail = 16 * 8; }
   else if (n == "kernel_ts") { src = e->dbg_ts; avail = 64 * 8; }
   else if (n == "host_ms") { host_src = e->host_ms; avail = 8 * 8; }
-  else if (n == "stream_dbg" && e->sDbg) { src = e->sDbg; avail = (int64_t)e->L * 5 * 4 * e->d * 4; }
-  else if (n == "stream_ts" && e->sTs) { src = e->sTs; avail = ((int64_t)3 * e->L * 16 + (int64_t)e->sG * 4) * 8; }
-  else if (n == "stream_ctl" && e->sCtl) { src = e->sCtl; avail = 16; }
+  else if (n == "options") {        // the option state as text (vc_set_option), NUL-padded
+    memset(host_dst, 0, (size_t)nbytes);
+    memcpy(host_dst, e->opt_state.c_str(), std::min<size_t>((size_t)nbytes > 0 ? (size_t)nbytes - 1 : 0, e->opt_state.size()));
+    return VC_OK;
+  }
   else if (n == "launch_counts") { host_src = vc_launch_counts; avail = VC_LC_N * 8; }     // process-wide census of kernel forms (vc_common.h)
   else return fail(e, VC_EINVAL, "unknown debug buffer '%s'", n.c_str());
   if (nbytes > avail) return fail(e, VC_ECAP, "debug buffer '%s' holds %lld bytes", n.c_str(), (long long)avail);
@@ -1694,21 +1626,9 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   bool hot = false;
   std::string w2 = w;
   if (w.size() > 4 && w.substr(w.size() - 4) == "_hot") { hot = true; w2 = w.substr(0, w.size() - 4); }
-  bool with_pf = false, pf_only = false;      // "<kernel>_pf": the layer's matrix is prefetched (weight_prefetch_k, direct form) right before
-  if (w2.size() > 3 && w2.substr(w2.size() - 3) == "_pf") { with_pf = true; w2 = w2.substr(0, w2.size() - 3); }
-  if (w2.size() > 7 && w2.substr(w2.size() - 7) == "_pfonly") { pf_only = true; w2 = w2.substr(0, w2.size() - 7); }
   auto one = [&](int i) -> int {
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
-    if ((with_pf || pf_only) && e->pf_ahead > 0) {
-      const int segi = 4 * (i % e->L) + (w == "qkv" ? 0 : w == "oproj" ? 1 : w == "ffn1" ? 2 : 3);
-      PrefetchArgs pa;
-      memset(&pa, 0, sizeof pa);
-      pa.segs = e->pf_segs; pa.n_seg = 4 * e->L + 2; pa.prog = e->pf_prog; pa.n_active = e->one; pa.stop = e->h_flag + 12;
-      pa.ahead = -(segi + 1); pa.G = e->pf_G;
-      HIPCHK(e, vc_prefetch_launch(pa, s));
-      if (pf_only) return VC_OK;
-    }
     const bool split_ln = n_rows >= e->ln_split_rows;   // the engine then normalises in ln_rows_k and takes the plain prologue
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);

@@ -332,8 +332,6 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   constexpr int TH = (EPI == EPI_QKV) ? VC_TH_QKV : 16;
   constexpr int SPT = 4 * TH;                     // fragment slots per (n_tile, k_tile)
   const int active = *a.n_active;                 // scalar; looked at once the burst is on its way
-  if (a.progress && tid == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0)      // "matrix progress_val - 1 of the step is being read": the
-    __hip_atomic_store(a.progress, a.progress_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // weight prefetcher's pace (a store, not a read-modify-write: the word is polled)
   const int m = lane & 15;
   const int kg = lane >> 4;
   const int n = nt * TH + 4 * kg;
@@ -344,7 +342,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   int epos, eseq;
   epi_preload<WT, EPI>(a, (m < n_rows) ? m : 0, n, grp, eb, epos, eseq);
   float4 ewg = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (PRO == PRO_LN) ewg = wg_preload<WT, EPI>(a, n, grp);
+  if constexpr (PRO == PRO_LN || PRO == PRO_LNW) ewg = wg_preload<WT, EPI>(a, n, grp);
 
   const uint4* wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * SPT;   // wave-uniform
   uint4 wf[KTW];
@@ -454,6 +452,50 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     }
 #undef VC_LOAD_ROW
 #undef VC_FINISH_ROW
+  } else if constexpr (PRO == PRO_LNW) {
+    // LayerNorm fold of 2..8 FINISHED rows (h holds the whole residual, bias included: the finished-row producers below,
+    // rows_gemm_fr_k): one WAVE per row - wave w takes rows w and w + 4 - so a row's mean and its two statistics are wave
+    // reductions, the prologue has no block barrier per row and both rows of a wave are requested ahead of the weight
+    // burst.  (PRO_LN walks the rows one after the other with the whole block: one dependent round trip + one barrier per
+    // row in every workgroup - 20 us per GEMM at 8 rows - which is why several-row steps used a separate LayerNorm launch.)
+    const int d = a.d;
+    const int npl = d >> 8;                                 // float4 per lane and row: d / 4 / 64 = 1..8 (d % 256 == 0)
+    const float* hrA = a.h_in + (long)min(wave, n_rows - 1) * d;
+    const float* hrB = a.h_in + (long)min(wave + 4, n_rows - 1) * d;
+    float4 xa[8], xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = (min(j, npl - 1) * 64 + lane) * 4;
+      xa[j] = *reinterpret_cast<const float4*>(hrA + c);
+      xb[j] = *reinterpret_cast<const float4*>(hrB + c);
+    }
+    VC_ISSUE_WEIGHTS(0);
+    VC_BURST_OUT();
+#define VC_LNW_ROW(X, r)                                                                         \
+    if ((r) < n_rows) {                                                                          \
+      float t_ = 0.f;                                                                            \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                              \
+        if (j < npl) t_ += (X[j].x + X[j].y) + (X[j].z + X[j].w);                                \
+      const float mu_ = wave_sum(t_) * (1.0f / (float)d);                                        \
+      WT* xr_ = reinterpret_cast<WT*>(xl + (size_t)(r) * xs);                                    \
+      float s1_ = 0.f, s2_ = 0.f;                                                                \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                              \
+        if (j < npl) {                                                                           \
+          const f32x4 y_ = {X[j].x - mu_, X[j].y - mu_, X[j].z - mu_, X[j].w - mu_};             \
+          const f32x4 q_ = store4r(xr_ + (j * 64 + lane) * 4, y_);                               \
+          s1_ += (q_[0] + q_[1]) + (q_[2] + q_[3]);                                              \
+          s2_ += (q_[0] * q_[0] + q_[1] * q_[1]) + (q_[2] * q_[2] + q_[3] * q_[3]);              \
+        }                                                                                        \
+      s1_ = wave_sum(s1_);                                                                       \
+      s2_ = wave_sum(s2_);                                                                       \
+      if (lane == 0) {      /* the epilogue sums four per-wave pairs: this row has one */          \
+        *reinterpret_cast<float4*>(stat + (r) * 8) = make_float4(s1_, s2_, 0.f, 0.f);            \
+        *reinterpret_cast<float4*>(stat + (r) * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);        \
+      }                                                                                          \
+    }
+    VC_LNW_ROW(xa, wave);
+    VC_LNW_ROW(xb, wave + 4);
+#undef VC_LNW_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
     // X rows copied as 16-byte units, flat index = row * upr + unit.  The first NB*256 units are
     // requested ahead of the weight burst (clamped, unconditional), the rest behind it.
@@ -616,7 +658,7 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
     }
-    if constexpr (PRO == PRO_LN) {   // LayerNorm fold on the centred row xc: y = rstd * (W'xc - mean(xc) * rowsum(W')) [+ cb in the epilogue]
+    if constexpr (PRO == PRO_LN || PRO == PRO_LNW) {   // LayerNorm fold on the centred row xc: y = rstd * (W'xc - mean(xc) * rowsum(W')) [+ cb in the epilogue]
       const float4 sa = *reinterpret_cast<const float4*>(stat + m * 8), sb = *reinterpret_cast<const float4*>(stat + m * 8 + 4);
       const float inv_d = 1.0f / (float)a.d;
       const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * inv_d;
@@ -629,6 +671,221 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   }
   VC_KTS(6);
   VC_KTS_FLUSH();
+}
+
+// ------------------------------------------------------------------ finished-row producers: decode passes of 2..8 rows
+// A several-row decode step (config 5's per-GPU share: 8 utterances) spent 18 % of its kernel time in two 8-workgroup
+// LayerNorm launches per layer: the out-projection and the FFN down-projection leave split-K slabs, the sum of h + bias +
+// 4 slabs per row is too much to redo in every consumer workgroup (320 KB each), so a launch of its own did it once.  Here
+// those two producers finish their rows instead: K is NOT split across workgroups - a workgroup owns 8 output channels
+// (VC_TH_RES: d/8 = 256 workgroups at d = 2048) over the whole K, its 8 waves stream K/8 each in ONE burst (the FFN
+// down-projection at d = 2048: 32 fragments of 512 B per wave, 128 KB per workgroup, everything requested at once), X of
+// all rows is staged in LDS (8 rows x 8192 x 2 B = 128 KB), and the epilogue adds the residual and the bias and writes the
+// row once.  The consumers then fold the LayerNorm of one FINISHED row per wave (PRO_LNW): no slabs, no LayerNorm launch.
+// PRO_PLAIN: X = activations (FFN down); PRO_ATT: X = merge of the attention's split partials of ALL heads (out-projection;
+// NS = partials per item the loads are unrolled for, rows x NS <= 16 so that one batch of loads covers every item).
+// Bounded by rows x K x sizeof(WT) <= 128 KB of LDS: 8 rows in bf16, 4 in the exact fp32 mode.
+template <typename WT, int KTW, int PRO, int NS>
+__global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr_k(const GemmArgs a) {
+  using T = WTr<WT>;
+  constexpr int NW = VC_FR_WAVES, NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockIdx.x;
+  const int n_rows = a.n_rows;                    // 2..8 (host contract)
+  const int K = a.K;
+  const int xs = K * (int)sizeof(WT) + 16;        // LDS row stride (+16: rotate bank slots)
+  char* xl = smem;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
+  const int active = *a.n_active;
+  const int m = lane & 15, kg = lane >> 4;
+  const bool nvalid = 4 * kg < TH;
+  const int n = nt * TH + (nvalid ? 4 * kg : 0);
+  const int wslot = kg * TH + min(m, TH - 1);
+  // epilogue operands first (a wave's loads return in order): the residual and the bias of the lane's four channels
+  const float4 eres = *reinterpret_cast<const float4*>(a.h_in + (long)((m < n_rows) ? m : 0) * a.d + n);
+  const float4 eb = *reinterpret_cast<const float4*>(a.bias + n);
+  const uint4* wbase = a.Wp + ((long)nt * a.KT + wave * KTW) * SPT;      // wave-uniform
+  uint4 wf[KTW];
+#define VC_FR_WEIGHTS(c_)                                                                        \
+  {                                                                                              \
+    const uint4* wb_ = wbase + (long)(c_) * (NW * KTW * SPT);                                     \
+    _Pragma("unroll") for (int i = 0; i < KTW; ++i)                                              \
+      wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb_ + i * SPT + wslot))); \
+  }
+  if constexpr (PRO == PRO_PLAIN) {
+    // X rows as 16-byte units, flat index = row * upr + unit; <= 16 units per thread (rows x K x sizeof <= 128 KB)
+    const int upr = K * (int)sizeof(WT) / 16;
+    const int total = n_rows * upr;
+    const char* src = reinterpret_cast<const char*>(a.x_in);
+    const long rstride = (long)a.x_ld * (long)sizeof(WT);
+    const int sh = a.x_upr_shift;
+    // (explicit scalars: an indexed array is demoted to scratch memory by the compiler)
+    uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+#define VC_FRX_LOAD(j, dst)                                                                      \
+    {                                                                                            \
+      const int i_ = min((j) * NTHR + tid, total - 1);                                           \
+      const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                        \
+      dst = *reinterpret_cast<const uint4*>(src + (long)r_ * rstride + (long)(i_ - r_ * upr) * 16); \
+    }
+#define VC_FRX_STORE(j, val)                                                                     \
+    {                                                                                            \
+      const int i_ = (j) * NTHR + tid;                                                           \
+      if (i_ < total) {                                                                          \
+        const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                      \
+        *reinterpret_cast<uint4*>(xl + (size_t)r_ * xs + (size_t)(i_ - r_ * upr) * 16) = val;    \
+      }                                                                                          \
+    }
+    VC_FRX_LOAD(0, x0) VC_FRX_LOAD(1, x1) VC_FRX_LOAD(2, x2) VC_FRX_LOAD(3, x3)
+    VC_FRX_LOAD(4, x4) VC_FRX_LOAD(5, x5) VC_FRX_LOAD(6, x6) VC_FRX_LOAD(7, x7)
+    VC_FRX_LOAD(8, x8) VC_FRX_LOAD(9, x9) VC_FRX_LOAD(10, x10) VC_FRX_LOAD(11, x11)
+    VC_FRX_LOAD(12, x12) VC_FRX_LOAD(13, x13) VC_FRX_LOAD(14, x14) VC_FRX_LOAD(15, x15)
+    VC_FR_WEIGHTS(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (active == 0) return;
+    VC_FRX_STORE(0, x0) VC_FRX_STORE(1, x1) VC_FRX_STORE(2, x2) VC_FRX_STORE(3, x3)
+    VC_FRX_STORE(4, x4) VC_FRX_STORE(5, x5) VC_FRX_STORE(6, x6) VC_FRX_STORE(7, x7)
+    VC_FRX_STORE(8, x8) VC_FRX_STORE(9, x9) VC_FRX_STORE(10, x10) VC_FRX_STORE(11, x11)
+    VC_FRX_STORE(12, x12) VC_FRX_STORE(13, x13) VC_FRX_STORE(14, x14) VC_FRX_STORE(15, x15)
+#undef VC_FRX_LOAD
+#undef VC_FRX_STORE
+  } else {   // PRO_ATT: item = (row, 4 columns of one head) with a.nsplit <= NS partials of (max, sum, acc[4]); NI items per thread
+    constexpr int NI = 16 / NS;
+    const int q4 = K >> 2;
+    const int n_items = n_rows * q4;              // <= NI * NTHR (rows x NS <= 16, K <= 2048: host contract)
+    const int qsh = a.att_q4_shift;
+    float2 ml[NI][NS];
+    float4 os[NI][NS];
+    int ir[NI], ic[NI];
+    bool on[NI];
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib) {
+      const int idx = ib * NTHR + tid;
+      on[ib] = idx < n_items;
+      const int i_ = on[ib] ? idx : 0;
+      ir[ib] = (qsh >= 0) ? (i_ >> qsh) : (i_ / q4);
+      ic[ib] = (i_ - ir[ib] * q4) * 4;
+      const int h_ = ic[ib] / a.hd, e_ = ic[ib] - h_ * a.hd;
+      const float2* mp = reinterpret_cast<const float2*>(a.att_ml) + (long)(ir[ib] * a.H + h_) * a.nsplit;
+      const float* op = a.att_o + ((long)(ir[ib] * a.H + h_) * a.nsplit) * a.hd + e_;
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        const int se = (sp < a.nsplit) ? sp : 0;
+        ml[ib][sp] = mp[se];
+        os[ib][sp] = *reinterpret_cast<const float4*>(op + (long)se * a.hd);
+      }
+    }
+    VC_FR_WEIGHTS(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (active == 0) return;
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib) {
+      float M = -INFINITY;
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        ml[ib][sp].x = (sp < a.nsplit) ? ml[ib][sp].x : -INFINITY;
+        M = fmaxf(M, ml[ib][sp].x);
+      }
+      float L = 0.f;
+      f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        const float w = (ml[ib][sp].x == -INFINITY) ? 0.f : expf(ml[ib][sp].x - M);
+        L += w * ml[ib][sp].y;
+        o[0] += w * os[ib][sp].x; o[1] += w * os[ib][sp].y; o[2] += w * os[ib][sp].z; o[3] += w * os[ib][sp].w;
+      }
+      const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+      o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+      if (on[ib]) store4(reinterpret_cast<WT*>(xl + (size_t)ir[ib] * xs) + ic[ib], o);
+    }
+  }
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int mrow = (m < a.r_lds) ? m : 0;
+  const char* xrow = xl + (size_t)mrow * xs + (size_t)kg * 16;
+  for (int c = 0; c < a.nchunk; ++c) {
+    const int ktl = (c * NW + wave) * KTW;
+#pragma unroll
+    for (int i = 0; i < KTW; ++i) {
+      const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)(ktl + i) * 64);
+      acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);     // (fragment rows 8..15 repeat slot 7: they only reach D rows nobody reads)
+    }
+    if (c + 1 < a.nchunk) VC_FR_WEIGHTS(c + 1);          // exact fp32 mode at d = 2048: the registers hold half of a wave's share
+  }
+#undef VC_FR_WEIGHTS
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0 && m < n_rows && nvalid) {
+#pragma unroll
+    for (int w = 1; w < NW; ++w) acc += red[w * 64 + lane];
+    const f32x4 o = {eres.x + eb.x + acc[0], eres.y + eb.y + acc[1], eres.z + eb.z + acc[2], eres.w + eb.w + acc[3]};
+    store4(a.h_out + (long)m * a.d + n, o);
+  }
+}
+
+template <typename WT, int KTW, int PRO, int NS>
+static hipError_t launch_fr_n(const GemmArgs& a, size_t lds, hipStream_t s) {
+  auto kern = rows_gemm_fr_k<WT, KTW, PRO, NS>;
+  if (lds > 64 * 1024) {
+    static size_t granted[16] = {0};   // per instantiation and device
+    int dev = 0;
+    if (hipError_t ge = hipGetDevice(&dev); ge != hipSuccess) return ge;
+    if (dev >= 0 && dev < 16 && lds > granted[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      granted[dev] = lds;
+    }
+  }
+  ++vc_launch_counts[VC_LC_ROWS_GEMM_FR];
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(64 * VC_FR_WAVES), lds, s, a);
+  return hipGetLastError();
+}
+template <typename WT, int KTW>
+static hipError_t launch_fr_ktw(const GemmArgs& a, int pro, size_t lds, hipStream_t s) {
+  if (pro == PRO_PLAIN) return launch_fr_n<WT, KTW, PRO_PLAIN, 1>(a, lds, s);
+  if constexpr (KTW <= 16) {           // the out-projection: K = d <= 2048
+    if (pro == PRO_ATT) {
+      if (a.nsplit > 4) return launch_fr_n<WT, KTW, PRO_ATT, 8>(a, lds, s);
+      if (a.nsplit > 2) return launch_fr_n<WT, KTW, PRO_ATT, 4>(a, lds, s);
+      return launch_fr_n<WT, KTW, PRO_ATT, 2>(a, lds, s);
+    }
+  }
+  return hipErrorInvalidValue;
+}
+size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype) {
+  const size_t esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
+  return (size_t)rows * ((size_t)K * esz + 16) + (size_t)VC_FR_WAVES * 64 * sizeof(f32x4);
+}
+// A finished-row producer pass: out-projection (PRO_ATT) or FFN down-projection (PRO_PLAIN) of 2..VC_FR_MAX_ROWS rows; a.Wp
+// is the 8-channel-tile image of the matrix, a.h_in the residual rows, a.bias the layer's bias, a.h_out the finished rows.
+hipError_t vc_launch_gemm_fr(const GemmArgs& a0, int dtype, int pro, hipStream_t s) {
+  GemmArgs a = a0;
+  const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16;
+  a.n_tiles = a.N / VC_TH_RES;
+  a.KT = a.K / KW;
+  a.r_lds = a.n_rows;
+  int ktw = 32;
+  while (ktw > 1 && a.KT % (VC_FR_WAVES * ktw) != 0) ktw >>= 1;
+  if (a.KT % (VC_FR_WAVES * ktw) != 0 || a.N % VC_TH_RES != 0 || a.n_rows < 1 || a.n_rows > VC_FR_MAX_ROWS) return hipErrorInvalidValue;
+  a.nchunk = a.KT / (VC_FR_WAVES * ktw);
+  const int esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
+  const int upr = a.K * esz / 16, q4 = a.K / 4;
+  a.x_upr_shift = -1; a.att_q4_shift = -1;
+  for (int sft = 0; sft < 20; ++sft) {
+    if ((1 << sft) == upr) a.x_upr_shift = sft;
+    if ((1 << sft) == q4) a.att_q4_shift = sft;
+  }
+  if (pro == PRO_PLAIN && (long)a.n_rows * upr > 16L * 64 * VC_FR_WAVES) return hipErrorInvalidValue;
+  if (pro == PRO_ATT && (a.nsplit < 1 || a.n_rows * (a.nsplit > 4 ? 8 : a.nsplit > 2 ? 4 : 2) > 16 || (long)a.n_rows * q4 > 16L / (a.nsplit > 4 ? 8 : a.nsplit > 2 ? 4 : 2) * 64 * VC_FR_WAVES))
+    return hipErrorInvalidValue;
+  const size_t lds = vc_gemm_fr_lds_bytes(a.n_rows, a.K, dtype);
+#define VC_FR_CASE(K_) case K_: return (dtype == VC_DTYPE_BF16) ? launch_fr_ktw<bf16_t, K_>(a, pro, lds, s) : launch_fr_ktw<float, K_>(a, pro, lds, s);
+  switch (ktw) {
+    VC_FR_CASE(1) VC_FR_CASE(2) VC_FR_CASE(4) VC_FR_CASE(8) VC_FR_CASE(16) VC_FR_CASE(32)
+    default: return hipErrorInvalidValue;
+  }
+#undef VC_FR_CASE
 }
 
 // ------------------------------------------------------------------ wide decode passes: 17..64 rows
@@ -682,12 +939,16 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
   const long rstride = (long)a.x_ld * (long)sizeof(WT);
   const int sh = a.x_upr_shift;
   uint4 xq0, xq1, xq2, xq3, xq4, xq5, xq6, xq7;   // explicit scalars: an indexed array is demoted to scratch
+  // (the 1024-thread form runs at the 128-register cap: the reciprocal of the general row split below - a loop invariant the
+  // compiler keeps in a VECTOR register although it is uniform - would be spilled across the row-tile loop; there the divisor
+  // is made opaque at each use, so the few instructions are redone per tile instead)
+  auto upr_div = [&]() { int u = upr; if constexpr (NTW >= 4) asm volatile("" : "+s"(u)); return u; };
 
   // X tile of rows [row0, row0 + nr): global -> registers (first XP * NT units) ...
 #define VC_XQ_LOAD(j, dst)                                                                       \
   if constexpr ((j) < XP) {                                                                      \
     const int i_ = min((j) * NT + tid, total - 1);                                               \
-    const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                          \
+    const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr_div());                                    \
     const int u_ = i_ - r_ * upr;                                                                \
     dst = *reinterpret_cast<const uint4*>(xsrc + (long)(row0 + r_) * rstride + (long)u_ * 16);   \
   }
@@ -695,7 +956,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
   if constexpr ((j) < XP) {                                                                      \
     const int i_ = (j) * NT + tid;                                                               \
     if (i_ < total) {                                                                            \
-      const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                        \
+      const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr_div());                                  \
       const int u_ = i_ - r_ * upr;                                                              \
       *reinterpret_cast<uint4*>(xl + (size_t)r_ * xs + (size_t)u_ * 16) = val;                   \
     }                                                                                            \
@@ -714,7 +975,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
       VC_XQ_STORE(0, xq0) VC_XQ_STORE(1, xq1) VC_XQ_STORE(2, xq2) VC_XQ_STORE(3, xq3)
       VC_XQ_STORE(4, xq4) VC_XQ_STORE(5, xq5) VC_XQ_STORE(6, xq6) VC_XQ_STORE(7, xq7)
       for (int i = XP * NT + tid; i < total; i += NT) {
-        const int r = (sh >= 0) ? (i >> sh) : (i / upr);
+        const int r = (sh >= 0) ? (i >> sh) : (i / upr_div());
         const int u = i - r * upr;
         *reinterpret_cast<uint4*>(xl + (size_t)r * xs + (size_t)u * 16) =
             *reinterpret_cast<const uint4*>(xsrc + (long)(row0 + r) * rstride + (long)u * 16);
@@ -755,7 +1016,9 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
     // to the stores they are a dependent L2 round trip per 16-row tile on the critical path of every workgroup
     float4 eb = make_float4(0.f, 0.f, 0.f, 0.f);
     int epos = -1, eseq = 0;
-    if (wave == 0) epi_preload<WT, EPI>(a, row0 + min(m, nr - 1), n, grp, eb, epos, eseq);
+    // (the 1024-thread form runs at the 128-register cap: there the six operand registers would spill across the MFMA loop,
+    // so it asks for them after the loop, under the K-reduce barrier)
+    if constexpr (NTW < 4) { if (wave == 0) epi_preload<WT, EPI>(a, row0 + min(m, nr - 1), n, grp, eb, epos, eseq); }
     if (nr1 > 0) x_fetch(row1, nr1);       // next tile on its way while this one is in the MFMAs
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     const int mrow = (m < nr) ? m : 0;
@@ -776,12 +1039,19 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
         acc = mfma_frag(wf[i], xf, acc, (WT*)nullptr);
       }
     }
+    // (... and the channel index is made opaque per tile: otherwise the epilogue's loop-invariant address arithmetic - head
+    // and element of the lane's channels, 64-bit products - is hoisted out of the row-tile loop and spilled across it)
+    int n_e = n;
+    if constexpr (NTW >= 4) {
+      asm volatile("" : "+v"(n_e));
+      if (wave == 0) epi_preload<WT, EPI>(a, row0 + min(m, nr - 1), n_e, grp, eb, epos, eseq);
+    }
     red[wave * 64 + lane] = acc;
     __syncthreads();
     if (wave == 0 && m < nr && nvalid && tile_ok) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
-      gemm_epilogue<WT, EPI>(a, acc, row0 + m, n, ks, grp, (int)gridDim.z, eb, epos, eseq);
+      gemm_epilogue<WT, EPI>(a, acc, row0 + m, n_e, ks, grp, (int)gridDim.z, eb, epos, eseq);
     }
     __syncthreads();            // x and red are rewritten for the next tile
     if (nr1 > 0) x_park(row1, nr1);
@@ -1364,6 +1634,9 @@ static hipError_t launch_ktw(const GemmArgs& a, int dtype, int pro, int epi, int
   if (pro == PRO_LN && epi == EPI_QKV) return launch_one<WT, KTW, PRO_LN, EPI_QKV>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LN && epi == EPI_RELU) return launch_one<WT, KTW, PRO_LN, EPI_RELU>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LN && epi == EPI_GELU) return launch_one<WT, KTW, PRO_LN, EPI_GELU>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_LNW && epi == EPI_QKV) return launch_dec<WT, KTW, PRO_LNW, EPI_QKV>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_LNW && epi == EPI_RELU) return launch_dec<WT, KTW, PRO_LNW, EPI_RELU>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_LNW && epi == EPI_GELU) return launch_dec<WT, KTW, PRO_LNW, EPI_GELU>(a, dtype, ksplit, groups, s);
   if (pro == PRO_ATT && epi == EPI_PART) return launch_one<WT, KTW, PRO_ATT, EPI_PART>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_PART) return launch_one<WT, KTW, PRO_PLAIN, EPI_PART>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_LOGITS) return launch_one<WT, KTW, PRO_PLAIN, EPI_LOGITS>(a, dtype, ksplit, groups, s);

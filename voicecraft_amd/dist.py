@@ -34,8 +34,11 @@ def gather_token_blocks(gens: list[torch.Tensor], t_max: int, n_slots: int | Non
     if world == 1:
         blocks = [blk]
     else:
+        if dist.get_backend(group) == "gloo" and blk.is_cuda:      # host collectives (ranks sharing one GPU in the single-GPU test
+            blk = blk.cpu()                                         # of the N > 1 path): gloo gathers host tensors
         blocks = [torch.empty_like(blk) for _ in range(world)]
         dist.all_gather(blocks, blk, group=group)
+        blocks = [b.to(dev) for b in blocks]
     out = []
     for b in blocks:
         out.append([b[i, :, : int(b[i, 0, t_max])].to(torch.int64) for i in range(b.shape[0]) if int(b[i, 0, t_max]) >= 0])

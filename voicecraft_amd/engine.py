@@ -429,6 +429,17 @@ class VoiceCraftEngine:
         return out
 
     # ------------------------------------------------------------------ measurement hooks
+    def set_option(self, name: str, value) -> None:
+        """Run-time launch-shape option of the decode step (include/vc_engine.h vc_set_option), e.g. ("attn_pf", "0") or
+        ("attn_pf", "8,0,32").  Results do not depend on it; bench.py --ab toggles one inside a process."""
+        check(self.lib.vc_set_option(self._h, str(name).encode(), str(value).encode()), self._h, f"vc_set_option({name})")
+
+    def options(self) -> str:
+        """The engine's option state as text: apf = attention-launch prefetch (slices, out-proj KB, FFN-up KB), lpf = LayerNorm-
+        launch prefetch (workgroups, QKV KB, FFN-up KB), g = steps per graph, ls = ln_split_rows, ab = attention workgroups aimed
+        at (several rows, one row), nt, fr = finished-row form up to this many rows."""
+        return bytes(self.debug_read("options", (256,), torch.uint8).tolist()).split(b"\0")[0].decode()
+
     def last_timing_ms(self):
         ms = (C.c_float * 3)()
         check(self.lib.vc_last_timing(self._h, ms), self._h, "vc_last_timing")
@@ -441,7 +452,7 @@ class VoiceCraftEngine:
         return ms.value, nbytes.value
 
     LAUNCH_FORMS = ("rows_gemm", "mt2", "mt4", "blk64", "blk128_sbs", "blk128_2x2", "blk64_occ2", "ln_rows", "rows_attn",
-                    "tile_attn", "persist", "big256", "big128")
+                    "tile_attn", "rows_gemm_fr", "big256", "big128")
 
     def launch_counts(self) -> dict:
         """Process-wide census of the kernel FORMS launched so far (vc_common.h VC_LC_*): the parity tests take the
