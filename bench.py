@@ -456,7 +456,9 @@ def main():
         for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
             ms_, by_ = eng.bench_kernel(kn, n_rows=mb_rows, iters=64)
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
-        roof = {"bound": "hbm", "kernel": "rows_gemm_k<plain,split-K slabs> (FFN down-projection)",
+        fr_form = 2 <= mb_rows <= 8 and "|fr0" not in eng.options()       # several-row steps: the finished-row producer is what runs
+        roof = {"bound": "hbm", "kernel": ("rows_gemm_fr_k<plain> (FFN down-projection, finished rows: 8-channel tiles over the whole K)" if fr_form
+                                           else "rows_gemm_k<plain,split-K slabs> (FFN down-projection)"),
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn2", args),
                 "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}

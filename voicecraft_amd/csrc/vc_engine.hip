@@ -1623,6 +1623,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   RowSrc rs{};
   rs.h_in = e->dec_h; rs.row_seq = e->dec_row_seq; rs.row_pos = e->dec_row_pos;
   rs.n_rows = n_rows; rs.nsplit = attn_nsplit(e, n_rows); rs.nt = 1;
+  if (n_rows >= 2 && n_rows <= fr_max_rows(e)) rs.nsplit = fr_nsplit(e, n_rows);
   bool hot = false;
   std::string w2 = w;
   if (w.size() > 4 && w.substr(w.size() - 4) == "_hot") { hot = true; w2 = w.substr(0, w.size() - 4); }
@@ -1630,6 +1631,28 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
     const bool split_ln = n_rows >= e->ln_split_rows;   // the engine then normalises in ln_rows_k and takes the plain prologue
+    if (n_rows >= 2 && n_rows <= fr_max_rows(e) && (w == "ffn1" || w == "ffn2" || w == "qkv" || w == "oproj")) {
+      // the forms a step of this many rows really launches (forward_rows_fr): finished rows in, finished rows out
+      if (w == "ffn1") {
+        GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
+        g.Wp = ly.W1; g.bias = ly.b1; g.wg = ly.wg_1; g.h_in = e->hA; g.out = e->act; g.out_ld = 4 * d;
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
+      } else if (w == "qkv") {
+        GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
+        g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.wg = ly.wg_qkv; g.h_in = e->hB; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
+      } else if (w == "ffn2") {
+        GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
+        g.Wp = ly.W28; g.bias = ly.b2; g.x_in = e->act; g.x_ld = 4 * d; g.h_in = e->hA; g.h_out = e->hB;
+        HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
+      } else {
+        GemmArgs g = base_args(e, rs, e->p_o, d, d);
+        g.Wp = ly.Wo8; g.bias = ly.bo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = fr_nsplit(e, n_rows);
+        g.h_in = e->hB; g.h_out = e->hA;
+        HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s));
+      }
+      return VC_OK;
+    }
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;

@@ -270,7 +270,7 @@ class VoiceCraftEngine:
 
     # ---- the training objective, teacher-forced
     @torch.no_grad()
-    def forward(self, batch, mask_intervals, mask_values=None, _per_row: bool = False):
+    def forward(self, batch, mask_intervals=None, mask_values=None, _per_row: bool = False):
         """`VoiceCraft.forward` (models/voicecraft.py:472-559) as an evaluation pass: batch = {"x" [B,Lx], "x_lens" [B],
         "y" [B,K,T], "y_lens" [B]} exactly as the reference's collate gives it; returns the reference's dict
         (`loss` = sum over codebooks of weight * summed cross-entropy, `top10acc`, `top10acc_by_codebook`,
@@ -280,6 +280,12 @@ class VoiceCraftEngine:
         shuffles them when `shuffle_mask_embedding` is set).  No gradients: this engine does not train."""
         import ast
         import random
+        if mask_intervals is None:
+            # `model(batch)` of the reference draws the spans itself (prepare_mask_intervals, models/voicecraft.py:198-237: random
+            # training-time augmentation).  That sampler is deliberately not part of this engine; say so instead of failing later
+            raise TypeError("VoiceCraftEngine.forward(batch, mask_intervals): the masked spans are an argument here - pass one list of "
+                            "(start, end) frame pairs per utterance (the reference samples them inside prepare_mask_intervals, which "
+                            "this inference engine does not reproduce)")
         x, x_lens, y, y_lens = batch["x"], batch["x_lens"], batch["y"], batch["y_lens"]
         if len(x) == 0:
             return None
