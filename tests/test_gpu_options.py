@@ -44,14 +44,15 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256, use_graph=False)
     L = a.num_decoder_layers
     got = {}
-    for mode in ("on", "off"):
-        eng.set_option("finished_rows", 8 if mode == "on" else 0)
-        assert ("fr8" if mode == "on" else "fr0") in eng.options()
+    for mode in ("on", "on1", "off"):              # on: two weight tiles per consumer workgroup (the default); on1: one
+        eng.set_option("finished_rows", 0 if mode == "off" else 8)
+        eng.set_option("lnw_tiles", 1 if mode == "on1" else 2)
+        assert ("fr0" if mode == "off" else "fr8") in eng.options()
         c0 = eng.launch_counts()
         outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3,
                                            _forced=forced, _logit_steps=n)
         c = _delta(eng.launch_counts(), c0)
-        if mode == "on":
+        if mode != "off":
             assert c["rows_gemm_fr"] >= 2 * L * (n - 1), c           # (the first of the n samples comes from the prefill's logits)
         else:
             assert c["rows_gemm_fr"] == 0 and (B < 3 or c["ln_rows"] >= 2 * L * (n - 1)), c
@@ -64,6 +65,7 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
         assert worst <= 2e-2, (mode, worst)
         got[mode] = lg
     assert np.abs(got["on"] - got["off"])[np.abs(got["off"]) < 1e3].max() < 0.25      # two roundings of the same numbers
+    assert np.array_equal(got["on"], got["on1"])               # one or two tiles per workgroup: the same sums in the same order
 
 
 @pytest.mark.parametrize("preset,B", [("tiny_h16", 2), ("tiny_h16", 4), ("tiny128", 3)])

@@ -244,7 +244,8 @@ struct GemmArgs {
   int r_lds;                // rows of X staged in LDS (<= VC_ROWS)
   int rows_cap;             // row stride of the split-K slabs: parts[s][rows_cap][N]
   int nt;                   // 1: stream the weights with non-temporal loads
-  int mt;                   // 1: prefill pass (rows_gemm_blk_k): n_rows may reach VC_MAX_ROWS, plain prologue only
+  int mt;                   // 1: prefill pass (rows_gemm_blk_k): n_rows may reach VC_MAX_ROWS, plain prologue only; 2: wide decode pass
+                            // (rows_gemm_mt_k); 3: PRO_LNW with two weight tiles per workgroup (rows_gemm_k<..., NTW = 2>)
   long w_group_stride;      // in uint4 units
   int bias_group_stride;
   // rows
@@ -384,6 +385,10 @@ struct SampleArgs {         // engine-constant part (kernel argument)
   const float* pe;
   float alpha_audio;
   int max_positions;
+  // sample_fused_k only: pf_blocks extra workgroups pull the head of the NEXT step's first weight matrix (layer 0's QKV tiles)
+  // into the L2 of the XCD that will read them while the sampler - one latency-bound workgroup per sequence - runs; 0 = none
+  PfSeg pf;
+  int pf_blocks;
 };
 
 struct AssembleArgs {       // writes res [K][res_cap] from y and the generated spans

@@ -100,9 +100,13 @@ struct vc_engine {
   // Measured (profiles/r03i_ln_prefetch_sweep.log): whole matrices LOSE (8 rows 0.911 -> 0.924-0.950 ms: the 4.9 us launch grows by
   // the 5 us the 25 MB take), the first 24 KB of every tile gain 1-2 % (0.857-0.863 -> 0.844).
   int lpf_blocks = 248, lpf_qkv_kb = 24, lpf_w1_kb = 24;
+  // the same on the sampler launch (one workgroup per sequence, ~15 us, HBM idle): VC_SAMP_PF=blocks[,qkv_kb] - the head of layer 0's
+  // QKV tiles for the NEXT step; 0 = off (the default until an in-process A/B shows a gain beyond its spread: bench.py --ab samp_pf=...)
+  int spf_blocks = 0, spf_qkv_kb = 24;
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
   // finished-row form of decode passes of 2..fr_rows rows (forward_rows_fr): 0 = off.  VC_FINISHED_ROWS / option "finished_rows"
   int fr_rows = VC_FR_MAX_ROWS;
+  int lnw_tiles = 2;                    // weight tiles per workgroup of the finished-row consumers (QKV, FFN-up): 1 or 2; option "lnw_tiles"
   int attn_blocks_multi = 512, attn_blocks_one = 256;   // VC_ATTN_BLOCKS / VC_ATTN_BLOCKS1: attention workgroups aimed at (several rows / one row)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
@@ -299,6 +303,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.wg = ly.wg_qkv;
       g.h_in = h_res;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      g.mt = e->lnw_tiles == 2 ? 3 : 0;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
     }
     {
@@ -325,6 +330,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.W1; g.bias = ly.b1; g.wg = ly.wg_1;
       g.h_in = e->hA;
       g.out = e->act; g.out_ld = 4 * d;
+      g.mt = e->lnw_tiles == 2 ? 3 : 0;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
     }
     {  // h'' = h' + b2 + W2 a
@@ -621,6 +627,11 @@ SampleArgs make_sample_args(vc_engine* e, int B, int rps) {
   a.logit_row = e->logit_row;
   a.audio_emb = e->audio_emb; a.mask_emb = e->mask_emb; a.pe = e->pe; a.alpha_audio = e->alpha_audio;
   a.max_positions = e->S_max;
+  if (e->spf_blocks > 0 && B * rps <= VC_ROWS && e->p_qkv.n_tiles % 8 == 0) {     // (wider steps read several tiles per workgroup)
+    const int tile_b = (e->d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * VC_TH_QKV;
+    a.pf = PfSeg{(const char*)e->layers[0].Wqkv, e->p_qkv.n_tiles, tile_b, std::min(tile_b, e->spf_qkv_kb * 1024), 1};
+    a.pf_blocks = e->spf_blocks;
+  }
   return a;
 }
 
@@ -777,10 +788,14 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->lpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->lpf_qkv_kb = std::max(0, v1);
     if (n >= 3) e->lpf_w1_kb = std::max(0, v2);
+  } else if (name == "samp_pf") {     // workgroups[,QKV KB] of the sampler launch's prefetch role (next step's first matrix); 0 = off
+    e->spf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
+    if (n >= 2) e->spf_qkv_kb = std::max(0, v1);
   } else if (name == "graph_steps") { e->steps_per_graph = std::max(1, std::min(64, v0));
   } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
   } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
   } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
+  } else if (name == "lnw_tiles") { e->lnw_tiles = v0 >= 2 ? 2 : 1;
   } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_FR_MAX_ROWS));
   } else if (name == "nt") { e->nt_decode = v0 ? 1 : 0;
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
@@ -792,8 +807,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d|fr%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
-           e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi, e->attn_blocks_one, e->nt_decode, e->fr_rows);
+  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|spf%d,%d|g%d|ls%d|ab%d,%d|nt%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
+           e->lpf_qkv_kb, e->lpf_w1_kb, e->spf_blocks, e->spf_qkv_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
+           e->attn_blocks_one, e->nt_decode, e->fr_rows, e->lnw_tiles);
   e->opt_state = buf;
 }
 
@@ -1050,7 +1066,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), std::make_pair("VC_LN_SPLIT_ROWS", "ln_split_rows"),
                          std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
-                         std::make_pair("VC_FINISHED_ROWS", "finished_rows")})
+                         std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_SAMP_PF", "samp_pf")})
     if (const char* v = getenv(kv.first))
       if ((rc = apply_option(e, kv.second, v))) return rc;
   refresh_opt_state(e);
@@ -1636,10 +1652,12 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       if (w == "ffn1") {
         GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
         g.Wp = ly.W1; g.bias = ly.b1; g.wg = ly.wg_1; g.h_in = e->hA; g.out = e->act; g.out_ld = 4 * d;
+        g.mt = e->lnw_tiles == 2 ? 3 : 0;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
       } else if (w == "qkv") {
         GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
         g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.wg = ly.wg_qkv; g.h_in = e->hB; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+        g.mt = e->lnw_tiles == 2 ? 3 : 0;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
       } else if (w == "ffn2") {
         GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);

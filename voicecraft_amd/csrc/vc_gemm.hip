@@ -305,16 +305,24 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT
 // behind from a wave-uniform base (SGPR addressing: no per-load VALU address arithmetic, no register
 // reuse that would make the compiler wait mid-burst); (3) a scheduling barrier keeps the prologue
 // arithmetic from being hoisted into the burst; (4) only then is anything waited for.
-template <typename WT, int KTW, int PRO, int EPI>
-__global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
+// NTW = 2 (PRO_LNW only): TWO weight tiles per workgroup, 8 waves - waves 0..3 stream tile 2x, waves 4..7 tile 2x + 1 - sharing ONE
+// staged copy of the rows.  The finished-row LayerNorm prologue reads 8 rows x 8 KB of fp32 h per workgroup out of L2: with
+// one tile per workgroup that is 33.5 MB per launch, as much as the weight stream itself (measured: QKV 6.9 -> 9.1 us, FFN-up
+// 7.0 -> 9.5 us against the plain prologue); two tiles halve it, and each of the 8 waves folds exactly one row.
+template <typename WT, int KTW, int PRO, int EPI, int NTW = 1>
+__global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
+  static_assert(NTW == 1 || PRO == PRO_LNW, "two tiles per workgroup: finished-row consumers only");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   VC_KTS_DECL();
   VC_KTS(0);
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nt = blockIdx.x, ks = blockIdx.y, grp = blockIdx.z;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = (NTW == 1) ? wv : (wv & 3);    // K quarter of the tile
+  const int tg = (NTW == 1) ? 0 : (wv >> 2);      // which of the workgroup's tiles
+  const int nt = (NTW == 1) ? (int)blockIdx.x : (int)blockIdx.x * NTW + tg;
+  const int ks = blockIdx.y, grp = blockIdx.z;
   const int n_rows = a.n_rows;                    // >= 1 (host contract)
   const int kt_blk = a.nchunk * 4 * KTW;          // k-tiles this block covers
   const int kt0 = ks * kt_blk;                    // first of them
@@ -322,8 +330,9 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
   const int k0 = kt0 * T::KW;
   const int xs = kblk * (int)sizeof(WT) + 16;     // LDS row stride in bytes (+16: rotate bank slots)
   char* xl = smem;
-  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
-  float* stat = reinterpret_cast<float*>(red + 256);      // LN prologue: [row][wave][sum, sum of squares] of the centred, rounded row
+  f32x4* red0 = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
+  f32x4* red = red0 + tg * 256;
+  float* stat = reinterpret_cast<float*>(red0 + 256 * NTW);      // LN prologue: [row][wave][sum, sum of squares] of the centred, rounded row
   float* msum = stat + VC_ROWS * 4 * 2;                   // LN prologue: [row][wave] partial sums of the fp32 row (its mean)
 
   // Tile height: the QKV projection (N = 3d) uses 12-channel tiles, so that its 3d/12 = d/4 tiles are
@@ -460,14 +469,16 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
     // row in every workgroup - 20 us per GEMM at 8 rows - which is why several-row steps used a separate LayerNorm launch.)
     const int d = a.d;
     const int npl = d >> 8;                                 // float4 per lane and row: d / 4 / 64 = 1..8 (d % 256 == 0)
-    const float* hrA = a.h_in + (long)min(wave, n_rows - 1) * d;
-    const float* hrB = a.h_in + (long)min(wave + 4, n_rows - 1) * d;
+    const int rowA = (NTW == 1) ? wave : wv;                // (two tiles per workgroup: 8 waves, one row each)
+    const int rowB = (NTW == 1) ? wave + 4 : VC_ROWS;
+    const float* hrA = a.h_in + (long)min(rowA, n_rows - 1) * d;
+    const float* hrB = a.h_in + (long)min(rowB, n_rows - 1) * d;
     float4 xa[8], xb[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int c = (min(j, npl - 1) * 64 + lane) * 4;
       xa[j] = *reinterpret_cast<const float4*>(hrA + c);
-      xb[j] = *reinterpret_cast<const float4*>(hrB + c);
+      if constexpr (NTW == 1) xb[j] = *reinterpret_cast<const float4*>(hrB + c);
     }
     VC_ISSUE_WEIGHTS(0);
     VC_BURST_OUT();
@@ -493,8 +504,8 @@ __global__ __launch_bounds__(256) void rows_gemm_k(const GemmArgs a) {
         *reinterpret_cast<float4*>(stat + (r) * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);        \
       }                                                                                          \
     }
-    VC_LNW_ROW(xa, wave);
-    VC_LNW_ROW(xb, wave + 4);
+    VC_LNW_ROW(xa, rowA);
+    if constexpr (NTW == 1) { VC_LNW_ROW(xb, rowB); }
 #undef VC_LNW_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
     // X rows copied as 16-byte units, flat index = row * upr + unit.  The first NB*256 units are
@@ -1490,10 +1501,10 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4) + VC_ROWS * 4 * 3 * sizeof(float);   // X rows, K-reduce area, LN statistics + row means
 }
 
-template <typename WT, int KTW, int PRO, int EPI>
+template <typename WT, int KTW, int PRO, int EPI, int NTW = 1>
 static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI>;
-  const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit);
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW>;
+  const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit) + (size_t)(NTW - 1) * 4 * 64 * sizeof(f32x4);
   if (lds > 64 * 1024) {
     static size_t granted[16] = {0};   // per instantiation and device
     int dev = 0;
@@ -1518,7 +1529,7 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
     }
   }
   ++vc_launch_counts[VC_LC_ROWS_GEMM];
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles, ksplit, groups), dim3(256), lds, s, b);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles / NTW, ksplit, groups), dim3(256 * NTW), lds, s, b);
   return hipGetLastError();
 }
 
@@ -1634,6 +1645,10 @@ static hipError_t launch_ktw(const GemmArgs& a, int dtype, int pro, int epi, int
   if (pro == PRO_LN && epi == EPI_QKV) return launch_one<WT, KTW, PRO_LN, EPI_QKV>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LN && epi == EPI_RELU) return launch_one<WT, KTW, PRO_LN, EPI_RELU>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LN && epi == EPI_GELU) return launch_one<WT, KTW, PRO_LN, EPI_GELU>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_LNW && a.mt == 3 && a.n_tiles % 2 == 0 && groups == 1) {     // two tiles per workgroup (finished-row consumers, GemmArgs.mt)
+    if (epi == EPI_QKV) return launch_dec<WT, KTW, PRO_LNW, EPI_QKV, 2>(a, dtype, ksplit, groups, s);
+    if (epi == EPI_RELU) return launch_dec<WT, KTW, PRO_LNW, EPI_RELU, 2>(a, dtype, ksplit, groups, s);
+  }
   if (pro == PRO_LNW && epi == EPI_QKV) return launch_dec<WT, KTW, PRO_LNW, EPI_QKV>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LNW && epi == EPI_RELU) return launch_dec<WT, KTW, PRO_LNW, EPI_RELU>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LNW && epi == EPI_GELU) return launch_dec<WT, KTW, PRO_LNW, EPI_GELU>(a, dtype, ksplit, groups, s);
