@@ -55,9 +55,10 @@ def parse():
     p.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                    help="collective backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host collectives, usable when "
                         "several ranks share ONE GPU (VC_RANKS_SHARE_DEVICE=1: the single-GPU test of the N > 1 code path)")
-    p.add_argument("--ab", default=None, metavar="KNOB=A:B",
+    p.add_argument("--ab", default="auto", metavar="KNOB=A:B",
                    help="in-process A/B of one engine option (vc_set_option), e.g. attn_pf=0:8,0,32 - interleaved pairs of whole calls, "
-                        "reported as the `ab` object of the JSON line")
+                        "reported as the `ab` object of the JSON line.  auto (default, N = 1 only): the default-ON launch-shape feature "
+                        "of this run's step - attn_pf=0:8,0,32 at one row per step, finished_rows=0:8 at 2..8 rows; none: skip")
     p.add_argument("--ab-pairs", type=int, default=7)
     return p.parse_args()
 
@@ -507,8 +508,14 @@ def main():
                 out["one_sample"] = one_sample_block(eng, a, dev, args)
             except Exception as e:   # reporting only
                 out["one_sample"] = {"error": str(e)}
-        if n_gpus == 1 and args.ab:
-            out["ab"] = ab_block(eng, one_step, args.ab, max(3, args.ab_pairs))
+        ab = args.ab
+        if ab == "auto":       # every default-ON feature has to show its gain in the line the driver records
+            ab = ("attn_pf=0:8,0,32" if B == 1 else "finished_rows=0:8" if B <= 8 else "none") if not edit else "attn_pf=0:8,0,32"
+        if n_gpus == 1 and ab and ab != "none":
+            try:
+                out["ab"] = ab_block(eng, one_step, ab, max(3, args.ab_pairs))
+            except Exception as e:   # reporting only
+                out["ab"] = {"error": str(e)}
         if n_gpus == 1 and not args.no_codec:
             try:
                 out["codec"] = codec_block(dev)

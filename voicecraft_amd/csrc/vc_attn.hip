@@ -38,6 +38,7 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 // leading bytes of up to two matrices' tiles (vc_common.h vc_prefetch_tiles).
 __device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  for (int i = 0; i < a.pf_delay; ++i) __builtin_amdgcn_s_sleep(4);      // ~256 clocks each
   vc_prefetch_tiles(a.pf, 2, lin, gridDim.x * gridDim.y * (unsigned)a.nsplit, gridDim.x * gridDim.y * (unsigned)a.pf_z);
 }
 

@@ -311,6 +311,8 @@ struct AttnArgs {
   // weight tiles into the L2 of the XCD whose workgroups will read them (vc_attn.hip, "piggyback prefetch"); 0 = none
   PfSeg pf[2];
   int pf_z;
+  int pf_delay;             // prefetch workgroups first sleep pf_delay x ~0.1 us, so that the attention workgroups' own K/V requests go out
+                            // into an idle memory system and the prefetch traffic overlaps their arithmetic / merge tail instead
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence
@@ -385,10 +387,6 @@ struct SampleArgs {         // engine-constant part (kernel argument)
   const float* pe;
   float alpha_audio;
   int max_positions;
-  // sample_fused_k only: pf_blocks extra workgroups pull the head of the NEXT step's first weight matrix (layer 0's QKV tiles)
-  // into the L2 of the XCD that will read them while the sampler - one latency-bound workgroup per sequence - runs; 0 = none
-  PfSeg pf;
-  int pf_blocks;
 };
 
 struct AssembleArgs {       // writes res [K][res_cap] from y and the generated spans

@@ -89,24 +89,29 @@ struct vc_engine {
   hipEvent_t ev_pace[2]{};
 
   hipStream_t own_stream = nullptr;     // used when the caller passes the null stream (not capturable)
-  int nt_decode = 1;                    // VC_NT=0 disables non-temporal weight loads in the decode step
+  // Non-temporal weight loads of the decode kernels, per matrix: bit 0 QKV, 1 out-projection, 2 FFN-up, 3 FFN-down, 4 heads-1, 5 heads-2.
+  // Option "nt" (VC_NT).  Until round 4 the compiled QKV / out-projection / heads-2 kernels carried NO such load whatever this said (the
+  // compiler merged the kernel's two load arms and dropped the hint): 28 reproduces that mix, 63 = every matrix (default), 0 = none.
+  int nt_decode = 63;
   // piggyback weight prefetch of the one-row attention launch (vc_attn.hip prefetch_role): VC_ATTN_PF=z[,wo_kb[,w1_kb]], 0 = off.
   // Measured (profiles/r03g_attn_prefetch_sweep.log): 8 slices x the first 32 KB of every FFN-up tile 0.598 -> 0.589 ms per step;
   // the out-projection's own matrix gains nothing (that launch waits for the attention partials, not for its weights),
   // 48-64 KB per tile or 4 slices lose (the attention launch ends with its slowest prefetcher).
-  int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = 32;
+  int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = 32, apf_delay = 0;
   // the same for several-row decode steps, carried by the per-row LayerNorm launches (8 workgroups, 4.9 us each, HBM idle):
   // VC_LN_PF=blocks[,qkv_kb[,w1_kb]] - LN1 prefetches the QKV matrix, LN2 the FFN-up matrix of the same layer; 0 = off
   // Measured (profiles/r03i_ln_prefetch_sweep.log): whole matrices LOSE (8 rows 0.911 -> 0.924-0.950 ms: the 4.9 us launch grows by
   // the 5 us the 25 MB take), the first 24 KB of every tile gain 1-2 % (0.857-0.863 -> 0.844).
   int lpf_blocks = 248, lpf_qkv_kb = 24, lpf_w1_kb = 24;
-  // the same on the sampler launch (one workgroup per sequence, ~15 us, HBM idle): VC_SAMP_PF=blocks[,qkv_kb] - the head of layer 0's
-  // QKV tiles for the NEXT step; 0 = off (the default until an in-process A/B shows a gain beyond its spread: bench.py --ab samp_pf=...)
-  int spf_blocks = 0, spf_qkv_kb = 24;
+  // (the same on the sampler launch - next step's layer-0 QKV tiles - was built and measured in round 4: 248 x 24 KB +0.01 %, 248 x 40 KB
+  // +0.10 %, 504 x 24 KB -0.35 % +- 0.17 at giga830M, +0.25 % at giga330M in in-process A/Bs, profiles/r04b_bench_spf_*: not carried)
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
   // finished-row form of decode passes of 2..fr_rows rows (forward_rows_fr): 0 = off.  VC_FINISHED_ROWS / option "finished_rows"
   int fr_rows = VC_FR_MAX_ROWS;
-  int lnw_tiles = 2;                    // weight tiles per workgroup of the finished-row consumers (QKV, FFN-up): 1 or 2; option "lnw_tiles"
+  // weight tiles per workgroup of the finished-row consumers (QKV, FFN-up); option "lnw_tiles": 1, 2, or 0 = by row count - two
+  // from 5 rows up (in-process A/Bs, profiles/r04b_bench_batch*.json.log: 8 rows -3.4 % +- 0.1 with two, 4 rows +0.5 % +- 0.05:
+  // there half of the 8 waves have no row to fold)
+  int lnw_tiles = 0;
   int attn_blocks_multi = 512, attn_blocks_one = 256;   // VC_ATTN_BLOCKS / VC_ATTN_BLOCKS1: attention workgroups aimed at (several rows / one row)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
@@ -261,12 +266,15 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.rows_cap = VC_SLAB_ROWS;
   g.row_seq = rs.row_seq; g.row_pos = rs.row_pos; g.n_rows = rs.n_rows;
   g.n_active = rs.n_active ? rs.n_active : e->one;
-  g.nt = (rs.n_active != nullptr || rs.nt) ? e->nt_decode : 0;   // decode steps (and the kernel microbenchmarks) stream once
+  g.nt = (rs.n_active != nullptr || rs.nt) ? 1 : 0;   // decode steps (and the kernel microbenchmarks) stream once; per matrix: nt_bit
   g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
   return g;
 }
+
+enum { NT_QKV = 1, NT_O = 2, NT_F1 = 4, NT_F2 = 8, NT_H1 = 16, NT_H2 = 32 };
+inline void nt_bit(const vc_engine* e, GemmArgs& g, int bit) { if (!(e->nt_decode & bit)) g.nt = 0; }
 
 int attn_nsplit(vc_engine* e, int rows) {
   // 8-wave blocks: one decode row is covered by ~256 of them; several rows get ~512 (two per CU), which
@@ -282,6 +290,7 @@ int fr_max_rows(const vc_engine* e) {
   while (r >= 2 && vc_gemm_fr_lds_bytes(r, 4 * e->d, e->dtype) > 150 * 1024) --r;
   return r >= 2 ? r : 0;
 }
+bool lnw_two(const vc_engine* e, int rows) { return e->lnw_tiles == 2 || (e->lnw_tiles == 0 && rows >= 5); }
 int fr_nsplit(vc_engine* e, int rows) {
   int ns = std::min(attn_nsplit(e, rows), 16 / rows);
   int p = 1;
@@ -300,10 +309,10 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     const float* h_res = (l == 0) ? rs.h_in : e->hB;      // residual entering the layer
     {  // q,k,v = Wqkv LN1(h) + b ; K/V go straight into the cache
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
-      g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.wg = ly.wg_qkv;
+      g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.wg = ly.wg_qkv;
       g.h_in = h_res;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      g.mt = e->lnw_tiles == 2 ? 3 : 0;
+      g.mt = lnw_two(e, rs.n_rows) ? 3 : 0;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
     }
     {
@@ -327,10 +336,10 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     }
     {  // a = relu(W1 LN2(h') + b1)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
-      g.Wp = ly.W1; g.bias = ly.b1; g.wg = ly.wg_1;
+      g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.wg = ly.wg_1;
       g.h_in = e->hA;
       g.out = e->act; g.out_ld = 4 * d;
-      g.mt = e->lnw_tiles == 2 ? 3 : 0;
+      g.mt = lnw_two(e, rs.n_rows) ? 3 : 0;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
     }
     {  // h'' = h' + b2 + W2 a
@@ -362,7 +371,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     Layer& ly = e->layers[l];
     {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
-      g.Wp = ly.Wqkv; g.bias = ly.bqkv;
+      g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv;
       g.h_in = (l == 0) ? rs.h_in : e->hB;
       g.h_out = e->hA;
       g.parts = e->parts;
@@ -401,7 +410,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         // the XCD that will read them (prefetch_role)
         const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
         const int tile_b = (d / KW) * 64 * 16;                 // out-projection and FFN-up tiles: 16 channels x d
-        a.pf_z = e->apf_z;
+        a.pf_z = e->apf_z; a.pf_delay = e->apf_delay;
         a.pf[0] = PfSeg{(const char*)ly.Wo, e->p_o.n_tiles, tile_b, std::min(tile_b, e->apf_wo_kb * 1024), 1};
         a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->apf_w1_kb * 1024), 1};
       }
@@ -409,14 +418,14 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     }
     {  // out-projection of the merged attention output -> split-K partial slabs
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
-      g.Wp = ly.Wo;
+      g.Wp = ly.Wo; nt_bit(e, g, NT_O);
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
-      g.Wp = ly.W1; g.bias = ly.b1;
+      g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1;
       g.h_in = e->hA; g.h_out = e->hB;
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.wg = ly.wg_1;
@@ -438,7 +447,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     }
     {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
-      g.Wp = ly.W2;
+      g.Wp = ly.W2; nt_bit(e, g, NT_F2);
       g.x_in = e->act; g.x_ld = 4 * d;
       g.part_out = e->parts;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
@@ -455,7 +464,7 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
   rs.n_rows = n; rs.n_active = n_active;
   {  //                                                                   
     GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
-    g.Wp = e->Wh1; g.bias = e->bh1;
+    g.Wp = e->Wh1; nt_bit(e, g, NT_H1); g.bias = e->bh1;
     g.h_in = e->hB + (size_t)in_row0 * e->d; g.h_out = nullptr;
     g.parts = e->parts + (size_t)in_row0 * e->d; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     if (e->finished_rows_h) { g.n_parts = 0; g.has_prev_bias = 0; }       // the finished-row form left the whole residual in hB
@@ -474,7 +483,7 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
   }
   {  //                                                                          
     GemmArgs g = base_args(e, rs, e->p_h2, e->V, e->P);
-    g.Wp = e->Wh2; g.bias = e->bh2;
+    g.Wp = e->Wh2; nt_bit(e, g, NT_H2); g.bias = e->bh2;
     g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
     g.x_in = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits + (size_t)out_row0 * e->K * e->V;
@@ -509,7 +518,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       // (no piggyback prefetch on the LayerNorm launches of WIDE decode passes: measured at 32 rows with the tiles grouped as
       // rows_gemm_mt_k reads them, PfSeg.sub = 4 - 1.428-1.437 -> 1.454 ms per step, profiles/r03j_lpf32_ab.log)
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
-      g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = mtv;
+      g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = mtv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
     }
@@ -526,7 +535,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     }
     {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
-      g.Wp = ly.Wo; g.part_out = e->parts; g.mt = mtv;
+      g.Wp = ly.Wo; nt_bit(e, g, NT_O); g.part_out = e->parts; g.mt = mtv;
       if (rs.nsplit == 1) {
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_o.ksplit, 1, s));
@@ -540,12 +549,12 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.x_out = e->xn;
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
-      g.Wp = ly.W1; g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = mtv;
+      g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = mtv;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
     }
     {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
-      g.Wp = ly.W2; g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts; g.mt = mtv;
+      g.Wp = ly.W2; nt_bit(e, g, NT_F2); g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts; g.mt = mtv;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     }
   }
@@ -627,11 +636,6 @@ SampleArgs make_sample_args(vc_engine* e, int B, int rps) {
   a.logit_row = e->logit_row;
   a.audio_emb = e->audio_emb; a.mask_emb = e->mask_emb; a.pe = e->pe; a.alpha_audio = e->alpha_audio;
   a.max_positions = e->S_max;
-  if (e->spf_blocks > 0 && B * rps <= VC_ROWS && e->p_qkv.n_tiles % 8 == 0) {     // (wider steps read several tiles per workgroup)
-    const int tile_b = (e->d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * VC_TH_QKV;
-    a.pf = PfSeg{(const char*)e->layers[0].Wqkv, e->p_qkv.n_tiles, tile_b, std::min(tile_b, e->spf_qkv_kb * 1024), 1};
-    a.pf_blocks = e->spf_blocks;
-  }
   return a;
 }
 
@@ -777,27 +781,25 @@ int check_err_flag(vc_engine* e, hipStream_t s) {
 
 // One option by name (vc_set_option, and the VC_* environment variables at creation).
 int apply_option(vc_engine* e, const std::string& name, const char* value) {
-  int v0 = 0, v1 = 0, v2 = 0;
-  const int n = sscanf(value ? value : "", "%d,%d,%d", &v0, &v1, &v2);
+  int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+  const int n = sscanf(value ? value : "", "%d,%d,%d,%d", &v0, &v1, &v2, &v3);
   if (n < 1) return fail(e, VC_EINVAL, "option '%s': '%s' is not a number list", name.c_str(), value ? value : "(null)");
   if (name == "attn_pf") {            // slices[,out-projection KB[,FFN-up KB]] of the one-row attention launch's prefetch role; 0 = off
     e->apf_z = std::max(0, std::min(v0, 16));
     if (n >= 2) e->apf_wo_kb = std::max(0, v1);
     if (n >= 3) e->apf_w1_kb = std::max(0, v2);
+    e->apf_delay = n >= 4 ? std::max(0, std::min(v3, 64)) : 0;      // [,delay in ~0.1 us units before the prefetch workgroups start]
   } else if (name == "ln_pf") {       // workgroups[,QKV KB[,FFN-up KB]] of the LayerNorm launches' prefetch role (several-row steps); 0 = off
     e->lpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->lpf_qkv_kb = std::max(0, v1);
     if (n >= 3) e->lpf_w1_kb = std::max(0, v2);
-  } else if (name == "samp_pf") {     // workgroups[,QKV KB] of the sampler launch's prefetch role (next step's first matrix); 0 = off
-    e->spf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
-    if (n >= 2) e->spf_qkv_kb = std::max(0, v1);
   } else if (name == "graph_steps") { e->steps_per_graph = std::max(1, std::min(64, v0));
   } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
   } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
   } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
-  } else if (name == "lnw_tiles") { e->lnw_tiles = v0 >= 2 ? 2 : 1;
+  } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
   } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_FR_MAX_ROWS));
-  } else if (name == "nt") { e->nt_decode = v0 ? 1 : 0;
+  } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
   } else {
     return fail(e, VC_EINVAL, "unknown option '%s'", name.c_str());
@@ -807,8 +809,8 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|spf%d,%d|g%d|ls%d|ab%d,%d|nt%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
-           e->lpf_qkv_kb, e->lpf_w1_kb, e->spf_blocks, e->spf_qkv_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_delay, e->lpf_blocks,
+           e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->fr_rows, e->lnw_tiles);
   e->opt_state = buf;
 }
@@ -1066,7 +1068,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), std::make_pair("VC_LN_SPLIT_ROWS", "ln_split_rows"),
                          std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
-                         std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_SAMP_PF", "samp_pf")})
+                         std::make_pair("VC_FINISHED_ROWS", "finished_rows")})
     if (const char* v = getenv(kv.first))
       if ((rc = apply_option(e, kv.second, v))) return rc;
   refresh_opt_state(e);
@@ -1651,13 +1653,13 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       // the forms a step of this many rows really launches (forward_rows_fr): finished rows in, finished rows out
       if (w == "ffn1") {
         GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
-        g.Wp = ly.W1; g.bias = ly.b1; g.wg = ly.wg_1; g.h_in = e->hA; g.out = e->act; g.out_ld = 4 * d;
-        g.mt = e->lnw_tiles == 2 ? 3 : 0;
+        g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.wg = ly.wg_1; g.h_in = e->hA; g.out = e->act; g.out_ld = 4 * d;
+        g.mt = lnw_two(e, rs.n_rows) ? 3 : 0;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
       } else if (w == "qkv") {
         GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
-        g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.wg = ly.wg_qkv; g.h_in = e->hB; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-        g.mt = e->lnw_tiles == 2 ? 3 : 0;
+        g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.wg = ly.wg_qkv; g.h_in = e->hB; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+        g.mt = lnw_two(e, rs.n_rows) ? 3 : 0;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
       } else if (w == "ffn2") {
         GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
@@ -1673,23 +1675,23 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     }
     if (w == "ffn1") {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
-      g.Wp = ly.W1; g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
+      g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
       g.prev_bias = ly.bo; g.has_prev_bias = 1; g.wg = ly.wg_1; g.out = e->act; g.out_ld = 4 * d;
       if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s)); }
       else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
     } else if (w == "ffn2") {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
-      g.Wp = ly.W2; g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts;
+      g.Wp = ly.W2; nt_bit(e, g, NT_F2); g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     } else if (w == "qkv") {
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
-      g.Wp = ly.Wqkv; g.bias = ly.bqkv; g.h_in = e->hB; g.h_out = e->hA; g.parts = e->parts; g.n_parts = e->p_f2.ksplit;
+      g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.h_in = e->hB; g.h_out = e->hA; g.parts = e->parts; g.n_parts = e->p_f2.ksplit;
       g.prev_bias = ly.b2; g.has_prev_bias = 1; g.wg = ly.wg_qkv; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s)); }
       else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
     } else if (w == "oproj") {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
-      g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts;
+      g.Wp = ly.Wo; nt_bit(e, g, NT_O); g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     } else if (w == "attn") {
       AttnArgs a;
@@ -1701,7 +1703,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "pf_ffn1") {      // the prefill pass's FFN up-projection on the MFMA block GEMM (X = xn, n_rows rows)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
-      g.Wp = ly.W1; g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = 1;
+      g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = 1;
       const char* dbg_env = getenv("VC_BLK_DBG");        // tools/blk_probe.py: wrong results by design, timing only
       vc_blk_dbg_mask = dbg_env ? atoi(dbg_env) : 0;
       hipError_t le = vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s);

@@ -309,7 +309,10 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT
 // staged copy of the rows.  The finished-row LayerNorm prologue reads 8 rows x 8 KB of fp32 h per workgroup out of L2: with
 // one tile per workgroup that is 33.5 MB per launch, as much as the weight stream itself (measured: QKV 6.9 -> 9.1 us, FFN-up
 // 7.0 -> 9.5 us against the plain prologue); two tiles halve it, and each of the 8 waves folds exactly one row.
-template <typename WT, int KTW, int PRO, int EPI, int NTW = 1>
+// NT: the weight stream uses non-temporal loads (decode: every byte is read exactly once per launch).  A TEMPLATE parameter, not
+// the runtime flag it used to be: with both load arms in one kernel the compiler merged them and silently dropped the hint -
+// through round 3 the compiled QKV, out-projection and heads-2 forms had no non-temporal load at all, the FFN forms 15 of 16.
+template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true>
 __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   static_assert(NTW == 1 || PRO == PRO_LNW, "two tiles per workgroup: finished-row consumers only");
@@ -355,11 +358,10 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
 
   const uint4* wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * SPT;   // wave-uniform
   uint4 wf[KTW];
-  // a.nt: non-temporal loads for a weight stream that is read exactly once per launch (decode)
 #define VC_ISSUE_WEIGHTS(c_)                                                                     \
   {                                                                                              \
     const uint4* wb_ = wbase + (long)(c_) * (4 * KTW * SPT);                                      \
-    if (a.nt) {                                                                                  \
+    if constexpr (NT) {                                                                          \
       _Pragma("unroll") for (int i = 0; i < KTW; ++i)                                            \
         wf[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wb_ + i * SPT + wslot))); \
     } else {                                                                                     \
@@ -1501,9 +1503,9 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4) + VC_ROWS * 4 * 3 * sizeof(float);   // X rows, K-reduce area, LN statistics + row means
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int NTW = 1>
-static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW>;
+template <typename WT, int KTW, int PRO, int EPI, int NTW, bool NT>
+static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW, NT>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit) + (size_t)(NTW - 1) * 4 * 64 * sizeof(f32x4);
   if (lds > 64 * 1024) {
     static size_t granted[16] = {0};   // per instantiation and device
@@ -1531,6 +1533,12 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   ++vc_launch_counts[VC_LC_ROWS_GEMM];
   hipLaunchKernelGGL(kern, dim3(a.n_tiles / NTW, ksplit, groups), dim3(256 * NTW), lds, s, b);
   return hipGetLastError();
+}
+
+template <typename WT, int KTW, int PRO, int EPI, int NTW = 1>
+static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
+  if (a.nt) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true>(a, dtype, ksplit, groups, s);
+  return launch_dec_nt<WT, KTW, PRO, EPI, NTW, false>(a, dtype, ksplit, groups, s);
 }
 
 template <typename WT, int EPI, int NTW, int WM, int OCC = 1>

@@ -594,11 +594,6 @@ extern __shared__ __attribute__((aligned(16))) float s_dyn[];   // K rows of 64*
 __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   __shared__ SeqState s_st;
   __shared__ int s_xs[VC_MAX_CODEBOOKS + 2];
-  if ((int)blockIdx.x >= a.B) {          // piggyback prefetch role (vc_common.h): the sampler leaves HBM idle for its whole 15 us
-    const unsigned lin0 = ((unsigned)a.B + 7u) & ~7u;
-    if (a.pf_blocks > 0 && blockIdx.x >= lin0 && *a.n_active != 0) vc_prefetch_tiles(&a.pf, 1, blockIdx.x, lin0, (unsigned)a.pf_blocks);
-    return;
-  }
   const int b = blockIdx.x;
   const long long t_entry = clock64();
   float v0[VC_VPL];
@@ -669,8 +664,7 @@ __global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
   const size_t lds = (size_t)a.K * (((a.V + 63) >> 6) << 6) * sizeof(float);
   if (!grouped) {
-    const int blocks = a.pf_blocks > 0 ? ((a.B + 7) & ~7) + a.pf_blocks : a.B;
-    hipLaunchKernelGGL(sample_fused_k, dim3(blocks), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(sample_fused_k, dim3(a.B), dim3(256), lds, s, a);
   } else {
     // the keep decision reads every sample's cond flag, so it needs the kernel boundary
     hipLaunchKernelGGL(sample_only_k, dim3(a.B), dim3(256), lds, s, a);
