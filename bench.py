@@ -22,6 +22,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # the host driver only supports dmabuf IPC (RCCL / tensor sharing across ranks)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

@@ -10,8 +10,8 @@ cfg = {"preset": cfg.get("preset", "giga830M"), "dtype": cfg.get("dtype", "bf16"
 d = 2048
 alg = {"ffn1": 4 * d * d * 2 + d * 4 + 4 * d * 2, "ffn2": 4 * d * d * 2 + 4 * d * 2 + d * 4, "qkv": 3 * d * d * 2 + d * 4 + 3 * d * 2,
        "oproj": d * d * 2 + d * 4 * 2}
-pat = {"ffn1": r"rows_gemm_k<bf16_t, 16, 0, 2>", "ffn2": r"rows_gemm_k<bf16_t, 16, 1, 1>", "qkv": r"rows_gemm_k<bf16_t, 16, 0, 0>",
-       "oproj": r"rows_gemm_k<bf16_t, 8, 2, 1>"}
+pat = {"ffn1": r"rows_gemm_k<bf16_t, 16, 0, 2,", "ffn2": r"rows_gemm_k<bf16_t, 16, 1, 1,", "qkv": r"rows_gemm_k<bf16_t, 16, 0, 0,",
+       "oproj": r"rows_gemm_k<bf16_t, 8, 2, 1,"}      # (template tail: tiles per workgroup, non-temporal)
 out = {"source": f"{src} (rocprofv3 --pmc FETCH_SIZE --kernel-trace, own pass of `python bench.py --steps 1 --warmup 0`; FETCH_SIZE[KB] * 1024 * 2)",
        "config": cfg, "kernels": {}}
 for line in open(src):

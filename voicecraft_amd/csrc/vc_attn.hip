@@ -38,11 +38,13 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 // leading bytes of up to two matrices' tiles (vc_common.h vc_prefetch_tiles).
 __device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  for (int i = 0; i < a.pf_delay; ++i) __builtin_amdgcn_s_sleep(4);      // ~256 clocks each
   vc_prefetch_tiles(a.pf, 2, lin, gridDim.x * gridDim.y * (unsigned)a.nsplit, gridDim.x * gridDim.y * (unsigned)a.pf_z);
 }
 
-template <typename WT>
+// NT: K/V rows are requested with the non-temporal hint (every cached row is read exactly once per step and never again before
+// the next step's 1.7 GB of weights have gone through the caches) - a template parameter so that the hint cannot be merged away
+// (vc_gemm.hip rows_gemm_k), chosen per launch from AttnArgs.nt (option "attn_nt").
+template <typename WT, bool NT>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;
   constexpr int NW = VC_ATT_WAVES;
@@ -98,8 +100,13 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
       pp[it] = (pb_) + (it * NW + wave) * PPW + sub;                         \
       const long pc = max(min(pp[it], p1 - 1), 0);                           \
       const long po = pc * hd - ((pc < share) ? own : 0);                    \
-      ku[it] = *reinterpret_cast<const uint4*>(kb + po);                     \
-      vu[it] = *reinterpret_cast<const uint4*>(vb + po);                     \
+      if constexpr (NT) {                                                    \
+        ku[it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + po))); \
+        vu[it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + po))); \
+      } else {                                                               \
+        ku[it] = *reinterpret_cast<const uint4*>(kb + po);                   \
+        vu[it] = *reinterpret_cast<const uint4*>(vb + po);                   \
+      }                                                                      \
     }
     VC_KV_LOADS(p0);
     __builtin_amdgcn_sched_barrier(0);
@@ -189,8 +196,13 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s) {
   dim3 grid(rows_cap, a.H, a.nsplit + a.pf_z);
   ++vc_launch_counts[VC_LC_ROWS_ATTN];
-  if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(rows_attn_k<bf16_t>, grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
-  else hipLaunchKernelGGL(rows_attn_k<float>, grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
+  if (dtype == VC_DTYPE_BF16) {
+    if (a.nt) hipLaunchKernelGGL((rows_attn_k<bf16_t, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
+    else hipLaunchKernelGGL((rows_attn_k<bf16_t, false>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
+  } else {
+    if (a.nt) hipLaunchKernelGGL((rows_attn_k<float, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
+    else hipLaunchKernelGGL((rows_attn_k<float, false>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
+  }
   return hipGetLastError();
 }
 

@@ -311,8 +311,7 @@ struct AttnArgs {
   // weight tiles into the L2 of the XCD whose workgroups will read them (vc_attn.hip, "piggyback prefetch"); 0 = none
   PfSeg pf[2];
   int pf_z;
-  int pf_delay;             // prefetch workgroups first sleep pf_delay x ~0.1 us, so that the attention workgroups' own K/V requests go out
-                            // into an idle memory system and the prefetch traffic overlaps their arithmetic / merge tail instead
+  int nt;                   // rows_attn_k: K/V rows requested with the non-temporal hint
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence

@@ -93,11 +93,14 @@ struct vc_engine {
   // Option "nt" (VC_NT).  Until round 4 the compiled QKV / out-projection / heads-2 kernels carried NO such load whatever this said (the
   // compiler merged the kernel's two load arms and dropped the hint): 28 reproduces that mix, 63 = every matrix (default), 0 = none.
   int nt_decode = 63;
+  int attn_nt = 0;                      // option "attn_nt": the decode attention's K/V loads carry the hint too (decode passes only)
   // piggyback weight prefetch of the one-row attention launch (vc_attn.hip prefetch_role): VC_ATTN_PF=z[,wo_kb[,w1_kb]], 0 = off.
   // Measured (profiles/r03g_attn_prefetch_sweep.log): 8 slices x the first 32 KB of every FFN-up tile 0.598 -> 0.589 ms per step;
   // the out-projection's own matrix gains nothing (that launch waits for the attention partials, not for its weights),
   // 48-64 KB per tile or 4 slices lose (the attention launch ends with its slowest prefetcher).
-  int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = 32, apf_delay = 0;
+  // (letting the prefetch workgroups start late, so that the attention workgroups' own K/V requests go out first, was measured in
+  // round 4: 0.4 us no effect, 0.8 us +1.7 %, 1.7 us +2.8 % per step - profiles/r04c_bench_apf_delay*.json.log; not carried)
+  int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = 32;
   // the same for several-row decode steps, carried by the per-row LayerNorm launches (8 workgroups, 4.9 us each, HBM idle):
   // VC_LN_PF=blocks[,qkv_kb[,w1_kb]] - LN1 prefetches the QKV matrix, LN2 the FFN-up matrix of the same layer; 0 = off
   // Measured (profiles/r03i_ln_prefetch_sweep.log): whole matrices LOSE (8 rows 0.911 -> 0.924-0.950 ms: the 4.9 us launch grows by
@@ -325,6 +328,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
+      a.nt = (rs.n_active != nullptr || rs.nt) ? e->attn_nt : 0;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {  // h' = h + bo + Wo merge(attention partials of all heads)
@@ -405,12 +409,13 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
+      a.nt = (rs.n_active != nullptr || rs.nt) ? e->attn_nt : 0;
       if (e->apf_z > 0 && rs.n_rows == 1 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0) {
         // one row: the launch leaves HBM mostly idle - extra workgroups pull the next two matrices' tiles into the L2 of
         // the XCD that will read them (prefetch_role)
         const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
         const int tile_b = (d / KW) * 64 * 16;                 // out-projection and FFN-up tiles: 16 channels x d
-        a.pf_z = e->apf_z; a.pf_delay = e->apf_delay;
+        a.pf_z = e->apf_z;
         a.pf[0] = PfSeg{(const char*)ly.Wo, e->p_o.n_tiles, tile_b, std::min(tile_b, e->apf_wo_kb * 1024), 1};
         a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->apf_w1_kb * 1024), 1};
       }
@@ -529,6 +534,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
+      a.nt = rs.n_active != nullptr ? e->attn_nt : 0;      // wide decode passes stream their K/V once, prefill passes re-read it
       if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
       if (rs.tiled && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
       else HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
@@ -781,14 +787,13 @@ int check_err_flag(vc_engine* e, hipStream_t s) {
 
 // One option by name (vc_set_option, and the VC_* environment variables at creation).
 int apply_option(vc_engine* e, const std::string& name, const char* value) {
-  int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-  const int n = sscanf(value ? value : "", "%d,%d,%d,%d", &v0, &v1, &v2, &v3);
+  int v0 = 0, v1 = 0, v2 = 0;
+  const int n = sscanf(value ? value : "", "%d,%d,%d", &v0, &v1, &v2);
   if (n < 1) return fail(e, VC_EINVAL, "option '%s': '%s' is not a number list", name.c_str(), value ? value : "(null)");
   if (name == "attn_pf") {            // slices[,out-projection KB[,FFN-up KB]] of the one-row attention launch's prefetch role; 0 = off
     e->apf_z = std::max(0, std::min(v0, 16));
     if (n >= 2) e->apf_wo_kb = std::max(0, v1);
     if (n >= 3) e->apf_w1_kb = std::max(0, v2);
-    e->apf_delay = n >= 4 ? std::max(0, std::min(v3, 64)) : 0;      // [,delay in ~0.1 us units before the prefetch workgroups start]
   } else if (name == "ln_pf") {       // workgroups[,QKV KB[,FFN-up KB]] of the LayerNorm launches' prefetch role (several-row steps); 0 = off
     e->lpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->lpf_qkv_kb = std::max(0, v1);
@@ -800,6 +805,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
   } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_FR_MAX_ROWS));
   } else if (name == "nt") { e->nt_decode = v0 & 63;
+  } else if (name == "attn_nt") { e->attn_nt = v0 ? 1 : 0;
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
   } else {
     return fail(e, VC_EINVAL, "unknown option '%s'", name.c_str());
@@ -809,9 +815,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_delay, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->fr_rows, e->lnw_tiles);
+           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles);
   e->opt_state = buf;
 }
 
@@ -1068,7 +1074,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), std::make_pair("VC_LN_SPLIT_ROWS", "ln_split_rows"),
                          std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
-                         std::make_pair("VC_FINISHED_ROWS", "finished_rows")})
+                         std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt")})
     if (const char* v = getenv(kv.first))
       if ((rc = apply_option(e, kv.second, v))) return rc;
   refresh_opt_state(e);
@@ -1699,7 +1705,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
-      a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
+      a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = e->attn_nt;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "pf_ffn1") {      // the prefill pass's FFN up-projection on the MFMA block GEMM (X = xn, n_rows rows)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);

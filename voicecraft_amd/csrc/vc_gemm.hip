@@ -909,6 +909,15 @@ hipError_t vc_launch_gemm_fr(const GemmArgs& a0, int dtype, int pro, hipStream_t
 // 16-row X tile staged in LDS feeds NTW output tiles (the X traffic out of L2 - 64 KB per row tile per
 // workgroup at d = 2048 - is what bounds this kernel, not HBM).  The next row tile is requested
 // while the current one is in the MFMAs.  LayerNorm is hoisted into ln_rows_k (one block per row).
+// (the weights are read from HBM exactly once per pass: non-temporal loads, compile-time - VC_MT_NT=0 builds the comparison twin)
+#ifndef VC_MT_NT
+#define VC_MT_NT 1
+#endif
+#if VC_MT_NT
+#define VC_MT_LOADW(p_) __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p_)))
+#else
+#define VC_MT_LOADW(p_) (*(p_))
+#endif
 template <typename WT, int KTW, int PRO, int EPI, int NTW>
 __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
   using T = WTr<WT>;
@@ -942,7 +951,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
     const int kt = kt0 + wave * KTW;
 #pragma unroll
     for (int i = 0; i < KTW; ++i) {
-      wf[i] = wp[(long)(kt + i) * SPT];
+      wf[i] = VC_MT_LOADW(wp + (long)(kt + i) * SPT);
       if (TH < 16 && !wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
     }
   }
@@ -1041,7 +1050,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
         const int kt = kt0 + (c * 4 + wave) * KTW;
 #pragma unroll
         for (int i = 0; i < KTW; ++i) {
-          wf[i] = wp[(long)(kt + i) * SPT];
+          wf[i] = VC_MT_LOADW(wp + (long)(kt + i) * SPT);
           if (TH < 16 && !wvalid) wf[i] = make_uint4(0u, 0u, 0u, 0u);
         }
       }
