@@ -60,7 +60,7 @@ def parse():
     p.add_argument("--ab", default="auto", metavar="KNOB=A:B",
                    help="in-process A/B of one engine option (vc_set_option), e.g. attn_pf=0:8,0,32 - interleaved pairs of whole calls, "
                         "reported as the `ab` object of the JSON line.  auto (default, N = 1 only): the default-ON launch-shape feature "
-                        "of this run's step - attn_pf=0:8,0,32 at one row per step, finished_rows=0:8 at 2..8 rows; none: skip")
+                        "of this run's step - attn_pf=0:8,0,32 at one row per step, finished_rows=0:8 at 2..8 rows, attn_nt=0:2 above; none: skip")
     p.add_argument("--ab-pairs", type=int, default=7)
     return p.parse_args()
 
@@ -512,7 +512,7 @@ def main():
                 out["one_sample"] = {"error": str(e)}
         ab = args.ab
         if ab == "auto":       # every default-ON feature has to show its gain in the line the driver records
-            ab = ("attn_pf=0:8,0,32" if B == 1 else "finished_rows=0:8" if B <= 8 else "none") if not edit else "attn_pf=0:8,0,32"
+            ab = ("attn_pf=0:8,0,32" if B == 1 else "finished_rows=0:8" if B <= 8 else "attn_nt=0:2") if not edit else "attn_pf=0:8,0,32"
         if n_gpus == 1 and ab and ab != "none":
             try:
                 out["ab"] = ab_block(eng, one_step, ab, max(3, args.ab_pairs))

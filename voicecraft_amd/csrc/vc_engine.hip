@@ -93,7 +93,11 @@ struct vc_engine {
   // Option "nt" (VC_NT).  Until round 4 the compiled QKV / out-projection / heads-2 kernels carried NO such load whatever this said (the
   // compiler merged the kernel's two load arms and dropped the hint): 28 reproduces that mix, 63 = every matrix (default), 0 = none.
   int nt_decode = 63;
-  int attn_nt = 0;                      // option "attn_nt": the decode attention's K/V loads carry the hint too (decode passes only)
+  int sampler_lds = 0;                  // option "sampler_lds": the sampler parks its argument blocks in LDS (sample_fused_lds_k)
+  // option "attn_nt": the decode attention's K/V loads carry the hint too - 0 never, 1 always, 2 (default) from two rows per step up
+  // (in-process A/Bs, profiles/r04d_bench_*attn_nt*: one row +0.3 % +- 0.09 - there the launch is latency-bound and carries the prefetch
+  // role -, 8 rows -4.8 % +- 0.05, 32 rows -6.5 % +- 0.05: several caches stream 58-230 MB per layer through L2 otherwise)
+  int attn_nt = 2;
   // piggyback weight prefetch of the one-row attention launch (vc_attn.hip prefetch_role): VC_ATTN_PF=z[,wo_kb[,w1_kb]], 0 = off.
   // Measured (profiles/r03g_attn_prefetch_sweep.log): 8 slices x the first 32 KB of every FFN-up tile 0.598 -> 0.589 ms per step;
   // the out-projection's own matrix gains nothing (that launch waits for the attention partials, not for its weights),
@@ -276,6 +280,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   return g;
 }
 
+inline int attn_nt_for(const vc_engine* e, int rows) { return e->attn_nt == 1 || (e->attn_nt == 2 && rows >= 2); }
 enum { NT_QKV = 1, NT_O = 2, NT_F1 = 4, NT_F2 = 8, NT_H1 = 16, NT_H2 = 32 };
 inline void nt_bit(const vc_engine* e, GemmArgs& g, int bit) { if (!(e->nt_decode & bit)) g.nt = 0; }
 
@@ -328,7 +333,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
-      a.nt = (rs.n_active != nullptr || rs.nt) ? e->attn_nt : 0;
+      a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {  // h' = h + bo + Wo merge(attention partials of all heads)
@@ -409,7 +414,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
-      a.nt = (rs.n_active != nullptr || rs.nt) ? e->attn_nt : 0;
+      a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
       if (e->apf_z > 0 && rs.n_rows == 1 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0) {
         // one row: the launch leaves HBM mostly idle - extra workgroups pull the next two matrices' tiles into the L2 of
         // the XCD that will read them (prefetch_role)
@@ -534,7 +539,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
-      a.nt = rs.n_active != nullptr ? e->attn_nt : 0;      // wide decode passes stream their K/V once, prefill passes re-read it
+      a.nt = rs.n_active != nullptr ? attn_nt_for(e, rs.n_rows) : 0;      // wide decode passes stream their K/V once, prefill passes re-read it
       if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
       if (rs.tiled && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
       else HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
@@ -642,6 +647,7 @@ SampleArgs make_sample_args(vc_engine* e, int B, int rps) {
   a.logit_row = e->logit_row;
   a.audio_emb = e->audio_emb; a.mask_emb = e->mask_emb; a.pe = e->pe; a.alpha_audio = e->alpha_audio;
   a.max_positions = e->S_max;
+  a.lds_args = e->sampler_lds;
   return a;
 }
 
@@ -805,7 +811,8 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
   } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_FR_MAX_ROWS));
   } else if (name == "nt") { e->nt_decode = v0 & 63;
-  } else if (name == "attn_nt") { e->attn_nt = v0 ? 1 : 0;
+  } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
+  } else if (name == "sampler_lds") { e->sampler_lds = v0 ? 1 : 0;
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
   } else {
     return fail(e, VC_EINVAL, "unknown option '%s'", name.c_str());
@@ -815,9 +822,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|sl%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles);
+           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->sampler_lds, e->fr_rows, e->lnw_tiles);
   e->opt_state = buf;
 }
 
@@ -1074,7 +1081,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), std::make_pair("VC_LN_SPLIT_ROWS", "ln_split_rows"),
                          std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
-                         std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt")})
+                         std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
+                         std::make_pair("VC_SAMPLER_LDS", "sampler_lds"), std::make_pair("VC_LNW_TILES", "lnw_tiles")})
     if (const char* v = getenv(kv.first))
       if ((rc = apply_option(e, kv.second, v))) return rc;
   refresh_opt_state(e);
@@ -1705,7 +1713,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
-      a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = e->attn_nt;
+      a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = attn_nt_for(e, rs.n_rows);
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "pf_ffn1") {      // the prefill pass's FFN up-projection on the MFMA block GEMM (X = xn, n_rows rows)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);

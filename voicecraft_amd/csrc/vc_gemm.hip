@@ -312,10 +312,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT
 // NT: the weight stream uses non-temporal loads (decode: every byte is read exactly once per launch).  A TEMPLATE parameter, not
 // the runtime flag it used to be: with both load arms in one kernel the compiler merged them and silently dropped the hint -
 // through round 3 the compiled QKV, out-projection and heads-2 forms had no non-temporal load at all, the FFN forms 15 of 16.
-template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true>
+// R2 (NTW = 2 only): every wave folds TWO rows (w and w + 8) - passes of 9..16 finished rows.
+template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true, bool R2 = false>
 __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   static_assert(NTW == 1 || PRO == PRO_LNW, "two tiles per workgroup: finished-row consumers only");
+  static_assert(!R2 || NTW == 2, "two rows per wave: the two-tile form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   VC_KTS_DECL();
@@ -471,8 +473,9 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
     // row in every workgroup - 20 us per GEMM at 8 rows - which is why several-row steps used a separate LayerNorm launch.)
     const int d = a.d;
     const int npl = d >> 8;                                 // float4 per lane and row: d / 4 / 64 = 1..8 (d % 256 == 0)
-    const int rowA = (NTW == 1) ? wave : wv;                // (two tiles per workgroup: 8 waves, one row each)
-    const int rowB = (NTW == 1) ? wave + 4 : VC_ROWS;
+    const int rowA = (NTW == 1) ? wave : wv;                // (two tiles per workgroup: 8 waves, one row each - or two, R2)
+    const int rowB = (NTW == 1) ? wave + 4 : wv + 8;
+    constexpr bool TWO_ROWS = (NTW == 1) || R2;
     const float* hrA = a.h_in + (long)min(rowA, n_rows - 1) * d;
     const float* hrB = a.h_in + (long)min(rowB, n_rows - 1) * d;
     float4 xa[8], xb[8];
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
     for (int j = 0; j < 8; ++j) {
       const int c = (min(j, npl - 1) * 64 + lane) * 4;
       xa[j] = *reinterpret_cast<const float4*>(hrA + c);
-      if constexpr (NTW == 1) xb[j] = *reinterpret_cast<const float4*>(hrB + c);
+      if constexpr (TWO_ROWS) xb[j] = *reinterpret_cast<const float4*>(hrB + c);
     }
     VC_ISSUE_WEIGHTS(0);
     VC_BURST_OUT();
@@ -507,7 +510,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
       }                                                                                          \
     }
     VC_LNW_ROW(xa, rowA);
-    if constexpr (NTW == 1) { VC_LNW_ROW(xb, rowB); }
+    if constexpr (TWO_ROWS) { VC_LNW_ROW(xb, rowB); }
 #undef VC_LNW_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
     // X rows copied as 16-byte units, flat index = row * upr + unit.  The first NB*256 units are
@@ -837,6 +840,121 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr_k(const GemmArg
   }
 }
 
+// The FFN down-projection of 9..16 finished rows: X (rows x 4d elements) no longer fits the LDS of one workgroup, so K goes
+// through it in TWO halves - the same LDS buffer twice - while the wave's weight fragments of BOTH halves are requested at the
+// very top (2 x KTW fragments in registers: the stream never waits for the staging).  The second half's X rows are requested
+// as soon as the first half has been parked (they return behind the weights: a wave's loads come back in order) and parked
+// once every wave has finished reading the first half.  Same sums in the same order as rows_gemm_fr_k.
+template <typename WT, int KTW>
+__global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr2_k(const GemmArgs a) {
+  using T = WTr<WT>;
+  constexpr int NW = VC_FR_WAVES, NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockIdx.x;
+  const int n_rows = a.n_rows;                    // <= 16 (host contract)
+  const int Kh = a.K >> 1;                        // K elements per half = NW * KTW k-tiles
+  const int xs = Kh * (int)sizeof(WT) + 16;
+  char* xl = smem;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)a.r_lds * xs);
+  const int active = *a.n_active;
+  const int m = lane & 15, kg = lane >> 4;
+  const bool nvalid = 4 * kg < TH;
+  const int n = nt * TH + (nvalid ? 4 * kg : 0);
+  const int wslot = kg * TH + min(m, TH - 1);
+  const float4 eres = *reinterpret_cast<const float4*>(a.h_in + (long)((m < n_rows) ? m : 0) * a.d + n);
+  const float4 eb = *reinterpret_cast<const float4*>(a.bias + n);
+  const uint4* wbase = a.Wp + ((long)nt * a.KT + wave * KTW) * SPT;      // wave-uniform; the second half is NW * KTW k-tiles further
+  uint4 wfa[KTW], wfb[KTW];
+  const int upr = Kh * (int)sizeof(WT) / 16;       // 16-byte units per row and half; rows x upr <= 16 x 512 (host contract)
+  const int total = n_rows * upr;
+  const char* src = reinterpret_cast<const char*>(a.x_in);
+  const long rstride = (long)a.x_ld * (long)sizeof(WT);
+  const long hoff = (long)Kh * (long)sizeof(WT);
+  const int sh = a.x_upr_shift;
+  uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+#define VC_FR2_LOAD(j, dst, off_)                                                                \
+    {                                                                                            \
+      const int i_ = min((j) * NTHR + tid, total - 1);                                           \
+      const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                        \
+      dst = *reinterpret_cast<const uint4*>(src + (off_) + (long)r_ * rstride + (long)(i_ - r_ * upr) * 16); \
+    }
+#define VC_FR2_STORE(j, val)                                                                     \
+    {                                                                                            \
+      const int i_ = (j) * NTHR + tid;                                                           \
+      if (i_ < total) {                                                                          \
+        const int r_ = (sh >= 0) ? (i_ >> sh) : (i_ / upr);                                      \
+        *reinterpret_cast<uint4*>(xl + (size_t)r_ * xs + (size_t)(i_ - r_ * upr) * 16) = val;    \
+      }                                                                                          \
+    }
+#define VC_FR2_LOAD_ALL(off_)                                                                    \
+    VC_FR2_LOAD(0, x0, off_) VC_FR2_LOAD(1, x1, off_) VC_FR2_LOAD(2, x2, off_) VC_FR2_LOAD(3, x3, off_)         \
+    VC_FR2_LOAD(4, x4, off_) VC_FR2_LOAD(5, x5, off_) VC_FR2_LOAD(6, x6, off_) VC_FR2_LOAD(7, x7, off_)         \
+    VC_FR2_LOAD(8, x8, off_) VC_FR2_LOAD(9, x9, off_) VC_FR2_LOAD(10, x10, off_) VC_FR2_LOAD(11, x11, off_)     \
+    VC_FR2_LOAD(12, x12, off_) VC_FR2_LOAD(13, x13, off_) VC_FR2_LOAD(14, x14, off_) VC_FR2_LOAD(15, x15, off_)
+#define VC_FR2_STORE_ALL()                                                                       \
+    VC_FR2_STORE(0, x0) VC_FR2_STORE(1, x1) VC_FR2_STORE(2, x2) VC_FR2_STORE(3, x3)               \
+    VC_FR2_STORE(4, x4) VC_FR2_STORE(5, x5) VC_FR2_STORE(6, x6) VC_FR2_STORE(7, x7)               \
+    VC_FR2_STORE(8, x8) VC_FR2_STORE(9, x9) VC_FR2_STORE(10, x10) VC_FR2_STORE(11, x11)           \
+    VC_FR2_STORE(12, x12) VC_FR2_STORE(13, x13) VC_FR2_STORE(14, x14) VC_FR2_STORE(15, x15)
+  VC_FR2_LOAD_ALL(0L)
+#pragma unroll
+  for (int i = 0; i < KTW; ++i)
+    wfa[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + i * SPT + wslot)));
+#pragma unroll
+  for (int i = 0; i < KTW; ++i)
+    wfb[i] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + (long)(NW * KTW + i) * SPT + wslot)));
+  __builtin_amdgcn_sched_barrier(0);
+  if (active == 0) return;
+  VC_FR2_STORE_ALL()
+  __syncthreads();
+  VC_FR2_LOAD_ALL(hoff)                           // second half of the rows: on its way during the first half's MFMAs
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int mrow = (m < a.r_lds) ? m : 0;
+  const char* xrow = xl + (size_t)mrow * xs + (size_t)kg * 16 + (size_t)(wave * KTW) * 64;
+#pragma unroll
+  for (int i = 0; i < KTW; ++i) {
+    const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)i * 64);
+    acc = mfma_frag(wfa[i], xf, acc, (WT*)nullptr);
+  }
+  __syncthreads();                                // every wave has read the first half
+  VC_FR2_STORE_ALL()
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < KTW; ++i) {
+    const uint4 xf = *reinterpret_cast<const uint4*>(xrow + (size_t)i * 64);
+    acc = mfma_frag(wfb[i], xf, acc, (WT*)nullptr);
+  }
+#undef VC_FR2_LOAD
+#undef VC_FR2_STORE
+#undef VC_FR2_LOAD_ALL
+#undef VC_FR2_STORE_ALL
+  red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0 && m < n_rows && nvalid) {
+#pragma unroll
+    for (int w = 1; w < NW; ++w) acc += red[w * 64 + lane];
+    const f32x4 o = {eres.x + eb.x + acc[0], eres.y + eb.y + acc[1], eres.z + eb.z + acc[2], eres.w + eb.w + acc[3]};
+    store4(a.h_out + (long)m * a.d + n, o);
+  }
+}
+template <typename WT, int KTW>
+static hipError_t launch_fr2(const GemmArgs& a, size_t lds, hipStream_t s) {
+  auto kern = rows_gemm_fr2_k<WT, KTW>;
+  static size_t granted[16] = {0};     // per instantiation and device
+  int dev = 0;
+  if (hipError_t ge = hipGetDevice(&dev); ge != hipSuccess) return ge;
+  if (lds > 64 * 1024 && dev >= 0 && dev < 16 && lds > granted[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    granted[dev] = lds;
+  }
+  ++vc_launch_counts[VC_LC_ROWS_GEMM_FR];
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(64 * VC_FR_WAVES), lds, s, a);
+  return hipGetLastError();
+}
+
 template <typename WT, int KTW, int PRO, int NS>
 static hipError_t launch_fr_n(const GemmArgs& a, size_t lds, hipStream_t s) {
   auto kern = rows_gemm_fr_k<WT, KTW, PRO, NS>;
@@ -880,7 +998,7 @@ hipError_t vc_launch_gemm_fr(const GemmArgs& a0, int dtype, int pro, hipStream_t
   a.r_lds = a.n_rows;
   int ktw = 32;
   while (ktw > 1 && a.KT % (VC_FR_WAVES * ktw) != 0) ktw >>= 1;
-  if (a.KT % (VC_FR_WAVES * ktw) != 0 || a.N % VC_TH_RES != 0 || a.n_rows < 1 || a.n_rows > VC_FR_MAX_ROWS) return hipErrorInvalidValue;
+  if (a.KT % (VC_FR_WAVES * ktw) != 0 || a.N % VC_TH_RES != 0 || a.n_rows < 1 || a.n_rows > VC_ROWS) return hipErrorInvalidValue;
   a.nchunk = a.KT / (VC_FR_WAVES * ktw);
   const int esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
   const int upr = a.K * esz / 16, q4 = a.K / 4;
@@ -889,7 +1007,21 @@ hipError_t vc_launch_gemm_fr(const GemmArgs& a0, int dtype, int pro, hipStream_t
     if ((1 << sft) == upr) a.x_upr_shift = sft;
     if ((1 << sft) == q4) a.att_q4_shift = sft;
   }
-  if (pro == PRO_PLAIN && (long)a.n_rows * upr > 16L * 64 * VC_FR_WAVES) return hipErrorInvalidValue;
+  if (pro == PRO_PLAIN && (long)a.n_rows * upr > 16L * 64 * VC_FR_WAVES) {
+    // X does not fit the LDS of a workgroup in one piece: K in two halves (rows_gemm_fr2_k), one burst of weights per half
+    const int ktw2 = a.KT / (2 * VC_FR_WAVES);
+    if (a.KT % (2 * VC_FR_WAVES) != 0 || (long)a.n_rows * (upr / 2) > 16L * 64 * VC_FR_WAVES || a.n_rows > VC_ROWS) return hipErrorInvalidValue;
+    a.nchunk = 2;
+    a.x_upr_shift = -1;
+    for (int sft = 0; sft < 20; ++sft) if ((1 << sft) == upr / 2) a.x_upr_shift = sft;
+    const size_t lds2 = vc_gemm_fr_lds_bytes(a.n_rows, a.K / 2, dtype);
+#define VC_FR2_CASE(K_) case K_: return (dtype == VC_DTYPE_BF16) ? launch_fr2<bf16_t, K_>(a, lds2, s) : launch_fr2<float, K_>(a, lds2, s);
+    switch (ktw2) {
+      VC_FR2_CASE(2) VC_FR2_CASE(4) VC_FR2_CASE(8) VC_FR2_CASE(16)
+      default: return hipErrorInvalidValue;
+    }
+#undef VC_FR2_CASE
+  }
   if (pro == PRO_ATT && (a.nsplit < 1 || a.n_rows * (a.nsplit > 4 ? 8 : a.nsplit > 2 ? 4 : 2) > 16 || (long)a.n_rows * q4 > 16L / (a.nsplit > 4 ? 8 : a.nsplit > 2 ? 4 : 2) * 64 * VC_FR_WAVES))
     return hipErrorInvalidValue;
   const size_t lds = vc_gemm_fr_lds_bytes(a.n_rows, a.K, dtype);
@@ -1512,9 +1644,9 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4) + VC_ROWS * 4 * 3 * sizeof(float);   // X rows, K-reduce area, LN statistics + row means
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int NTW, bool NT>
+template <typename WT, int KTW, int PRO, int EPI, int NTW, bool NT, bool R2 = false>
 static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW, NT>;
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW, NT, R2>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit) + (size_t)(NTW - 1) * 4 * 64 * sizeof(f32x4);
   if (lds > 64 * 1024) {
     static size_t granted[16] = {0};   // per instantiation and device
@@ -1662,6 +1794,12 @@ static hipError_t launch_ktw(const GemmArgs& a, int dtype, int pro, int epi, int
   if (pro == PRO_LN && epi == EPI_QKV) return launch_one<WT, KTW, PRO_LN, EPI_QKV>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LN && epi == EPI_RELU) return launch_one<WT, KTW, PRO_LN, EPI_RELU>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LN && epi == EPI_GELU) return launch_one<WT, KTW, PRO_LN, EPI_GELU>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_LNW && a.mt == 4 && a.n_tiles % 2 == 0 && groups == 1) {     // ... and two rows per wave (9..16 finished rows)
+    if (epi == EPI_QKV) return a.nt ? launch_dec_nt<WT, KTW, PRO_LNW, EPI_QKV, 2, true, true>(a, dtype, ksplit, groups, s)
+                                    : launch_dec_nt<WT, KTW, PRO_LNW, EPI_QKV, 2, false, true>(a, dtype, ksplit, groups, s);
+    if (epi == EPI_RELU) return a.nt ? launch_dec_nt<WT, KTW, PRO_LNW, EPI_RELU, 2, true, true>(a, dtype, ksplit, groups, s)
+                                     : launch_dec_nt<WT, KTW, PRO_LNW, EPI_RELU, 2, false, true>(a, dtype, ksplit, groups, s);
+  }
   if (pro == PRO_LNW && a.mt == 3 && a.n_tiles % 2 == 0 && groups == 1) {     // two tiles per workgroup (finished-row consumers, GemmArgs.mt)
     if (epi == EPI_QKV) return launch_dec<WT, KTW, PRO_LNW, EPI_QKV, 2>(a, dtype, ksplit, groups, s);
     if (epi == EPI_RELU) return launch_dec<WT, KTW, PRO_LNW, EPI_RELU, 2>(a, dtype, ksplit, groups, s);
