@@ -60,7 +60,7 @@ def parse():
     p.add_argument("--ab", default="auto", metavar="KNOB=A:B",
                    help="in-process A/B of one engine option (vc_set_option), e.g. attn_pf=0:8,0,32 - interleaved pairs of whole calls, "
                         "reported as the `ab` object of the JSON line.  auto (default, N = 1 only): the default-ON launch-shape feature "
-                        "of this run's step - attn_pf=0:8,0,32 at one row per step, finished_rows=0:8 at 2..8 rows, attn_nt=0:2 above; none: skip")
+                        "of this run's step - attn_pf=0:8,0,-1 (half of every FFN-up tile) at one row per step, finished_rows=0:16 at 2..16 rows, attn_nt=0:2 above; none: skip")
     p.add_argument("--ab-pairs", type=int, default=7)
     return p.parse_args()
 
@@ -459,7 +459,7 @@ def main():
         for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
             ms_, by_ = eng.bench_kernel(kn, n_rows=mb_rows, iters=64)
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
-        fr_form = 2 <= mb_rows <= 8 and "|fr0" not in eng.options()       # several-row steps: the finished-row producer is what runs
+        fr_form = 2 <= mb_rows <= 16 and "|fr0" not in eng.options()       # several-row steps: the finished-row producer is what runs
         roof = {"bound": "hbm", "kernel": ("rows_gemm_fr_k<plain> (FFN down-projection, finished rows: 8-channel tiles over the whole K)" if fr_form
                                            else "rows_gemm_k<plain,split-K slabs> (FFN down-projection)"),
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -512,7 +512,7 @@ def main():
                 out["one_sample"] = {"error": str(e)}
         ab = args.ab
         if ab == "auto":       # every default-ON feature has to show its gain in the line the driver records
-            ab = ("attn_pf=0:8,0,32" if B == 1 else "finished_rows=0:8" if B <= 8 else "attn_nt=0:2") if not edit else "attn_pf=0:8,0,32"
+            ab = ("attn_pf=0:8,0,-1" if B == 1 else "finished_rows=0:16" if B <= 16 else "attn_nt=0:2") if not edit else "attn_pf=0:8,0,-1"
         if n_gpus == 1 and ab and ab != "none":
             try:
                 out["ab"] = ab_block(eng, one_step, ab, max(3, args.ab_pairs))

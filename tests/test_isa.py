@@ -71,15 +71,17 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
         assert ";;#ASMSTART" in body and "global_load_dwordx4" in body.split(";;#ASMSTART")[1].split(";;#ASMEND")[0], name
     for name, (body, _, _) in pick(kern, "ln_rows_k<").items():
         assert ";;#ASMSTART" in body, name                                # the prefetch role of several-row decode steps
-    decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true>")         # FFN-up of a one-row step
+    decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false>")         # FFN-up of a one-row step
     for name, (body, _, _) in decode.items():
         assert body.count("v_mfma_f32_16x16x32_bf16") >= 2 and " nt" in body, name     # non-temporal weight stream
-    # finished-row form (2..8-row decode steps): the FFN down-projection streams a wave's whole share (32 fragments) in ONE burst
+    # finished-row form (2..16-row decode steps): the FFN down-projection streams a wave's whole share (32 fragments) in ONE burst
     # of non-temporal loads, 512 threads at <= 256 registers; the consumers with two tiles per workgroup are 512-thread kernels
     for name, (body, _, vgpr) in pick(kern, "rows_gemm_fr_k<bf16_t, 32, 1, 1>").items():
         assert body.count("global_load_dwordx4") >= 32 + 16 and body.count(" nt") >= 32 and body.count("v_mfma_f32_16x16x32_bf16") == 32, name
         assert vgpr <= 256, (name, vgpr)
-    for prefix in ("rows_gemm_k<bf16_t, 16, 3, 0, 2, true>", "rows_gemm_k<bf16_t, 16, 3, 2, 2, true>"):
+    for name, (body, _, vgpr) in pick(kern, "rows_gemm_fr2_k<bf16_t, 16>").items():      # 9..16 rows: both halves' fragments up front
+        assert body.count(" nt") >= 32 and body.count("v_mfma_f32_16x16x32_bf16") == 32 and vgpr <= 256, (name, vgpr)
+    for prefix in ("rows_gemm_k<bf16_t, 16, 3, 0, 2, true, false>", "rows_gemm_k<bf16_t, 16, 3, 2, 2, true, false>"):
         for name, (body, _, vgpr) in pick(kern, prefix).items():
             assert vgpr <= 128 and " nt" in body, (name, vgpr)             # 8 waves per workgroup, two workgroups per CU
 
@@ -92,7 +94,7 @@ def test_the_non_temporal_hint_survives_in_every_decode_gemm(kern):
     import re
     seen = 0
     for name, (body, _, _) in pick(kern, "rows_gemm_k<").items():
-        m = re.search(r"rows_gemm_k<(\w+), (\d+), (\d+), (\d+), (\d+), (true|false)>", name)
+        m = re.search(r"rows_gemm_k<(\w+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", name)
         assert m, name
         ktw, nt = int(m.group(2)), m.group(6) == "true"
         n = len(re.findall(r"global_load_dwordx4[^\n]* nt", body))

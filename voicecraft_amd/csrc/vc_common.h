@@ -386,8 +386,6 @@ struct SampleArgs {         // engine-constant part (kernel argument)
   const float* pe;
   float alpha_audio;
   int max_positions;
-  int lds_args;             // sample_fused_lds_k: both argument blocks are parked in LDS at the top (option "sampler_lds")
-  int pad_;
 };
 
 struct AssembleArgs {       // writes res [K][res_cap] from y and the generated spans

@@ -93,7 +93,6 @@ struct vc_engine {
   // Option "nt" (VC_NT).  Until round 4 the compiled QKV / out-projection / heads-2 kernels carried NO such load whatever this said (the
   // compiler merged the kernel's two load arms and dropped the hint): 28 reproduces that mix, 63 = every matrix (default), 0 = none.
   int nt_decode = 63;
-  int sampler_lds = 0;                  // option "sampler_lds": the sampler parks its argument blocks in LDS (sample_fused_lds_k)
   // option "attn_nt": the decode attention's K/V loads carry the hint too - 0 never, 1 always, 2 (default) from two rows per step up
   // (in-process A/Bs, profiles/r04d_bench_*attn_nt*: one row +0.3 % +- 0.09 - there the launch is latency-bound and carries the prefetch
   // role -, 8 rows -4.8 % +- 0.05, 32 rows -6.5 % +- 0.05: several caches stream 58-230 MB per layer through L2 otherwise)
@@ -104,7 +103,9 @@ struct vc_engine {
   // 48-64 KB per tile or 4 slices lose (the attention launch ends with its slowest prefetcher).
   // (letting the prefetch workgroups start late, so that the attention workgroups' own K/V requests go out first, was measured in
   // round 4: 0.4 us no effect, 0.8 us +1.7 %, 1.7 us +2.8 % per step - profiles/r04c_bench_apf_delay*.json.log; not carried)
-  int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = 32;
+  // FFN-up KB < 0 (default): HALF of every tile - 32 KB at d = 2048 (re-swept in round 4 with the hint on every matrix: 24 / 40 / 48 /
+  // 64 KB cost +1.0 / +1.2 / +3.0 / +4.0 % against 32), 16 KB at d = 1024 (giga330M: 16 against 32 KB -4.2 % +- 0.03; r04e_bench_*apf*)
+  int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = -1;
   // the same for several-row decode steps, carried by the per-row LayerNorm launches (8 workgroups, 4.9 us each, HBM idle):
   // VC_LN_PF=blocks[,qkv_kb[,w1_kb]] - LN1 prefetches the QKV matrix, LN2 the FFN-up matrix of the same layer; 0 = off
   // Measured (profiles/r03i_ln_prefetch_sweep.log): whole matrices LOSE (8 rows 0.911 -> 0.924-0.950 ms: the 4.9 us launch grows by
@@ -114,7 +115,7 @@ struct vc_engine {
   // +0.10 %, 504 x 24 KB -0.35 % +- 0.17 at giga830M, +0.25 % at giga330M in in-process A/Bs, profiles/r04b_bench_spf_*: not carried)
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
   // finished-row form of decode passes of 2..fr_rows rows (forward_rows_fr): 0 = off.  VC_FINISHED_ROWS / option "finished_rows"
-  int fr_rows = VC_FR_MAX_ROWS;
+  int fr_rows = VC_ROWS;
   // weight tiles per workgroup of the finished-row consumers (QKV, FFN-up); option "lnw_tiles": 1, 2, or 0 = by row count - two
   // from 5 rows up (in-process A/Bs, profiles/r04b_bench_batch*.json.log: 8 rows -3.4 % +- 0.1 with two, 4 rows +0.5 % +- 0.05:
   // there half of the 8 waves have no row to fold)
@@ -294,12 +295,23 @@ int attn_nsplit(vc_engine* e, int rows) {
 // Rows a pass may carry in the finished-row form: X of the FFN down-projection (rows x 4d elements) has to fit the LDS
 // of one workgroup, and the out-projection merges rows x nsplit <= 16 attention partials per thread in one batch.
 int fr_max_rows(const vc_engine* e) {
-  int r = std::min(e->fr_rows, VC_FR_MAX_ROWS);
-  while (r >= 2 && vc_gemm_fr_lds_bytes(r, 4 * e->d, e->dtype) > 150 * 1024) --r;
+  // one piece: rows x 4d elements of X in one workgroup's LDS (8 rows in bf16 at d = 2048, 4 in the exact mode); two halves
+  // (rows_gemm_fr2_k): rows x 2d elements, and a wave must hold its fragments of both halves (KT / 16 <= 16 per half)
+  const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
+  const int KT = 4 * e->d / KW;
+  int r = std::min(e->fr_rows, VC_ROWS);
+  auto fits = [&](int rows) {
+    if (vc_gemm_fr_lds_bytes(rows, 4 * e->d, e->dtype) <= 150 * 1024 && rows <= VC_FR_MAX_ROWS) return true;
+    return KT % (2 * VC_FR_WAVES) == 0 && KT / (2 * VC_FR_WAVES) <= 16 && vc_gemm_fr_lds_bytes(rows, 2 * e->d, e->dtype) <= 150 * 1024;
+  };
+  while (r >= 2 && !fits(r)) --r;
   return r >= 2 ? r : 0;
 }
-bool lnw_two(const vc_engine* e, int rows) { return e->lnw_tiles == 2 || (e->lnw_tiles == 0 && rows >= 5); }
+bool lnw_two(const vc_engine* e, int rows) { return e->lnw_tiles == 2 || (e->lnw_tiles == 0 && rows >= 5) || rows > VC_FR_MAX_ROWS; }
+// splits of the decode attention in the finished-row form: the out-projection merges rows x splits <= 16 partials per thread in
+// one batch of loads; from 9 rows up the attention is unsplit (rows x heads >= 144 workgroups) and normalises itself
 int fr_nsplit(vc_engine* e, int rows) {
+  if (rows > VC_FR_MAX_ROWS) return 1;
   int ns = std::min(attn_nsplit(e, rows), 16 / rows);
   int p = 1;
   while (p * 2 <= ns) p *= 2;
@@ -320,7 +332,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.wg = ly.wg_qkv;
       g.h_in = h_res;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      g.mt = lnw_two(e, rs.n_rows) ? 3 : 0;
+      g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
     }
     {
@@ -334,21 +346,27 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
+      if (rs.nsplit == 1) a.x_out = e->xn;        // unsplit (9..16 rows): the workgroup saw every position and normalises itself
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {  // h' = h + bo + Wo merge(attention partials of all heads)
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo8; g.bias = ly.bo;
-      g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.h_in = h_res; g.h_out = e->hA;
-      HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s));
+      if (rs.nsplit == 1) {
+        g.x_in = e->xn; g.x_ld = d;
+        HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
+      } else {
+        g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
+        HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s));
+      }
     }
     {  // a = relu(W1 LN2(h') + b1)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.wg = ly.wg_1;
       g.h_in = e->hA;
       g.out = e->act; g.out_ld = 4 * d;
-      g.mt = lnw_two(e, rs.n_rows) ? 3 : 0;
+      g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
     }
     {  // h'' = h' + b2 + W2 a
@@ -422,7 +440,8 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         const int tile_b = (d / KW) * 64 * 16;                 // out-projection and FFN-up tiles: 16 channels x d
         a.pf_z = e->apf_z;
         a.pf[0] = PfSeg{(const char*)ly.Wo, e->p_o.n_tiles, tile_b, std::min(tile_b, e->apf_wo_kb * 1024), 1};
-        a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->apf_w1_kb * 1024), 1};
+        const int w1_len = e->apf_w1_kb < 0 ? ((tile_b / 2 + 8191) & ~8191) : e->apf_w1_kb * 1024;
+        a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, w1_len), 1};
       }
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -647,7 +666,6 @@ SampleArgs make_sample_args(vc_engine* e, int B, int rps) {
   a.logit_row = e->logit_row;
   a.audio_emb = e->audio_emb; a.mask_emb = e->mask_emb; a.pe = e->pe; a.alpha_audio = e->alpha_audio;
   a.max_positions = e->S_max;
-  a.lds_args = e->sampler_lds;
   return a;
 }
 
@@ -799,7 +817,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   if (name == "attn_pf") {            // slices[,out-projection KB[,FFN-up KB]] of the one-row attention launch's prefetch role; 0 = off
     e->apf_z = std::max(0, std::min(v0, 16));
     if (n >= 2) e->apf_wo_kb = std::max(0, v1);
-    if (n >= 3) e->apf_w1_kb = std::max(0, v2);
+    if (n >= 3) e->apf_w1_kb = v2;                       // < 0: half a tile
   } else if (name == "ln_pf") {       // workgroups[,QKV KB[,FFN-up KB]] of the LayerNorm launches' prefetch role (several-row steps); 0 = off
     e->lpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->lpf_qkv_kb = std::max(0, v1);
@@ -809,10 +827,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
   } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
   } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
-  } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_FR_MAX_ROWS));
+  } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
   } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
-  } else if (name == "sampler_lds") { e->sampler_lds = v0 ? 1 : 0;
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
   } else {
     return fail(e, VC_EINVAL, "unknown option '%s'", name.c_str());
@@ -822,9 +839,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|sl%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->sampler_lds, e->fr_rows, e->lnw_tiles);
+           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles);
   e->opt_state = buf;
 }
 
@@ -1082,7 +1099,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
-                         std::make_pair("VC_SAMPLER_LDS", "sampler_lds"), std::make_pair("VC_LNW_TILES", "lnw_tiles")})
+                         std::make_pair("VC_LNW_TILES", "lnw_tiles")})
     if (const char* v = getenv(kv.first))
       if ((rc = apply_option(e, kv.second, v))) return rc;
   refresh_opt_state(e);
@@ -1668,12 +1685,12 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       if (w == "ffn1") {
         GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
         g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.wg = ly.wg_1; g.h_in = e->hA; g.out = e->act; g.out_ld = 4 * d;
-        g.mt = lnw_two(e, rs.n_rows) ? 3 : 0;
+        g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
       } else if (w == "qkv") {
         GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
         g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.wg = ly.wg_qkv; g.h_in = e->hB; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-        g.mt = lnw_two(e, rs.n_rows) ? 3 : 0;
+        g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
       } else if (w == "ffn2") {
         GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
@@ -1681,9 +1698,9 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
         HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
       } else {
         GemmArgs g = base_args(e, rs, e->p_o, d, d);
-        g.Wp = ly.Wo8; g.bias = ly.bo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = fr_nsplit(e, n_rows);
-        g.h_in = e->hB; g.h_out = e->hA;
-        HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s));
+        g.Wp = ly.Wo8; g.bias = ly.bo; g.h_in = e->hB; g.h_out = e->hA;
+        if (fr_nsplit(e, n_rows) == 1) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s)); }
+        else { g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = fr_nsplit(e, n_rows); HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s)); }
       }
       return VC_OK;
     }

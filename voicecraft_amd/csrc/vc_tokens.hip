@@ -637,41 +637,10 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
     if (b == (int)gridDim.x - 1) { acc[9] += t_exit - t_entry; acc[10] += 1; }
   }
 }
-// The same kernel with its two argument blocks parked in LDS first (option "sampler_lds"): SampleArgs is 38 dwords and the
-// compiler re-loads pieces of it from the kernarg segment a dozen times in the middle of the kernel (scalar round trips on the
-// critical path of a kernel that is ONE dependent chain), and keeps SampleDyn in 30 vector registers.  One vector load per
-// thread at the top - in flight together with the logits row and the state - then every later access is an LDS read.
-__global__ __launch_bounds__(256) void sample_fused_lds_k(const SampleArgs a0) {
-  __shared__ SeqState s_st;
-  __shared__ int s_xs[VC_MAX_CODEBOOKS + 2];
-  __shared__ SampleArgs s_a;
-  __shared__ SampleDyn s_dy;
-  constexpr int WA = sizeof(SampleArgs) / 4, WD = sizeof(SampleDyn) / 4;
-  static_assert(WA <= 256 && WD <= 256 && sizeof(SampleArgs) % 4 == 0 && sizeof(SampleDyn) % 4 == 0, "one word per thread");
-  const int tid = threadIdx.x;
-  float v0[VC_VPL];
-  preload_row(a0, blockIdx.x, v0);
-  const int sw = fetch_state(a0, blockIdx.x);
-  const int dw = reinterpret_cast<const int*>(a0.dyn)[min(tid, WD - 1)];
-  const int aw = reinterpret_cast<const int*>(&a0)[min(tid, WA - 1)];
-  const int active = *a0.n_active;
-  __builtin_amdgcn_sched_barrier(0);
-  if (active == 0) return;
-  if (tid < WA) reinterpret_cast<int*>(&s_a)[tid] = aw;
-  if (tid < WD) reinterpret_cast<int*>(&s_dy)[tid] = dw;
-  park_state(&s_st, sw);                       // (ends with the block barrier that also publishes s_a / s_dy)
-  const SampleArgs& a = s_a;
-  const SampleDyn& dy = s_dy;
-  const int b = blockIdx.x;
-  VC_TS(0);
-  sample_phase(a, dy, blockIdx.x, &s_st, s_xs, s_dyn, v0);
-  __syncthreads();
-  VC_TS(6);
-  advance_phase(a, dy, blockIdx.x, false, &s_st, s_xs);
-  VC_TS(8);
-  store_state(a, blockIdx.x, &s_st);
-  VC_TS(9);
-}
+// (A twin of this kernel that parks SampleArgs / SampleDyn in LDS first - 4 scalar kernarg loads instead of 23, no argument
+// re-loads in the middle of the dependent chain - was built and measured in round 4: +0.25 % per step at one sequence, +0.18 % at
+// eight, in-process; profiles/r04e_bench_*sampler_lds*.  The sampler's 12-26 us at one sequence turned out to vary with the BOX
+// (12.5 us and 26 us on two boxes for the same code, stamps in profiles/r04d_sampler_stamps_b1.log / r04e_*), not with this.)
 __global__ __launch_bounds__(256) void sample_only_k(const SampleArgs a) {
   __shared__ SeqState s_st;
   float v0[VC_VPL];
@@ -699,8 +668,7 @@ __global__ __launch_bounds__(256) void advance_only_k(const SampleArgs a) {
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
   const size_t lds = (size_t)a.K * (((a.V + 63) >> 6) << 6) * sizeof(float);
   if (!grouped) {
-    if (a.lds_args) hipLaunchKernelGGL(sample_fused_lds_k, dim3(a.B), dim3(256), lds, s, a);
-    else hipLaunchKernelGGL(sample_fused_k, dim3(a.B), dim3(256), lds, s, a);
+    hipLaunchKernelGGL(sample_fused_k, dim3(a.B), dim3(256), lds, s, a);
   } else {
     // the keep decision reads every sample's cond flag, so it needs the kernel boundary
     hipLaunchKernelGGL(sample_only_k, dim3(a.B), dim3(256), lds, s, a);
