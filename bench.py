@@ -285,8 +285,9 @@ def ab_block(eng, one_step, spec, pairs):
     """In-process A/B of ONE engine option (vc_set_option): the same engine, the same process, the same box.  Whole calls
     are timed in interleaved pairs (A B, B A, A B ...: drift cancels), each arm's captured graph already warm; the figure
     compared is the device-timed decode loop per step taken.  `median_delta_pct` = median over pairs of (B - A) / A;
-    `spread_pct` = half the range of those per-pair deltas (the noise a single pair carries).  An option only earns a
-    default when |median_delta_pct| > spread_pct in a driver-run line."""
+    `spread_pct` = 1.4826 x the median absolute deviation of the per-pair deltas (the noise one pair carries; `half_range_pct` =
+    half their range, which a single disturbed call inflates).  An option only earns a default when |median_delta_pct| >
+    spread_pct in a driver-run line."""
     knob, vals = spec.split("=", 1)
     va, vb = vals.split(":", 1)
 
@@ -304,11 +305,14 @@ def ab_block(eng, one_step, spec, pairs):
         deltas.append((t[vb] - t[va]) / t[va] * 100.0)
     eng.set_option(knob, vb)
     med = lambda xs: sorted(xs)[len(xs) // 2]
+    m = med(deltas)
+    mad = 1.4826 * med([abs(d - m) for d in deltas])          # robust sigma of one pair's delta: a call hit by a host hiccup does not define it
+    half_range = (max(deltas) - min(deltas)) / 2.0
     return {"knob": knob, "A": va, "B": vb, "pairs": pairs, "metric": "decode ms per step taken (device events around the loop)",
             "A_ms_median": round(med(a_ms), 5), "B_ms_median": round(med(b_ms), 5),
-            "median_delta_pct": round(med(deltas), 3), "spread_pct": round((max(deltas) - min(deltas)) / 2.0, 3),
+            "median_delta_pct": round(m, 3), "spread_pct": round(mad, 3), "half_range_pct": round(half_range, 3),
             "deltas_pct": [round(d, 3) for d in deltas],
-            "verdict": ("B faster" if med(deltas) < 0 else "B slower") + (" beyond the spread" if abs(med(deltas)) > (max(deltas) - min(deltas)) / 2.0 else " (inside the spread: not shown)")}
+            "verdict": ("B faster" if m < 0 else "B slower") + (" beyond the spread" if abs(m) > max(mad, 0.05) else " (inside the spread: not shown)")}
 
 
 def cpu_only(args):

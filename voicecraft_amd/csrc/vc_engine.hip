@@ -106,6 +106,8 @@ struct vc_engine {
   // FFN-up KB < 0 (default): HALF of every tile - 32 KB at d = 2048 (re-swept in round 4 with the hint on every matrix: 24 / 40 / 48 /
   // 64 KB cost +1.0 / +1.2 / +3.0 / +4.0 % against 32), 16 KB at d = 1024 (giga330M: 16 against 32 KB -4.2 % +- 0.03; r04e_bench_*apf*)
   int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = -1;
+  int apf_scale = 4;                    // quarters of the configured length in force (decode_loop: per graph, by context length)
+  int apf_cut1 = 0, apf_cut2 = 0;       // option "attn_pf_cut" = "p1,p2": half the length from position p1, none from p2; 0,0 = never cut
   // the same for several-row decode steps, carried by the per-row LayerNorm launches (8 workgroups, 4.9 us each, HBM idle):
   // VC_LN_PF=blocks[,qkv_kb[,w1_kb]] - LN1 prefetches the QKV matrix, LN2 the FFN-up matrix of the same layer; 0 = off
   // Measured (profiles/r03i_ln_prefetch_sweep.log): whole matrices LOSE (8 rows 0.911 -> 0.924-0.950 ms: the 4.9 us launch grows by
@@ -433,14 +435,15 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
-      if (e->apf_z > 0 && rs.n_rows == 1 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0) {
+      if (e->apf_z > 0 && e->apf_scale > 0 && rs.n_rows == 1 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0) {
         // one row: the launch leaves HBM mostly idle - extra workgroups pull the next two matrices' tiles into the L2 of
         // the XCD that will read them (prefetch_role)
         const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
         const int tile_b = (d / KW) * 64 * 16;                 // out-projection and FFN-up tiles: 16 channels x d
         a.pf_z = e->apf_z;
         a.pf[0] = PfSeg{(const char*)ly.Wo, e->p_o.n_tiles, tile_b, std::min(tile_b, e->apf_wo_kb * 1024), 1};
-        const int w1_len = e->apf_w1_kb < 0 ? ((tile_b / 2 + 8191) & ~8191) : e->apf_w1_kb * 1024;
+        int w1_len = e->apf_w1_kb < 0 ? ((tile_b / 2 + 8191) & ~8191) : e->apf_w1_kb * 1024;
+        w1_len = ((w1_len * e->apf_scale / 4) + 8191) & ~8191;
         a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, w1_len), 1};
       }
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
@@ -715,33 +718,57 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
 // sequence retires, and the host paces itself one graph behind the GPU with events, so a queued graph is
 // always waiting when the running one ends (measured before: ~8 us of idle GPU per graph launch and ~100 us
 // per blocking poll).  Steps replayed after the last sequence retired are no-ops (*n_active == 0).
+// apf_scale: the attention-launch prefetch fetches apf_scale / 4 of its configured length (decode_loop switches it per graph by context
+// length); refresh_opt_state() folds it into the key of the captured graphs
+void refresh_opt_state(vc_engine* e);
+
 int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, const vc_sample_cfg* sc,
-                int max_steps, int* steps_run, hipStream_t s) {
+                int max_steps, int* steps_run, hipStream_t s, int pos0 = 0) {
   const int G = std::max(1, e->steps_per_graph);
-  hipGraphExec_t exec = nullptr;
   const double t0 = now_ms();
   e->host_ms[1] = e->host_ms[2] = 0;
-  if (sc->use_graph) {
+  // One captured graph per (shape, option state).  The only thing that varies INSIDE a call is the prefetch length of the one-row
+  // attention launch: it is worth most while the context is short (the launch's own K/V traffic grows with the position and the
+  // window it leaves shrinks), so the host - which knows how many steps it has launched - picks full / half / none per graph of G
+  // steps from the position the graph starts at (option "attn_pf_cut" = first position of the half, of the none range).
+  auto exec_for = [&](int scale, hipGraphExec_t* out) -> int {
+    const int keep = e->apf_scale;
+    e->apf_scale = scale;
+    refresh_opt_state(e);
     const auto key = std::make_pair(std::make_tuple(B, rps, grouped ? 1 : 0), e->opt_state);
     auto it = e->graphs.find(key);
+    int rc = VC_OK;
     if (it != e->graphs.end()) {
-      exec = it->second;
+      *out = it->second;
     } else {
+      const double tc = now_ms();
       hipGraph_t graph = nullptr;
-      HIPCHK(e, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-      int rc = VC_OK;
+      hipError_t be = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+      if (be != hipSuccess) rc = fail(e, VC_EHIP, "hipStreamBeginCapture failed: %s", hipGetErrorString(be));
       for (int i = 0; i < G && rc == VC_OK; ++i) rc = decode_step(e, sa, B, rps, grouped, s);
-      hipError_t ce = hipStreamEndCapture(s, &graph);
-      if (rc) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-      HIPCHK(e, ce);
-      e->host_ms[1] = now_ms() - t0;
-      hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-      (void)hipGraphDestroy(graph);
-      if (ie != hipSuccess) return fail(e, VC_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
-      e->host_ms[2] = now_ms() - t0 - e->host_ms[1];
-      e->graphs[key] = exec;
+      if (be == hipSuccess) {
+        hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc == VC_OK && ce != hipSuccess) rc = fail(e, VC_EHIP, "hipStreamEndCapture failed: %s", hipGetErrorString(ce));
+      }
+      e->host_ms[1] += now_ms() - tc;
+      if (rc == VC_OK) {
+        const double ti = now_ms();
+        hipError_t ie = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+        if (ie != hipSuccess) rc = fail(e, VC_EHIP, "hipGraphInstantiate failed: %s", hipGetErrorString(ie));
+        else e->graphs[key] = *out;
+        e->host_ms[2] += now_ms() - ti;
+      }
+      if (graph) (void)hipGraphDestroy(graph);
     }
-  }
+    e->apf_scale = keep;
+    refresh_opt_state(e);
+    return rc;
+  };
+  const bool one_row = B * rps == 1 && e->apf_z > 0;
+  auto scale_at = [&](int pos) {
+    if (!one_row || e->apf_cut2 <= 0) return 4;
+    return pos >= e->apf_cut2 ? 0 : pos >= e->apf_cut1 ? 2 : 4;
+  };
   const double t1 = now_ms();
   volatile int* live = e->h_flag + 8;
   int launched = 0, rc = VC_OK, batch = 0;
@@ -751,11 +778,18 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
       if (we != hipSuccess) { rc = fail(e, VC_EHIP, "pacing event: %s", hipGetErrorString(we)); break; }
       if (*live <= 0) break;
     }
-    if (exec) {
+    const int scale = scale_at(pos0 + launched);
+    if (sc->use_graph) {
+      hipGraphExec_t exec = nullptr;
+      rc = exec_for(scale, &exec);
+      if (rc) break;
       hipError_t le = hipGraphLaunch(exec, s);
       if (le != hipSuccess) rc = fail(e, VC_EHIP, "hipGraphLaunch failed: %s", hipGetErrorString(le));
     } else {
+      const int keep = e->apf_scale;
+      e->apf_scale = scale;
       for (int i = 0; i < G && rc == VC_OK; ++i) rc = decode_step(e, sa, B, rps, grouped, s);
+      e->apf_scale = keep;
     }
     if (rc) break;
     launched += G;
@@ -818,6 +852,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->apf_z = std::max(0, std::min(v0, 16));
     if (n >= 2) e->apf_wo_kb = std::max(0, v1);
     if (n >= 3) e->apf_w1_kb = v2;                       // < 0: half a tile
+  } else if (name == "attn_pf_cut") {   // p1,p2: half the prefetch from cached position p1 on, none from p2 on (one-row steps); 0 = never
+    e->apf_cut1 = std::max(0, v0);
+    e->apf_cut2 = n >= 2 ? std::max(e->apf_cut1, v1) : 0;
   } else if (name == "ln_pf") {       // workgroups[,QKV KB[,FFN-up KB]] of the LayerNorm launches' prefetch role (several-row steps); 0 = off
     e->lpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->lpf_qkv_kb = std::max(0, v1);
@@ -839,7 +876,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles);
   e->opt_state = buf;
@@ -1099,7 +1136,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
-                         std::make_pair("VC_LNW_TILES", "lnw_tiles")})
+                         std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut")})
     if (const char* v = getenv(kv.first))
       if ((rc = apply_option(e, kv.second, v))) return rc;
   refresh_opt_state(e);
@@ -1192,7 +1229,9 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   int steps_run = 0;
-  rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s);
+  int pos0 = 0;
+  for (const TtsJob& j : jobs) pos0 = std::max(pos0, j.Lx + j.T + 1);
+  rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s, pos0);
   if (rc) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
@@ -1361,7 +1400,7 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   HIPCHK(e, vc_launch_sample(sa, false, s));
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   int steps_run = 0;
-  rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, &steps_run, s);
+  rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, &steps_run, s, Lx + col);
   if (rc) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState), hipMemcpyDeviceToHost, s));
