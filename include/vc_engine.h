@@ -95,10 +95,14 @@ const char* vc_version(void);
 
 /* Run-time options of a finalized engine: launch-shape knobs of the decode step, the same ones the VC_* environment
  * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  name / value:
- *   "attn_pf"      "slices[,out-proj KB[,FFN-up KB]]"   prefetch role of the one-row attention launch, 0 = off
+ *   "attn_pf"      "slices[,out-proj KB[,FFN-up KB]]"   prefetch role of the one-row attention launch, 0 = off; KB < 0 = half a tile
+ *   "attn_pf_cut"  "p1,p2[,p0]"   that role fetches half its length from cached position p1, nothing from p2 or below p0 (0,0: never cut)
  *   "ln_pf"        "workgroups[,QKV KB[,FFN-up KB]]"    prefetch role of the LayerNorm launches of several-row steps, 0 = off
- *   "graph_steps"  decode steps captured per hipGraph;  "ln_split_rows", "attn_blocks", "attn_blocks1", "nt", "prefill_rows",
- *   "finished_rows" (rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs, 0 = off)
+ *   "nt"           bit mask of the weight matrices streamed with the non-temporal hint (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down, 16 / 32
+ *                  heads); "attn_nt" 0 / 1 / 2 = the decode attention's K/V loads never / always / from two rows per step
+ *   "finished_rows" rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs (0 = off, max 16);
+ *   "lnw_tiles"    weight tiles per workgroup of that form's consumers (0 = by row count, 1, 2)
+ *   "graph_steps"  decode steps captured per hipGraph;  "ln_split_rows", "attn_blocks", "attn_blocks1", "prefill_rows"
  * Results never depend on an option (tests/test_gpu_options.py).  Captured decode graphs are kept per option state, so an
  * in-process A/B (bench.py --ab) pays for capture once per state.  Unknown names / malformed values: VC_EINVAL. */
 int vc_set_option(vc_engine* e, const char* name, const char* value);

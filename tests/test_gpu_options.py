@@ -98,8 +98,9 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
     x, xl, y = synth.random_prompt(a, 6, 21, seed=11)
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=2, max_positions=256)
     base = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
-    for name, value in [("attn_pf", "0"), ("attn_pf", "8,0,32"), ("attn_pf", "4,16,16"), ("graph_steps", "3"), ("attn_blocks1", "64"),
-                        ("nt", "0"), ("ln_split_rows", "2"), ("graph_steps", "8")]:
+    for name, value in [("attn_pf", "0"), ("attn_pf", "8,0,32"), ("attn_pf", "4,16,16"), ("attn_pf_cut", "0,0"), ("attn_pf_cut", "30,40,28"),
+                        ("attn_pf", "8,0,-1"), ("attn_nt", "1"), ("attn_nt", "0"), ("nt", "28"), ("nt", "0"), ("nt", "63"), ("graph_steps", "3"), ("attn_blocks1", "64"),
+                        ("ln_split_rows", "2"), ("graph_steps", "8")]:
         eng.set_option(name, value)
         got = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
         assert np.array_equal(got, base), (name, value)

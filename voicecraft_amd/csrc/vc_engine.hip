@@ -107,7 +107,12 @@ struct vc_engine {
   // 64 KB cost +1.0 / +1.2 / +3.0 / +4.0 % against 32), 16 KB at d = 1024 (giga330M: 16 against 32 KB -4.2 % +- 0.03; r04e_bench_*apf*)
   int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = -1;
   int apf_scale = 4;                    // quarters of the configured length in force (decode_loop: per graph, by context length)
-  int apf_cut1 = 0, apf_cut2 = 0;       // option "attn_pf_cut" = "p1,p2": half the length from position p1, none from p2; 0,0 = never cut
+  // option "attn_pf_cut" = "p1,p2[,p0]": half the length from cached position p1, none from p2, none below p0; 0,0 = never cut.
+  // Measured per context range on a box where the uncut role gained only 0.2 % over a whole utterance (profiles/r04h_*): positions
+  // 41-221 +0.5 %, 141-441 -1.5 %, 461-661 +1.4 %, 731-884 +1.5 %, editing (793+) +1.4 % - the launch's own K/V traffic grows
+  // with the position and the window it leaves shrinks.  Cuts against uncut there: 400,700 -2.0 % (TTS) / -2.7 % (editing), 500,800
+  // -0.7 / -1.8, 300,600 -0.9, 600,900 -0.2.
+  int apf_cut1 = 400, apf_cut2 = 700, apf_cut0 = 128;
   // the same for several-row decode steps, carried by the per-row LayerNorm launches (8 workgroups, 4.9 us each, HBM idle):
   // VC_LN_PF=blocks[,qkv_kb[,w1_kb]] - LN1 prefetches the QKV matrix, LN2 the FFN-up matrix of the same layer; 0 = off
   // Measured (profiles/r03i_ln_prefetch_sweep.log): whole matrices LOSE (8 rows 0.911 -> 0.924-0.950 ms: the 4.9 us launch grows by
@@ -767,7 +772,7 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   const bool one_row = B * rps == 1 && e->apf_z > 0;
   auto scale_at = [&](int pos) {
     if (!one_row || e->apf_cut2 <= 0) return 4;
-    return pos >= e->apf_cut2 ? 0 : pos >= e->apf_cut1 ? 2 : 4;
+    return (pos >= e->apf_cut2 || pos < e->apf_cut0) ? 0 : pos >= e->apf_cut1 ? 2 : 4;
   };
   const double t1 = now_ms();
   volatile int* live = e->h_flag + 8;
@@ -855,6 +860,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "attn_pf_cut") {   // p1,p2: half the prefetch from cached position p1 on, none from p2 on (one-row steps); 0 = never
     e->apf_cut1 = std::max(0, v0);
     e->apf_cut2 = n >= 2 ? std::max(e->apf_cut1, v1) : 0;
+    e->apf_cut0 = n >= 3 ? std::max(0, v2) : (e->apf_cut2 > 0 ? 128 : 0);
   } else if (name == "ln_pf") {       // workgroups[,QKV KB[,FFN-up KB]] of the LayerNorm launches' prefetch role (several-row steps); 0 = off
     e->lpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->lpf_qkv_kb = std::max(0, v1);
@@ -876,7 +882,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles);
   e->opt_state = buf;
