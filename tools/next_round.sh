@@ -1,24 +1,15 @@
 #!/bin/bash
-# First GPU call of a round (from the repo root on the GPU box; ~8 minutes):
-#   gpurun --timeout 1200 -- 'bash tools/next_round.sh > gpurun_out/next_round.log 2>&1; tail -60 gpurun_out/next_round.log'
-# Re-establishes the state the previous round ended in (round 3: 178 GPU tests green; batch 1 6.6-6.7 k tok/s, 0.587-0.598 ms per
-# step; 8 rows 0.82-0.90 ms box to box; C4 prefill 3.3-3.45 ms; C5 prefill 5.3 ms; FFN-up probe 0.27 / 0.44 of the bf16 peak at
-# 512 / 2048 rows; tile attention 14.7 / 24.9 / 89.5 us at 512 / 800 / 2048 rows) and re-measures the two prefetch switches.
+# First GPU call of a round (from the repo root on the GPU box; ~12 minutes):
+#   gpurun --timeout 1500 -- 'bash tools/next_round.sh > gpurun_out/next_round.log 2>&1; tail -60 gpurun_out/next_round.log'
+# Re-establishes the state round 4 ended in: 194 GPU tests (193 pass, the 2-GPU RCCL one skips); batch 1 6.8-7.2 k codec-tok/s by
+# box (decode step 0.552-0.582 ms); 8 / 16 / 32 / 64 utterances per GPU 42.9 k / 70.0 k / 90.0 k / 119 k; giga330M 7.4 k; editing
+# 5.5 k (800-row prefill 3.4 ms).  Every default-on launch-shape feature carries its in-process A/B in the line (`ab`).
 set -u
 export TMPDIR=/tmp
-echo "== GPU suite"
-timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -4
-echo "== default bench line"
-timeout 300 python bench.py --steps 5 --warmup 2 2>/dev/null | tail -c 3000
-echo
-echo "== piggyback prefetch, batch 1 (off / default)"
-bash tools/apf_sweep.sh 0 8,0,32 0 8,0,32
-echo "== piggyback prefetch on the LayerNorm launches, 8 rows (off / default)"
-bash tools/lpf_sweep.sh 0 248,24,24 0 248,24,24
-echo "== prefill GEMM and attention by pass size"
-timeout 200 python tools/pf_gemm_probe.py 2>&1 | grep pf_gemm
-timeout 200 python tools/pf_attn_probe.py 2>&1 | grep pf_attn
-echo "== editing (C4) and 32 rows"
-for cfg in "--mode edit" "--batch 32"; do
-  timeout 300 python bench.py $cfg --steps 3 --warmup 1 --no-cpu-baseline --no-codec 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$cfg', d['value'], 'step', d['decode_ms_per_token_step'], 'prefill', d['prefill_ms'])"
+TAG=next bash tools/r04_final.sh
+echo "== the round-4 A/Bs, one each (in-process, interleaved pairs)"
+B="--steps 3 --warmup 1 --no-cpu-baseline --no-codec --ab-pairs 7"
+for ab in nt=28:63 attn_pf=0:8,0,-1 attn_pf_cut=0,0:400,700,128; do
+  timeout 300 python bench.py $B --ab $ab 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('batch 1', d['ab'])"
 done
+timeout 300 python bench.py --batch 8 $B --ab attn_nt=0:2 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('batch 8', d['ab'])"
