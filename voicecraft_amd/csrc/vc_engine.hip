@@ -127,6 +127,7 @@ struct vc_engine {
   // from 5 rows up (in-process A/Bs, profiles/r04b_bench_batch*.json.log: 8 rows -3.4 % +- 0.1 with two, 4 rows +0.5 % +- 0.05:
   // there half of the 8 waves have no row to fold)
   int lnw_tiles = 0;
+  int fr_split_rows = VC_FR_MAX_ROWS;   // option "fr_split_rows": passes of more rows run the attention unsplit (it normalises itself, plain out-projection prologue)
   int attn_blocks_multi = 512, attn_blocks_one = 256;   // VC_ATTN_BLOCKS / VC_ATTN_BLOCKS1: attention workgroups aimed at (several rows / one row)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
@@ -318,7 +319,7 @@ bool lnw_two(const vc_engine* e, int rows) { return e->lnw_tiles == 2 || (e->lnw
 // splits of the decode attention in the finished-row form: the out-projection merges rows x splits <= 16 partials per thread in
 // one batch of loads; from 9 rows up the attention is unsplit (rows x heads >= 144 workgroups) and normalises itself
 int fr_nsplit(vc_engine* e, int rows) {
-  if (rows > VC_FR_MAX_ROWS) return 1;
+  if (rows > std::min(e->fr_split_rows, VC_FR_MAX_ROWS)) return 1;
   int ns = std::min(attn_nsplit(e, rows), 16 / rows);
   int p = 1;
   while (p * 2 <= ns) p *= 2;
@@ -869,6 +870,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
   } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
   } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
+  } else if (name == "fr_split_rows") { e->fr_split_rows = std::max(1, std::min(v0, VC_FR_MAX_ROWS));
   } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
   } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
   } else if (name == "nt") { e->nt_decode = v0 & 63;
@@ -882,9 +884,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles);
+           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows);
   e->opt_state = buf;
 }
 
