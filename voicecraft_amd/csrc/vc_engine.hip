@@ -308,9 +308,16 @@ int fr_max_rows(const vc_engine* e) {
   const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
   const int KT = 4 * e->d / KW;
   int r = std::min(e->fr_rows, VC_ROWS);
+  // (mirrors vc_launch_gemm_fr: a thread stages at most 16 units of X per piece, a wave holds its fragments of one piece - or
+  // of both halves, 2 x {2, 4, 8, 16} - in registers)
+  const long esz = e->dtype == VC_DTYPE_BF16 ? 2 : 4;
+  const long upr = 4L * e->d * esz / 16;
+  const long per_thread_cap = 16L * 64 * VC_FR_WAVES;
   auto fits = [&](int rows) {
-    if (vc_gemm_fr_lds_bytes(rows, 4 * e->d, e->dtype) <= 150 * 1024 && rows <= VC_FR_MAX_ROWS) return true;
-    return KT % (2 * VC_FR_WAVES) == 0 && KT / (2 * VC_FR_WAVES) <= 16 && vc_gemm_fr_lds_bytes(rows, 2 * e->d, e->dtype) <= 150 * 1024;
+    if (KT % VC_FR_WAVES == 0 && rows * upr <= per_thread_cap && vc_gemm_fr_lds_bytes(rows, 4 * e->d, e->dtype) <= 150 * 1024) return true;
+    const int k2 = KT / (2 * VC_FR_WAVES);
+    return KT % (2 * VC_FR_WAVES) == 0 && (k2 == 2 || k2 == 4 || k2 == 8 || k2 == 16) && rows * (upr / 2) <= per_thread_cap &&
+           vc_gemm_fr_lds_bytes(rows, 2 * e->d, e->dtype) <= 150 * 1024;
   };
   while (r >= 2 && !fits(r)) --r;
   return r >= 2 ? r : 0;

@@ -1800,6 +1800,7 @@ static hipError_t launch_ktw(const GemmArgs& a, int dtype, int pro, int epi, int
     if (epi == EPI_RELU) return a.nt ? launch_dec_nt<WT, KTW, PRO_LNW, EPI_RELU, 2, true, true>(a, dtype, ksplit, groups, s)
                                      : launch_dec_nt<WT, KTW, PRO_LNW, EPI_RELU, 2, false, true>(a, dtype, ksplit, groups, s);
   }
+  if (pro == PRO_LNW && a.n_rows > VC_FR_MAX_ROWS) return hipErrorInvalidValue;   // (9..16 rows exist only in the two-rows-per-wave form above)
   if (pro == PRO_LNW && a.mt == 3 && a.n_tiles % 2 == 0 && groups == 1) {     // two tiles per workgroup (finished-row consumers, GemmArgs.mt)
     if (epi == EPI_QKV) return launch_dec<WT, KTW, PRO_LNW, EPI_QKV, 2>(a, dtype, ksplit, groups, s);
     if (epi == EPI_RELU) return launch_dec<WT, KTW, PRO_LNW, EPI_RELU, 2>(a, dtype, ksplit, groups, s);
