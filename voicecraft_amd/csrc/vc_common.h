@@ -191,7 +191,9 @@ enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2, PRO_LNW = 3 };      // PRO_LNW: L
 enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4, EPI_RES = 5 };   // EPI_RES: h_out = h_in + bias + W x (whole rows)
 #define VC_TH_RES 8         // output channels per weight tile of the finished-row producers (rows_gemm_fr_k): d/8 workgroups
 #define VC_FR_WAVES 8       // waves of a finished-row producer workgroup (each streams K/8 of its 8 channels in ONE burst)
-#define VC_FR_MAX_ROWS 8    // rows a finished-row pass may carry (X of the FFN down-projection: rows x 4d elements in LDS)
+#define VC_FR_MAX_ROWS 8    // finished-row passes of up to this many rows: one row per consumer wave, split attention merged by the
+                            // out-projection, X of the FFN down-projection (rows x 4d elements) in LDS in one piece; 9..VC_ROWS rows: two
+                            // rows per wave, unsplit attention, FFN down-projection through LDS in two halves (rows_gemm_fr2_k)
 
 // ---------------------------------------------------------------- piggyback weight prefetch
 // A launch that leaves HBM idle (the one-row attention launch, the per-row LayerNorm launches of a several-row step) carries

@@ -689,7 +689,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   VC_KTS_FLUSH();
 }
 
-// ------------------------------------------------------------------ finished-row producers: decode passes of 2..8 rows
+// ------------------------------------------------------------------ finished-row producers: decode passes of 2..8 rows (9..16: also rows_gemm_fr2_k below)
 // A several-row decode step (config 5's per-GPU share: 8 utterances) spent 18 % of its kernel time in two 8-workgroup
 // LayerNorm launches per layer: the out-projection and the FFN down-projection leave split-K slabs, the sum of h + bias +
 // 4 slabs per row is too much to redo in every consumer workgroup (320 KB each), so a launch of its own did it once.  Here
@@ -709,7 +709,7 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr_k(const GemmArg
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x;
-  const int n_rows = a.n_rows;                    // 2..8 (host contract)
+  const int n_rows = a.n_rows;                    // 2..16 as far as rows x K fits LDS and 16 staging units per thread (host contract)
   const int K = a.K;
   const int xs = K * (int)sizeof(WT) + 16;        // LDS row stride (+16: rotate bank slots)
   char* xl = smem;
