@@ -207,6 +207,12 @@ int vc_pattern_unshift(const int64_t* span_dev, int N, int K, int64_t* out_dev, 
  * Only top_k / top_p / temperature / seed of `sc` are read.  No engine needed. */
 int vc_debug_sample(const float* logits_dev, int V, const vc_sample_cfg* sc, int n_draws,
                     int32_t* out_dev, void* stream);
+/* Host-only (no engine, no GPU): how a decode pass of `rows` rows is launched for this model shape and compute dtype.
+ * out[0] rows up to which the finished-row form applies; out[1] form of this pass (0 slabs + rows-GEMM, 1 finished rows, 2 wide
+ * decode); out[2] attention splits; out[3] consumer kernel shape (GemmArgs.mt) or -1; out[4] / out[5] producer form of the
+ * out-projection / FFN down-projection (1 one piece, 2 K in two halves, 0 = NOT LAUNCHABLE, -1 n/a); out[6] heads-1 folds finished
+ * rows itself; out[7] the consumers' tile counts are even.  tests/test_plan_cpu.py walks every model width with it. */
+int vc_debug_plan(const vc_model_cfg* cfg, int compute_dtype, int rows, int32_t out[8]);
 /* Copies a named internal device buffer to host memory. */
 int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int64_t nbytes);
 /* Timing of the last vc_tts/vc_edit call, measured with HIP events on `stream`:

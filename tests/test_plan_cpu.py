@@ -1,0 +1,57 @@
+"""Host-side pass planning without a GPU (vc_debug_plan): for EVERY model width the engine accepts (d a multiple of 256 up to
+2048; head_dim 32 / 64 / 128), both compute dtypes and every row count of a decode pass, the form the engine would pick must be
+one the kernel launchers accept - the finished-row producers have shape constraints (rows x K of X in one workgroup's LDS in one or
+two pieces, a wave's fragments in registers, rows x splits <= 16 partials per thread) that only a few widths exercise on hardware."""
+import ctypes as C
+
+import pytest
+
+from voicecraft_amd import _lib
+from voicecraft_amd._lib import ModelCfg
+
+WIDTHS = [(d, h) for d in range(256, 2049, 256) for h in (d // 32, d // 64, d // 128) if h >= 1 and d % h == 0 and d // h in (32, 64, 128)]
+
+
+def plan(d, h, dtype, rows):
+    cfg = ModelCfg(d_model=d, nhead=h, num_layers=2, n_codebooks=4, audio_vocab_size=2048, n_special=4, text_rows=101, head_hidden=1024,
+                   empty_token=2048, eog=2049, audio_pad_token=2050, eos=2051, reduced_eog=1, encodec_sr=50, max_n_spans=3, max_seqs=64,
+                   max_positions=1024)
+    out = (C.c_int32 * 8)()
+    assert _lib.load().vc_debug_plan(C.byref(cfg), dtype, rows, out) == 0
+    return list(out)
+
+
+@pytest.mark.parametrize("dtype", [_lib.VC_DTYPE_BF16, _lib.VC_DTYPE_F32])
+def test_every_planned_pass_is_launchable(dtype):
+    seen_forms = set()
+    for d, h in WIDTHS:
+        for rows in range(1, 65):
+            frmax, form, nsplit, mt, oform, dform, heads_lnw, even = plan(d, h, dtype, rows)
+            assert even == 1, (d, h)
+            assert 0 <= frmax <= 16 and 1 <= nsplit <= 8
+            if rows == 1:
+                assert form == 0
+            if rows > 16:
+                assert form == 2 and nsplit == 1
+            if form == 1:
+                assert 2 <= rows <= frmax
+                assert oform == 1 and dform in (1, 2), (d, h, dtype, rows, oform, dform)
+                assert mt in ((4,) if rows > 8 else (0, 3)), (d, rows, mt)
+                assert nsplit * rows <= 16 or nsplit == 1
+                assert (nsplit == 1) == (rows > 8)
+                assert heads_lnw == (1 if rows <= 8 else 0)
+                seen_forms.add((dform, mt))
+            elif rows <= 16:
+                assert rows == 1 or rows > frmax
+    assert (1, 0) in seen_forms and (1, 3) in seen_forms and (2, 4) in seen_forms, seen_forms
+
+
+def test_the_benchmarked_shapes_take_the_forms_the_profiles_describe():
+    bf, f32 = _lib.VC_DTYPE_BF16, _lib.VC_DTYPE_F32
+    assert plan(2048, 16, bf, 8)[:6] == [16, 1, 2, 3, 1, 1]          # config 5's share: split 2, two tiles per consumer workgroup, one piece
+    assert plan(2048, 16, bf, 16)[:6] == [16, 1, 1, 4, 1, 2]         # 16 rows: unsplit attention, two rows per wave, FFN-down in two halves
+    assert plan(2048, 16, bf, 4)[:6] == [16, 1, 4, 0, 1, 1]
+    assert plan(2048, 16, bf, 2)[2] == 8 and plan(2048, 16, bf, 1)[:3] == [16, 0, 8]
+    assert plan(2048, 16, f32, 4)[:2] == [4, 1] and plan(2048, 16, f32, 5)[1] == 0      # exact mode at d = 2048: X of 4 rows fills the LDS
+    assert plan(1024, 16, bf, 16)[:6] == [16, 1, 1, 4, 1, 1]         # giga330M: 16 rows x 8 KB still one piece
+    assert plan(2048, 16, bf, 32)[1] == 2

@@ -411,6 +411,7 @@ hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ks
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
 hipError_t vc_launch_gemm_fr(const GemmArgs& a, int dtype, int pro, hipStream_t s);   // finished-row producers (vc_gemm.hip)
 size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype);
+int vc_gemm_fr_form(int rows, int N, int K, int dtype, int pro, int nsplit);   // 0 none, 1 one piece, 2 K in two halves
 extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production
 // Launch census (process-wide, host side): which kernel FORM each launcher picked.  Read through
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one

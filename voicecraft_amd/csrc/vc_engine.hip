@@ -303,23 +303,10 @@ int attn_nsplit(vc_engine* e, int rows) {
 // Rows a pass may carry in the finished-row form: X of the FFN down-projection (rows x 4d elements) has to fit the LDS
 // of one workgroup, and the out-projection merges rows x nsplit <= 16 attention partials per thread in one batch.
 int fr_max_rows(const vc_engine* e) {
-  // one piece: rows x 4d elements of X in one workgroup's LDS (8 rows in bf16 at d = 2048, 4 in the exact mode); two halves
-  // (rows_gemm_fr2_k): rows x 2d elements, and a wave must hold its fragments of both halves (KT / 16 <= 16 per half)
-  const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
-  const int KT = 4 * e->d / KW;
+  // the FFN down-projection decides (X = rows x 4d elements): one piece up to 8 rows in bf16 at d = 2048 (4 in the exact mode), two
+  // halves beyond while a wave can hold its fragments of both; vc_gemm_fr_form is the launcher's own statement of that
   int r = std::min(e->fr_rows, VC_ROWS);
-  // (mirrors vc_launch_gemm_fr: a thread stages at most 16 units of X per piece, a wave holds its fragments of one piece - or
-  // of both halves, 2 x {2, 4, 8, 16} - in registers)
-  const long esz = e->dtype == VC_DTYPE_BF16 ? 2 : 4;
-  const long upr = 4L * e->d * esz / 16;
-  const long per_thread_cap = 16L * 64 * VC_FR_WAVES;
-  auto fits = [&](int rows) {
-    if (KT % VC_FR_WAVES == 0 && rows * upr <= per_thread_cap && vc_gemm_fr_lds_bytes(rows, 4 * e->d, e->dtype) <= 150 * 1024) return true;
-    const int k2 = KT / (2 * VC_FR_WAVES);
-    return KT % (2 * VC_FR_WAVES) == 0 && (k2 == 2 || k2 == 4 || k2 == 8 || k2 == 16) && rows * (upr / 2) <= per_thread_cap &&
-           vc_gemm_fr_lds_bytes(rows, 2 * e->d, e->dtype) <= 150 * 1024;
-  };
-  while (r >= 2 && !fits(r)) --r;
+  while (r >= 2 && vc_gemm_fr_form(r, e->d, 4 * e->d, e->dtype, PRO_PLAIN, 1) == 0) --r;
   return r >= 2 ? r : 0;
 }
 bool lnw_two(const vc_engine* e, int rows) { return e->lnw_tiles == 2 || (e->lnw_tiles == 0 && rows >= 5) || rows > VC_FR_MAX_ROWS; }
@@ -900,6 +887,26 @@ void refresh_opt_state(vc_engine* e) {
 }  // namespace
 
 // =====================================================================================  C ABI
+// Host-only: how a decode pass of `rows` rows would be launched for this model shape and compute dtype (no engine, no GPU).
+extern "C" int vc_debug_plan(const vc_model_cfg* c, int compute_dtype, int rows, int32_t out[8]) {
+  if (!c || !out || rows < 1 || rows > VC_MAX_SEQS || c->d_model <= 0 || c->nhead <= 0 || c->d_model % c->nhead) return VC_EINVAL;
+  if (compute_dtype != VC_DTYPE_BF16 && compute_dtype != VC_DTYPE_F32) return VC_EINVAL;
+  vc_engine e;
+  e.cfg = *c; e.d = c->d_model; e.H = c->nhead; e.hd = c->d_model / c->nhead; e.dtype = compute_dtype;
+  const int d = e.d, frmax = fr_max_rows(&e);
+  const bool fr = rows >= 2 && rows <= VC_ROWS && rows <= frmax;
+  const int ns = fr ? fr_nsplit(&e, rows) : attn_nsplit(&e, rows);
+  out[0] = frmax;
+  out[1] = rows > VC_ROWS ? 2 : fr ? 1 : 0;                                   // 0 slab form (rows-GEMM), 1 finished-row form, 2 wide decode
+  out[2] = rows > VC_ROWS ? 1 : ns;                                           // attention splits
+  out[3] = fr ? (rows > VC_FR_MAX_ROWS ? 4 : lnw_two(&e, rows) ? 3 : 0) : -1; // consumers: GemmArgs.mt (0 one tile, 3 two tiles, 4 two tiles x two rows per wave)
+  out[4] = fr ? vc_gemm_fr_form(rows, d, d, compute_dtype, ns == 1 ? PRO_PLAIN : PRO_ATT, ns) : -1;    // out-projection producer form
+  out[5] = fr ? vc_gemm_fr_form(rows, d, 4 * d, compute_dtype, PRO_PLAIN, 1) : -1;                      // FFN-down producer form
+  out[6] = fr && rows <= VC_FR_MAX_ROWS ? 1 : 0;                              // heads-1 folds finished rows itself (else LayerNorm launch)
+  out[7] = (3 * d / VC_TH_QKV) % 2 == 0 && (4 * d / 16) % 2 == 0 ? 1 : 0;     // the consumers' tile counts are even (two tiles per workgroup)
+  return VC_OK;
+}
+
 extern "C" int vc_set_option(vc_engine* e, const char* name, const char* value) {
   int rc = check_ready(e);
   if (rc) return rc;

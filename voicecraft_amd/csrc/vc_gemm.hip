@@ -990,7 +990,34 @@ size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype) {
 }
 // A finished-row producer pass: out-projection (PRO_ATT) or FFN down-projection (PRO_PLAIN) of 2..VC_FR_MAX_ROWS rows; a.Wp
 // is the 8-channel-tile image of the matrix, a.h_in the residual rows, a.bias the layer's bias, a.h_out the finished rows.
+// Which form a finished-row producer pass takes - 0: none (the launcher refuses it), 1: X in LDS in one piece (rows_gemm_fr_k),
+// 2: K through LDS in two halves (rows_gemm_fr2_k, plain prologue only).  The ONE statement of the constraints: the launcher
+// below and the engine's pass planning (vc_engine.hip fr_max_rows, checked for every model width by tests/test_plan_cpu.py
+// through vc_debug_plan) both go through it.
+int vc_gemm_fr_form(int rows, int N, int K, int dtype, int pro, int nsplit) {
+  const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16, esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
+  if (rows < 1 || rows > VC_ROWS || N % VC_TH_RES != 0 || K % KW != 0) return 0;
+  const int KT = K / KW;
+  const long upr = (long)K * esz / 16, cap = 16L * 64 * VC_FR_WAVES;        // 16-byte units of X per row; units a workgroup stages per piece
+  const size_t lds_max = 160 * 1024;
+  if (pro == PRO_ATT) {        // the out-projection merging split partials: K = d <= 2048 (a wave's share <= 16 fragments), one batch of loads
+    const int ns = nsplit > 4 ? 8 : nsplit > 2 ? 4 : 2;
+    if (nsplit < 1 || nsplit > 8 || rows * ns > 16 || (long)rows * (K / 4) > 16L / ns * 64 * VC_FR_WAVES) return 0;
+    if (KT % VC_FR_WAVES != 0 || KT / VC_FR_WAVES > 16) return 0;
+    return vc_gemm_fr_lds_bytes(rows, K, dtype) <= lds_max ? 1 : 0;
+  }
+  if (pro != PRO_PLAIN) return 0;
+  if (KT % VC_FR_WAVES == 0 && rows * upr <= cap && vc_gemm_fr_lds_bytes(rows, K, dtype) <= lds_max) return 1;
+  const int k2 = KT / (2 * VC_FR_WAVES);
+  if (KT % (2 * VC_FR_WAVES) == 0 && (k2 == 2 || k2 == 4 || k2 == 8 || k2 == 16) && rows * (upr / 2) <= cap &&
+      vc_gemm_fr_lds_bytes(rows, K / 2, dtype) <= lds_max)
+    return 2;
+  return 0;
+}
+
 hipError_t vc_launch_gemm_fr(const GemmArgs& a0, int dtype, int pro, hipStream_t s) {
+  const int form = vc_gemm_fr_form(a0.n_rows, a0.N, a0.K, dtype, pro, a0.nsplit);
+  if (form == 0) return hipErrorInvalidValue;
   GemmArgs a = a0;
   const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16;
   a.n_tiles = a.N / VC_TH_RES;
@@ -1007,7 +1034,7 @@ hipError_t vc_launch_gemm_fr(const GemmArgs& a0, int dtype, int pro, hipStream_t
     if ((1 << sft) == upr) a.x_upr_shift = sft;
     if ((1 << sft) == q4) a.att_q4_shift = sft;
   }
-  if (pro == PRO_PLAIN && (long)a.n_rows * upr > 16L * 64 * VC_FR_WAVES) {
+  if (form == 2) {
     // X does not fit the LDS of a workgroup in one piece: K in two halves (rows_gemm_fr2_k), one burst of weights per half
     const int ktw2 = a.KT / (2 * VC_FR_WAVES);
     if (a.KT % (2 * VC_FR_WAVES) != 0 || (long)a.n_rows * (upr / 2) > 16L * 64 * VC_FR_WAVES || a.n_rows > VC_ROWS) return hipErrorInvalidValue;
