@@ -25,12 +25,15 @@
 //
 // Block = 4 waves sharing one 16-row output tile; the waves split the block's K range 4 ways and
 // reduce through LDS.  Cross-block split-K (EPI_PART) leaves fp32 partial slabs that the NEXT
-// kernel's LayerNorm prologue sums (launch-boundary reduce: no atomics, deterministic).
+// kernel's LayerNorm prologue sums (launch-boundary reduce: no atomics, deterministic) - the form of ONE-row steps.
+// Steps of 2..16 rows keep whole residual rows instead (finished-row form, round 4): rows_gemm_fr_k / rows_gemm_fr2_k produce
+// them, the PRO_LNW prologue of rows_gemm_k folds their LayerNorm one wave per row.
 #include "vc_common.h"
 
 // ------------------------------------------------------------------ packing
-// th = output channels per tile: 16 (every lane of the A fragment) or 12 (VC_TH_QKV: lanes with
-// (lane & 15) >= 12 carry no weight and nothing is stored for them - a tile is 4 x 12 fragments).
+// th = output channels per tile: 16 (every lane of the A fragment), 12 (VC_TH_QKV: lanes with
+// (lane & 15) >= 12 carry no weight and nothing is stored for them - a tile is 4 x 12 fragments) or 8 (VC_TH_RES: the second
+// image of the out-projection / FFN-down matrices that the finished-row producers stream, d/8 whole-K tiles).
 template <typename WT>
 __global__ void pack_k(const float* __restrict__ src, const float* __restrict__ colscale, WT* __restrict__ dst,
                        int N, int K, int KT, long total, int th) {
