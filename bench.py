@@ -464,7 +464,8 @@ def main():
             ms_, by_ = eng.bench_kernel(kn, n_rows=mb_rows, iters=64)
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
         fr_form = 2 <= mb_rows <= 16 and "|fr0" not in eng.options()       # several-row steps: the finished-row producer is what runs
-        roof = {"bound": "hbm", "kernel": ("rows_gemm_fr_k<plain> (FFN down-projection, finished rows: 8-channel tiles over the whole K)" if fr_form
+        roof = {"bound": "hbm", "kernel": (("rows_gemm_fr_k<plain> (FFN down-projection, finished rows: 8-channel tiles over the whole K)" +
+                                            ("" if B <= 16 else f"; microbenchmarked at 16 rows - this run's {B}-row steps use the wide-decode kernel rows_gemm_mt_k")) if fr_form
                                            else "rows_gemm_k<plain,split-K slabs> (FFN down-projection)"),
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn2", args),
