@@ -497,6 +497,219 @@ __global__ __launch_bounds__(64 * NW) void tile_attn_k(const AttnArgs a) {
   }
 }
 
+// ---------------------------------------------------------------- prefill attention, second form: 64 query rows per workgroup
+// tile_attn_k gives a wave 16 query rows and a QUARTER of the keys: ~450 VALU instructions per 16 MFMAs (32 DPP steps of row
+// reductions per 16 x 32 score tile, P through LDS, every wave staging its own V tile) and a cross-wave merge at the end -
+// 0.03-0.08 of the bf16 MFMA peak.  Here (bf16, head_dim 128; prompts laid out on 64-row boundaries, vc_engine.hip prefill_batch):
+//   workgroup = 64 consecutive rows of one sequence x one head; wave w owns row tile w for ALL key tiles: no merge.
+//   key tiles of 64 keys; K and V of a tile are staged ONCE per workgroup (8 x 16 B per thread), double-buffered, one block
+//     barrier per tile; the next tile's global loads fly during this tile's MFMAs.
+//     K: fragment-linear (fragment (sub, ks) = 1 KB, lane l at 16 l: every ds_read_b128 conflict-free); wave w stages sub-tile w.
+//     V: row-major [key][128 dims], the 16-byte slot index XOR-ed with ((key & 3) << 2 | (key >> 2) & 3), so that the transposed
+//        reads of 4 keys x 4 lane groups spread over all banks; wave w stages keys 16 w .. 16 w + 15.
+//   the score product is computed TRANSPOSED: S^T = K Q^T (A = K fragments, B = Q fragments).  Its D layout - lane (m, kg) holds
+//     keys 4 kg .. 4 kg + 3 of every 16-key sub-tile for QUERY m - gives each lane ONE query row: running maximum and sum are one
+//     scalar per lane, the row reductions two cross-lane steps (lanes m, m + 16, m + 32, m + 48), and the eight probabilities of two
+//     sub-tiles, packed to bf16, ARE the B fragment of O^T += V^T P^T for the 32-key step whose k order is (4 kg .. 4 kg + 3 of the
+//     first sub-tile, then of the second) - P never leaves the registers; the A fragments (V^T in the same key order) come from
+//     the V tile through two ds_read_b64_tr_b16 each (semantics as in tile_attn_k, tools/tr_probe.hip).
+//   per 16 x 64 score tile and wave: 32 MFMAs against ~100 VALU instructions and 48 LDS reads.
+#define VC_TA2_KEYS 64
+__global__ __launch_bounds__(256) void tile_attn64_k(const AttnArgs a) {
+  using WT = bf16_t;
+  constexpr int HD = 128, KEYS = VC_TA2_KEYS, NKS = HD / 32, NDT = HD / 16;
+  constexpr int KBYTES = KEYS * HD * 2, STAGE = 2 * KBYTES;            // 16 KB of K fragments + 16 KB of V rows per stage
+  extern __shared__ __attribute__((aligned(16))) char smem[];           // 2 stages = 64 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m = lane & 15, kg = lane >> 4;
+  const int h = blockIdx.x, r0 = ((int)gridDim.y - 1 - (int)blockIdx.y) * 64;      // longest blocks first
+  const int share = *a.share_len;
+  // the block's rows: consecutive positions of one sequence, padding (row_pos = -1) only at the end
+  const int rp_blk = (r0 + lane < a.n_rows) ? a.row_pos[r0 + lane] : -1;
+  const int na_total = __popcll(__ballot(rp_blk >= 0));
+  const int pos_blk = __builtin_amdgcn_readfirstlane(rp_blk);           // position of the block's first row
+  if (na_total == 0 || pos_blk < 0) {                                    // nothing but padding: zero rows, as tile_attn_k leaves them
+    for (int e2 = tid; e2 < 64 * HD; e2 += 256) {
+      const int row = r0 + e2 / HD;
+      if (row < a.n_rows) WTr<WT>::st(reinterpret_cast<WT*>(a.x_out) + (long)row * a.d + h * HD + (e2 % HD), 0.f);
+    }
+    return;
+  }
+  const int seq = a.row_seq[r0];
+  const int blk_last = pos_blk + na_total - 1;                           // last key any row of the block sees
+  const int tpos0 = pos_blk + 16 * wave;                                 // first position of this wave's row tile
+  const int na_w = max(0, min(16, na_total - 16 * wave));                // active rows of the tile
+  const int t_last = tpos0 + na_w - 1;
+  const int qpos = (m < na_w) ? tpos0 + m : -1;
+  const long hbase = (long)h * a.S_max * HD;
+  const WT* kc = reinterpret_cast<const WT*>(a.kcache) + hbase;
+  const WT* vc = reinterpret_cast<const WT*>(a.vcache) + hbase;
+  const long own = (long)seq * a.cache_seq_stride;
+  // ---- staging roles of this thread: K sub-tile `wave` (fragment (wave, ks): key 16 wave + m, dims 32 ks + 8 kg), V keys
+  //      16 wave + 4 i + (lane >> 4), slot' = lane & 15 holding the row's 16-byte piece slot' ^ v(key)
+  // (explicit scalars and macros: arrays captured by a lambda are demoted to scratch memory here)
+  uint4 sk0, sk1, sk2, sk3, sv0, sv1, sv2, sv3;
+#define VC_TA2_LOADV(i_, dst_)                                                                   \
+  {                                                                                              \
+    const int key_ = 16 * wave + 4 * (i_) + (lane >> 4);   /* key index inside the tile */      \
+    const int v_ = (((key_ & 3) << 2) | ((key_ >> 2) & 3));                                      \
+    const int kp_ = min(kt0_ + key_, blk_last);                                                  \
+    dst_ = *reinterpret_cast<const uint4*>(vc + ((kp_ < share) ? 0 : own) + (long)kp_ * HD + 8 * ((lane & 15) ^ v_)); \
+  }
+#define VC_TA2_STAGE_LOAD(kt0_arg)                                                               \
+  {                                                                                              \
+    const int kt0_ = (kt0_arg);                                                                  \
+    const int kpk_ = min(kt0_ + 16 * wave + m, blk_last);                                        \
+    const WT* kr_ = kc + ((kpk_ < share) ? 0 : own) + (long)kpk_ * HD + 8 * kg;                  \
+    sk0 = *reinterpret_cast<const uint4*>(kr_); sk1 = *reinterpret_cast<const uint4*>(kr_ + 32); \
+    sk2 = *reinterpret_cast<const uint4*>(kr_ + 64); sk3 = *reinterpret_cast<const uint4*>(kr_ + 96); \
+    VC_TA2_LOADV(0, sv0) VC_TA2_LOADV(1, sv1) VC_TA2_LOADV(2, sv2) VC_TA2_LOADV(3, sv3)          \
+  }
+#define VC_TA2_STAGE_STORE(st_arg)                                                               \
+  {                                                                                              \
+    char* st_ = (st_arg);                                                                        \
+    *reinterpret_cast<uint4*>(st_ + (wave * NKS + 0) * 1024 + lane * 16) = sk0;                  \
+    *reinterpret_cast<uint4*>(st_ + (wave * NKS + 1) * 1024 + lane * 16) = sk1;                  \
+    *reinterpret_cast<uint4*>(st_ + (wave * NKS + 2) * 1024 + lane * 16) = sk2;                  \
+    *reinterpret_cast<uint4*>(st_ + (wave * NKS + 3) * 1024 + lane * 16) = sk3;                  \
+    *reinterpret_cast<uint4*>(st_ + KBYTES + (wave * 4 + 0) * 1024 + lane * 16) = sv0;           \
+    *reinterpret_cast<uint4*>(st_ + KBYTES + (wave * 4 + 1) * 1024 + lane * 16) = sv1;           \
+    *reinterpret_cast<uint4*>(st_ + KBYTES + (wave * 4 + 2) * 1024 + lane * 16) = sv2;           \
+    *reinterpret_cast<uint4*>(st_ + KBYTES + (wave * 4 + 3) * 1024 + lane * 16) = sv3;           \
+  }
+  static_assert(NKS == 4, "the staging macros are written for head_dim 128");
+  VC_TA2_STAGE_LOAD(0)
+  // ---- Q fragments of the wave's row tile, pre-scaled to log2 units (B operand of S^T)
+  uint4 qf[NKS];
+  {
+    const float qs = a.scale * 1.4426950408889634f;
+    const float* qp = a.q + (long)min(r0 + 16 * wave + m, a.n_rows - 1) * a.d + h * HD + 8 * kg;
+#pragma unroll
+    for (int ks = 0; ks < NKS; ++ks) {
+      WT tmp[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) WTr<WT>::st(&tmp[j], qp[32 * ks + j] * qs);
+      qf[ks] = *reinterpret_cast<const uint4*>(tmp);
+    }
+  }
+  float mrun = -INFINITY, lsum = 0.f;                                    // lsum: this lane's share of the row sum (its own keys)
+  f32x4 o[NDT];
+#pragma unroll
+  for (int dt = 0; dt < NDT; ++dt) o[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  VC_TA2_STAGE_STORE(smem)
+  __syncthreads();
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const int vkey = (((m >> 2) & 3) << 2) | kg;                           // v(key) of the keys this lane addresses in the transposed reads
+  const int nkt = blk_last / KEYS + 1;
+  for (int t = 0; t < nkt; ++t) {
+    const int kt0 = t * KEYS;
+    char* st = smem + (t & 1) * STAGE;
+    const bool more = t + 1 < nkt;
+    if (more) VC_TA2_STAGE_LOAD(kt0 + KEYS)                              // in flight during this tile's MFMAs
+    if (na_w > 0 && kt0 <= t_last) {
+      // ---- S^T = K Q^T: lane (query m, kg) gets keys kt0 + 16 sub + 4 kg + r
+      f32x4 sc[4];
+#pragma unroll
+      for (int sub = 0; sub < 4; ++sub) {
+        sc[sub] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+          const uint4 kf = *reinterpret_cast<const uint4*>(st + (sub * NKS + ks) * 1024 + lane * 16);
+          sc[sub] = mfma_frag(kf, qf[ks], sc[sub], (WT*)nullptr);
+        }
+      }
+      // ---- online softmax of ONE query row per lane
+      float mx = -INFINITY;
+      if (kt0 + KEYS - 1 <= tpos0) {                                     // interior tile: every key visible to every row of the tile
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, sc[sub][r]);
+      } else {                                                           // the causal mask cuts through it
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int kp = kt0 + 16 * sub + 4 * kg + r;
+            sc[sub][r] = (kp <= qpos) ? sc[sub][r] : -INFINITY;
+            mx = fmaxf(mx, sc[sub][r]);
+          }
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float mn = fmaxf(mrun, mx);
+      const float msafe = (mn == -INFINITY) ? 0.f : mn;                  // nothing visible yet: exp2(-inf - 0) = 0 everywhere
+      const float corr = (mrun == mn) ? 1.f : fast_exp2(mrun - msafe);
+      float ps = 0.f;
+      uint4 pf[2];
+      {
+        float p[4][4];
+#pragma unroll
+        for (int sub = 0; sub < 4; ++sub)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) { p[sub][r] = fast_exp2(sc[sub][r] - msafe); ps += p[sub][r]; }
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          pf[c].x = pack_bf16x2(p[2 * c][0], p[2 * c][1]);
+          pf[c].y = pack_bf16x2(p[2 * c][2], p[2 * c][3]);
+          pf[c].z = pack_bf16x2(p[2 * c + 1][0], p[2 * c + 1][1]);
+          pf[c].w = pack_bf16x2(p[2 * c + 1][2], p[2 * c + 1][3]);
+        }
+      }
+      lsum = lsum * corr + ps;
+      mrun = mn;
+      if (__any(corr != 1.f)) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) { o[dt][0] *= corr; o[dt][1] *= corr; o[dt][2] *= corr; o[dt][3] *= corr; }
+      }
+      // ---- O^T += V^T P^T: two 32-key steps; A = V^T fragment of (dim tile dt, step c) through two transposed reads
+      const char* vb = st + KBYTES + (4 * kg + (m >> 2)) * (HD * 2) + (m & 1) * 8;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+          const int slot = ((2 * dt + ((m >> 1) & 1)) ^ vkey) * 16;
+          const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + (2 * c) * 16 * (HD * 2) + slot));
+          const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + (2 * c + 1) * 16 * (HD * 2) + slot));
+          const uint2 l2 = __builtin_bit_cast(uint2, lo), h2 = __builtin_bit_cast(uint2, hi);
+          uint4 vf;
+          vf.x = l2.x; vf.y = l2.y; vf.z = h2.x; vf.w = h2.y;
+          o[dt] = mfma_frag(vf, pf[c], o[dt], (WT*)nullptr);
+        }
+      }
+    }
+    if (more) VC_TA2_STAGE_STORE(smem + ((t + 1) & 1) * STAGE)           // (that buffer's readers left it before the last barrier)
+    __syncthreads();
+  }
+  // ---- the four lanes of a query add up their shares of the row sum; O^T[dim = 16 dt + 4 kg + r][query m] -> x_out[row][dim]
+  lsum += __shfl_xor(lsum, 16, 64);
+  lsum += __shfl_xor(lsum, 32, 64);
+  const int row = r0 + 16 * wave + m;
+  if (row < a.n_rows) {
+    const float inv = (m < na_w && lsum > 0.f) ? 1.0f / lsum : 0.f;
+    WT* xo = reinterpret_cast<WT*>(a.x_out) + (long)row * a.d + h * HD + 4 * kg;
+#pragma unroll
+    for (int dt = 0; dt < NDT; ++dt) {
+      uint2 u;
+      u.x = pack_bf16x2(o[dt][0] * inv, o[dt][1] * inv);
+      u.y = pack_bf16x2(o[dt][2] * inv, o[dt][3] * inv);
+      *reinterpret_cast<uint2*>(xo + 16 * dt) = u;
+    }
+  }
+}
+
+#undef VC_TA2_LOADV
+#undef VC_TA2_STAGE_LOAD
+#undef VC_TA2_STAGE_STORE
+hipError_t vc_launch_tile_attn64(const AttnArgs& a, hipStream_t s) {
+  if (!a.x_out || a.hd != 128) return hipErrorInvalidValue;
+  ++vc_launch_counts[VC_LC_TILE_ATTN];
+  hipLaunchKernelGGL(tile_attn64_k, dim3(a.H, (a.n_rows + 63) / 64), dim3(256), 4 * VC_TA2_KEYS * 128 * 2, s, a);
+  return hipGetLastError();
+}
+
 template <typename WT, int HD, int NW>
 static hipError_t launch_tile_attn(const AttnArgs& a, hipStream_t s) {
   constexpr int VS = WTr<WT>::KW * (int)sizeof(WT) + 16;

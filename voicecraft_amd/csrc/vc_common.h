@@ -422,6 +422,7 @@ extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);
 hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s);
+hipError_t vc_launch_tile_attn64(const AttnArgs& a, hipStream_t s);   // bf16, head_dim 128, prompts on 64-row boundaries
 hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s);
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s);
 hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s);

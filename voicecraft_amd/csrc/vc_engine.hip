@@ -127,6 +127,10 @@ struct vc_engine {
   // from 5 rows up (in-process A/Bs, profiles/r04b_bench_batch*.json.log: 8 rows -3.4 % +- 0.1 with two, 4 rows +0.5 % +- 0.05:
   // there half of the 8 waves have no row to fold)
   int lnw_tiles = 0;
+  // option "tile_attn": prefill attention kernel - 1 = tile_attn_k (16 query rows per wave, keys split over the waves), 2 =
+  // tile_attn64_k (64 query rows per workgroup, transposed score product, P in registers; bf16 / head_dim 128 only, prompts are then
+  // laid out on 64-row boundaries)
+  int tile_attn = 1;
   int fr_split_rows = VC_FR_MAX_ROWS;   // option "fr_split_rows": passes of more rows run the attention unsplit (it normalises itself, plain out-projection prologue)
   int attn_blocks_multi = 512, attn_blocks_one = 256;   // VC_ATTN_BLOCKS / VC_ATTN_BLOCKS1: attention workgroups aimed at (several rows / one row)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
@@ -563,7 +567,8 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
       a.nt = rs.n_active != nullptr ? attn_nt_for(e, rs.n_rows) : 0;      // wide decode passes stream their K/V once, prefill passes re-read it
       if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
-      if (rs.tiled && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
+      if (rs.tiled == 2 && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn64(a, s));
+      else if (rs.tiled && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
       else HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {
@@ -608,7 +613,12 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
     // attention of the prefill works on such tiles; the padding rows are inactive, row_pos = -1)
     size_t i1 = i0;
     int R = 0;
-    auto rows_of = [](const PromptArgs& pa) { return ((pa.Lx + pa.n_cols - pa.skip) + 15) & ~15; };
+    // (tile_attn64_k works on 64-row blocks of one sequence: prompts then start on multiples of 64 rows)
+    long call_rows = 0;
+    for (const PromptArgs& pa : pas) call_rows += pa.Lx + pa.n_cols - pa.skip;
+    const bool attn64 = e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128 && call_rows >= 128 && !getenv("VC_NO_TILE_ATTN");
+    const int al = attn64 ? 64 : 16;
+    auto rows_of = [al](const PromptArgs& pa) { return ((pa.Lx + pa.n_cols - pa.skip) + al - 1) & ~(al - 1); };
     while (i1 < pas.size() && (i1 == i0 || R + rows_of(pas[i1]) <= e->emb_cap)) {
       R += rows_of(pas[i1]);
       ++i1;
@@ -628,7 +638,7 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
       pa.logit_row = e->logit_row + slots[i];
       pa.logit_row_val = last[i - i0] % chunk;            // index of the prompt's last row inside its pass
       HIPCHK(e, vc_launch_prompt(pa, s));
-      row0 += (rows + 15) & ~15;
+      row0 += (rows + al - 1) & ~(al - 1);
     }
     for (int r0 = 0; r0 < R; r0 += chunk) {
       RowSrc rs{};
@@ -636,7 +646,7 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
       rs.row_seq = e->pre_row_seq + r0; rs.row_pos = e->pre_row_pos + r0;
       rs.n_rows = std::min(chunk, R - r0);
       int rc;
-      if (rs.n_rows > VC_ROWS) { rs.nsplit = 1; rs.tiled = getenv("VC_NO_TILE_ATTN") ? 0 : 1; rc = prefill_rows(e, rs, s); }
+      if (rs.n_rows > VC_ROWS) { rs.nsplit = 1; rs.tiled = getenv("VC_NO_TILE_ATTN") ? 0 : (attn64 ? 2 : 1); rc = prefill_rows(e, rs, s); }
       else { rs.nsplit = attn_nsplit(e, rs.n_rows); rc = forward_rows(e, rs, s); }
       if (rc) return rc;
       for (size_t i = i0; i < i1; ++i)
@@ -864,6 +874,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
   } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
   } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
+  } else if (name == "tile_attn") { e->tile_attn = v0 == 2 ? 2 : 1;
   } else if (name == "fr_split_rows") { e->fr_split_rows = std::max(1, std::min(v0, VC_FR_MAX_ROWS));
   } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
   } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
@@ -878,9 +889,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d,%d|ta%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows);
+           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->tile_attn);
   e->opt_state = buf;
 }
 
@@ -1158,7 +1169,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
-                         std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut")})
+                         std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn")})
     if (const char* v = getenv(kv.first))
       if ((rc = apply_option(e, kv.second, v))) return rc;
   refresh_opt_state(e);
@@ -1808,7 +1819,8 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = 1; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = e->pre_row_seq; a.row_pos = e->pre_row_pos; a.n_rows = n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.x_out = e->xn;
-      HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
+      if (e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128) HIPCHK(e, vc_launch_tile_attn64(a, s));
+      else HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);
       if (r) return r;
