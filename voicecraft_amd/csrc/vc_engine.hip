@@ -130,7 +130,9 @@ struct vc_engine {
   // option "tile_attn": prefill attention kernel - 1 = tile_attn_k (16 query rows per wave, keys split over the waves), 2 =
   // tile_attn64_k (64 query rows per workgroup, transposed score product, P in registers; bf16 / head_dim 128 only, prompts are then
   // laid out on 64-row boundaries)
-  int tile_attn = 1;
+  // Default 2 from 768 prompt rows per call ("tile_attn" = "k[,min_rows]"): measured on one layer of giga830M (profiles/r04o_attn64_probe.log)
+  // 512 / 800 / 2048 causal rows: 14.3 / 24.6 / 86.7 us (first kernel) against 15.5 / 21.0 / 52.5 us (second).
+  int tile_attn = 2, tile_attn_min_rows = 768;
   int fr_split_rows = VC_FR_MAX_ROWS;   // option "fr_split_rows": passes of more rows run the attention unsplit (it normalises itself, plain out-projection prologue)
   int attn_blocks_multi = 512, attn_blocks_one = 256;   // VC_ATTN_BLOCKS / VC_ATTN_BLOCKS1: attention workgroups aimed at (several rows / one row)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
@@ -616,7 +618,7 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
     // (tile_attn64_k works on 64-row blocks of one sequence: prompts then start on multiples of 64 rows)
     long call_rows = 0;
     for (const PromptArgs& pa : pas) call_rows += pa.Lx + pa.n_cols - pa.skip;
-    const bool attn64 = e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128 && call_rows >= 128 && !getenv("VC_NO_TILE_ATTN");
+    const bool attn64 = e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128 && call_rows >= e->tile_attn_min_rows && !getenv("VC_NO_TILE_ATTN");
     const int al = attn64 ? 64 : 16;
     auto rows_of = [al](const PromptArgs& pa) { return ((pa.Lx + pa.n_cols - pa.skip) + al - 1) & ~(al - 1); };
     while (i1 < pas.size() && (i1 == i0 || R + rows_of(pas[i1]) <= e->emb_cap)) {
@@ -874,7 +876,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
   } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
   } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
-  } else if (name == "tile_attn") { e->tile_attn = v0 == 2 ? 2 : 1;
+  } else if (name == "tile_attn") {
+    e->tile_attn = v0 == 2 ? 2 : 1;
+    if (n >= 2) e->tile_attn_min_rows = std::max(64, v1);
   } else if (name == "fr_split_rows") { e->fr_split_rows = std::max(1, std::min(v0, VC_FR_MAX_ROWS));
   } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
   } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
@@ -889,9 +893,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d,%d|ta%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d,%d|ta%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->tile_attn);
+           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->tile_attn, e->tile_attn_min_rows);
   e->opt_state = buf;
 }
 
