@@ -130,7 +130,7 @@ struct vc_engine {
   // option "tile_attn": prefill attention kernel - 1 = tile_attn_k (16 query rows per wave, keys split over the waves), 2 =
   // tile_attn64_k (64 query rows per workgroup, transposed score product, P in registers; bf16 / head_dim 128 only, prompts are then
   // laid out on 64-row boundaries)
-  // Default 2 from 768 prompt rows per call ("tile_attn" = "k[,min_rows]"): measured on one layer of giga830M (profiles/r04o_attn64_probe.log)
+  // Default 2 when the call's longest prompt has at least 768 rows ("tile_attn" = "k[,min_rows]"): measured on one layer of giga830M (profiles/r04o_attn64_probe.log)
   // 512 / 800 / 2048 causal rows: 14.3 / 24.6 / 86.7 us (first kernel) against 15.5 / 21.0 / 52.5 us (second).
   int tile_attn = 2, tile_attn_min_rows = 768;
   int fr_split_rows = VC_FR_MAX_ROWS;   // option "fr_split_rows": passes of more rows run the attention unsplit (it normalises itself, plain out-projection prologue)
@@ -616,9 +616,13 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
     size_t i1 = i0;
     int R = 0;
     // (tile_attn64_k works on 64-row blocks of one sequence: prompts then start on multiples of 64 rows)
-    long call_rows = 0;
-    for (const PromptArgs& pa : pas) call_rows += pa.Lx + pa.n_cols - pa.skip;
-    const bool attn64 = e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128 && call_rows >= e->tile_attn_min_rows && !getenv("VC_NO_TILE_ATTN");
+    // ... and only when the call holds a LONG prompt: the kernel's gain grows with the sequence (800 rows -15 %, 2048 rows -39 %
+    // of the attention launch; 512 rows +8 %), while the 64-row layout costs up to 48 padding rows per prompt in every GEMM of the
+    // pass - config 5's eight 231-row prompts would pay 6.7 % more GEMM rows for no attention gain (measured neutral: prefill 5.2 ms
+    // either way, profiles/r04p_default_attn64.log), so they stay on the first kernel and 16-row boundaries
+    long longest = 0;
+    for (const PromptArgs& pa : pas) longest = std::max<long>(longest, pa.Lx + pa.n_cols - pa.skip);
+    const bool attn64 = e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128 && longest >= e->tile_attn_min_rows && !getenv("VC_NO_TILE_ATTN");
     const int al = attn64 ? 64 : 16;
     auto rows_of = [al](const PromptArgs& pa) { return ((pa.Lx + pa.n_cols - pa.skip) + al - 1) & ~(al - 1); };
     while (i1 < pas.size() && (i1 == i0 || R + rows_of(pas[i1]) <= e->emb_cap)) {
