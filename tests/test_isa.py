@@ -65,6 +65,9 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
     for name, (body, _, vgpr) in pick(kern, "tile_attn_k<bf16_t, 128").items():
         assert body.count("ds_read_b64_tr_b16") == 16 and body.count("v_mfma_f32_16x16x32_bf16") == 16, name
         assert body.count("v_exp_f32") >= 8 and vgpr <= 256, name
+    for name, (body, _, vgpr) in pick(kern, "tile_attn64_k(").items():     # second prefill attention: P stays in registers, one barrier per key tile
+        assert body.count("v_mfma_f32_16x16x32_bf16") == 32 and body.count("ds_read_b64_tr_b16") == 32 and body.count("ds_read_b128") == 16, name
+        assert body.count("v_cvt_pk_bf16_f32") >= 8 and vgpr <= 256, (name, vgpr)
     for name, (body, _, _) in pick(kern, "tile_attn_k<float, 128").items():
         assert "ds_read_b64_tr_b16" not in body and body.count("v_mfma_f32_16x16x4_f32") >= 64, name
     for name, (body, _, _) in pick(kern, "rows_attn_k<").items():
