@@ -102,6 +102,9 @@ const char* vc_version(void);
  *                  heads); "attn_nt" 0 / 1 / 2 = the decode attention's K/V loads never / always / from two rows per step
  *   "finished_rows" rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs (0 = off, max 16);
  *   "lnw_tiles"    weight tiles per workgroup of that form's consumers (0 = by row count, 1, 2)
+ *   "tile_attn"    "k[,min_rows]"  prefill attention kernel (1: 16 query rows per wave; 2: 64 per workgroup, P in registers - bf16,
+ *                  head_dim 128, calls whose longest prompt has at least min_rows rows); "fr_split_rows" rows up to which that form's
+ *                  attention stays split
  *   "graph_steps"  decode steps captured per hipGraph;  "ln_split_rows", "attn_blocks", "attn_blocks1", "prefill_rows"
  * Results never depend on an option (tests/test_gpu_options.py).  Captured decode graphs are kept per option state, so an
  * in-process A/B (bench.py --ab) pays for capture once per state.  Unknown names / malformed values: VC_EINVAL. */
