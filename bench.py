@@ -483,6 +483,13 @@ def main():
         mfma["at_run_rows"] = mfma_obj("pf_ffn1", own_rows, f"rows_gemm_blk_k<ReLU> (prefill FFN up-projection, this run's {own_rows}-row pass)")
         mfma["at_2048_rows"] = mfma_obj("pf_ffn1", 2048, "rows_gemm_big_k<ReLU> (prefill FFN up-projection, a 2048-row stream: 256 x 256 tiles, LDS-DMA)")
         mfma["attention"] = mfma_obj("pf_attn", 512, "tile_attn_k (prefill attention, 512 causal rows of one sequence, all heads)")
+        try:      # the second kernel (prompts of >= 768 rows): as many rows as this engine's cache holds, 1024 by default
+            rows_long = min(2048, eng.max_positions) // 64 * 64
+            if rows_long >= 768:
+                mfma["attention"]["long_prompt"] = mfma_obj("pf_attn", rows_long, f"tile_attn64_k (prefill attention, {rows_long} causal rows of one sequence, all heads: "
+                                                            "64 query rows per workgroup, P in registers)")
+        except Exception as e:   # reporting only
+            mfma["attention"]["long_prompt"] = {"error": str(e)}
         # per step TAKEN: the timed region also covers the (graph-rounded) tail of replayed no-op steps after the last sequence
         # retired, so this slightly OVERstates the step (never understates it); the launched count is kept as an annotation
         dec_step_ms = dec_ms / max(1, steps_run)

@@ -1827,7 +1827,8 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = 1; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = e->pre_row_seq; a.row_pos = e->pre_row_pos; a.n_rows = n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.x_out = e->xn;
-      if (e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128) HIPCHK(e, vc_launch_tile_attn64(a, s));
+      // (the kernel a prompt of this many rows would get: prefill_batch's rule)
+      if (e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128 && n_rows >= e->tile_attn_min_rows) HIPCHK(e, vc_launch_tile_attn64(a, s));
       else HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
     } else if (w == "step") {
       int r = forward_rows(e, rs, s);
