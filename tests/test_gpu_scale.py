@@ -235,3 +235,30 @@ def test_giga330M_eight_utterances_and_a_576_row_editing_prefill(giga330):
     assert res.shape == (1, K, 600 - 100 + (n - K))
     rel = rel_l2(lg.cpu().numpy()[steps], want)
     assert rel.max() <= 2e-2, dict(zip(steps, rel.tolist()))
+
+
+def test_twelve_row_decode_in_the_two_half_finished_row_form(giga):
+    """12 sequences per step at d = 2048: the finished-row form beyond 8 rows - unsplit attention that normalises itself, the
+    out-projection on the plain prologue, the FFN down-projection taking K = 8192 through LDS in two halves with 2 x 16 fragments
+    per wave (rows_gemm_fr2_k<bf16, 16>), consumers folding two rows per wave - per-sequence bf16 logits at three steps."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga
+    B, n = 12, 10
+    prompts = [synth.random_prompt(a, 6 + (u % 5), 8 + (u % 7), seed=500 + u) for u in range(B)]
+    forced = np.stack([forced_trajectory(a, n, seed=190 + u, term=a.eos) for u in range(B)], axis=1)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256, use_graph=False)
+    c0 = eng.launch_counts()
+    outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
+                                       _forced=forced, _logit_steps=n)
+    c = delta(eng.launch_counts(), c0)
+    if "|fr0" not in eng.options():
+        assert c["rows_gemm_fr"] >= 2 * a.num_decoder_layers * (n - 1) and c["mt2"] + c["mt4"] == 0, c
+    lg = lg.cpu().numpy()
+    steps = [0, 4, n - 1]
+    worst = 0.0
+    for u in range(B):
+        want = orc.tts_logits_for_trajectory(prompts[u][0], prompts[u][2], forced[:, u], steps=steps).numpy()
+        worst = max(worst, float(rel_l2(lg[steps, u], want).max()))
+        assert outs[u][1].shape[2] == n - a.n_codebooks
+    assert worst <= 2e-2, worst
