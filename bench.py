@@ -51,6 +51,7 @@ def parse():
     p.add_argument("--cpu-steps", type=int, default=64, help="decode steps of the bounded CPU sample (half at the start, half at the end of the run's context)")
     p.add_argument("--cpu-threads", type=int, default=16, help="torch intra-op threads for the CPU baseline (capped at the core count)")
     p.add_argument("--no-codec", action="store_true", help="skip the EnCodec encode/decode timing block")
+    p.add_argument("--no-configs", action="store_true", help="skip the block that times BASELINE configs 1, 2, 4 and 5's per-GPU share on their own engines")
     p.add_argument("--dump", default=None, help="rank 0 writes the token blocks gathered in the last step to this .npz (tests)")
     p.add_argument("--cpu-baseline-only", action="store_true",
                    help="time only the CPU leg (the port, and the unmodified reference when VC_REFERENCE_ROOT names its tree); needs no GPU")
@@ -79,6 +80,43 @@ def pmc_traffic(kernel, args):
         return int(j["kernels"][kernel]["fetch_bytes_per_launch"])
     except Exception:
         return None
+
+
+def in_situ(kernel, args):
+    """The same kernel's IN-SITU average from the committed rocprofv3 kernel trace of THIS command (profiles/in_situ.json, written by
+    tools/in_situ_to_json.py from a tools/prof_decode.sh summary): every launch of the decode loop, rotating layers, caches as the
+    step leaves them - the microbenchmark of `roofline.achieved` runs the kernel back to back on a quiet chip and comes out ~5 %
+    higher.  None unless the trace on file was taken on this run's preset / dtype / batch / Lx / prompt length / mode."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "in_situ.json")) as f:
+            j = json.load(f)
+        want = {"preset": args.preset, "dtype": args.dtype, "batch": args.batch, "lx": args.lx,
+                "prompt_frames": args.prompt_frames, "mode": args.mode}
+        if j.get("config") != want:
+            return None
+        k = j["kernels"][kernel]
+        return {"kernel": k["name"], "avg_us": k["avg_us"], "calls": k["calls"], "frac": round(k["algorithmic_bytes"] / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                "source": j.get("source")}
+    except Exception:
+        return None
+
+
+def options_object(text):
+    """The engine's option state (a compact text, vc_debug_read "options") as a JSON object."""
+    names = {"apf": ("attn_pf", ["slices", "wo_kb", "w1_kb", "scale_quarters", "cut1", "cut2", "cut0"]), "lpf": ("ln_pf", ["workgroups", "qkv_kb", "w1_kb"]),
+             "g": ("graph_steps", None), "ls": ("ln_split_rows", None), "ab": ("attn_blocks", ["several_rows", "one_row"]),
+             "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "lnw_tiles", "split_rows"]),
+             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast"])}
+    out = {"text": text}
+    try:
+        for part in text.split("|"):
+            key, vs = part.split("=", 1)
+            vals = [int(v) for v in vs.split(",")]
+            nm, fields = names.get(key, (key, None))
+            out[nm] = vals[0] if fields is None and len(vals) == 1 else (dict(zip(fields, vals)) if fields else vals)
+    except Exception:       # reporting only
+        pass
+    return out
 
 
 def reference_ratio_note(args):
@@ -281,6 +319,115 @@ def one_sample_block(eng, a, dev, args):
             "codec_tokens_per_sec_end_to_end": round(4 * gen_frames / sec["total"], 1)}
 
 
+def step_alg_bytes(a, dtype, B, s_mean):
+    """Algorithmic HBM bytes of one decode step: every weight once + K/V read and write of each of the B sequences."""
+    d, L, K = a.d_model, a.num_decoder_layers, a.n_codebooks
+    V, P = a.audio_vocab_size + a.n_special, a.audio_vocab_size // 2
+    esz = 2 if dtype == "bf16" else 4
+    w_bytes = esz * (L * (12 * d * d + 13 * d) + 2 * d + K * (d * P + P + P * V + V))
+    return w_bytes + B * esz * 2 * L * d * (s_mean + 1)
+
+
+class Workload:
+    """One benchmark workload on its own engine: BASELINE configs 1-5 differ only in these arguments.  `call(seed)` is one whole
+    `inference_tts` / `inference_tts_multi` / `inference` call (prompt build + prefill + every decode step + un-shift) and returns
+    the generated frames of every utterance."""
+
+    def __init__(self, preset, mode, batch, lx, prompt_frames, top_k, dtype, dev, use_graph=True, rank=0, world=1, sd=None):
+        from voicecraft_amd import synth
+        from voicecraft_amd.engine import VoiceCraftEngine
+        self.preset, self.mode, self.B, self.lx, self.top_k, self.dtype, self.dev = preset, mode, batch, lx, top_k, dtype, dev
+        self.a = a = synth.make_args(preset)
+        self.K = K = a.n_codebooks
+        self.sd = sd if sd is not None else synth.make_state_dict(a, seed=0, perturb=False, mute_eos=True, fast=True)
+        self.edit = mode == "edit"
+        self.span = None
+        if self.edit:      # 16 s utterance (10 frames per phoneme), the middle eighth masked: generation runs to the
+            assert batch == 1, "editing is single-utterance (models/voicecraft.py:607)"      # reference's length cap y_len > 10*Lx
+            prompt_frames = 10 * lx
+            self.span = (prompt_frames * 3 // 8, prompt_frames * 4 // 8)        # SURVEY section 8 C4: [300,400) of 800 frames
+        self.prompt_frames = prompt_frames
+        span = self.span
+        # generated frames: TTS 10 Lx - T (the length cap); editing: the cap minus the rearranged prompt's columns
+        # (two shifted pieces of K extra columns each, two mask placeholders, the end token and the start column)
+        self.Tg = 10 * lx - prompt_frames if not self.edit else 10 * lx - (prompt_frames - (span[1] - span[0]) + 2 * K + 4) + 1
+        self.eng = VoiceCraftEngine(a, self.sd, device=dev, dtype=dtype, max_seqs=max(1, batch),
+                                    max_positions=max(1024, lx + prompt_frames + self.Tg + 64), use_graph=use_graph)
+        # utterance u of this rank = global utterance (u * world + rank); seed = 1 + global index (SURVEY section 8d)
+        self.prompts = [synth.random_prompt(a, lx, prompt_frames, seed=1 + (u * world + rank)) for u in range(batch)]
+        self.xs = [p[0].to(dev) for p in self.prompts]
+        self.xls = [p[1].to(dev) for p in self.prompts]
+        self.ys = [p[2].to(dev) for p in self.prompts]
+        self.knobs = dict(top_k=top_k, top_p=1.0, temperature=1.0, stop_repetition=3)
+
+    def call(self, seed):
+        eng, K = self.eng, self.K
+        if self.edit:
+            mi = torch.tensor([[list(self.span)]], dtype=torch.int64)
+            res = eng.inference(self.xs[0], self.xls[0], self.ys[0], mi, silence_tokens=[1388, 1898, 131], _seed=seed, **self.knobs)
+            return [None], (int(res.shape[2]) - (self.prompt_frames - (self.span[1] - self.span[0]))) * K
+        if self.B == 1:
+            res, gen = eng.inference_tts(self.xs[0], self.xls[0], self.ys[0], kvcache=1, silence_tokens=[1388, 1898, 131], _seed=seed, **self.knobs)
+            gens = [gen]
+        else:
+            outs = eng.inference_tts_multi([x[0] for x in self.xs], [y[0] for y in self.ys], silence_tokens=[1388, 1898, 131], _seed=seed, **self.knobs)
+            gens = [o[1] for o in outs]
+        return gens, sum(int(g.shape[2]) * K for g in gens)
+
+    def label(self, use_graph=True):
+        if self.edit:
+            return (f"{self.preset} speech editing, Lx={self.lx}, {self.prompt_frames}-frame utterance, span "
+                    f"{self.span} re-generated (~{self.Tg} frames, reference length cap), top_k={self.top_k}")
+        return (f"{self.preset} TTS, batch {self.B}/GPU, Lx={self.lx}, {self.prompt_frames} prompt frames -> "
+                f"{self.Tg} generated frames ({(self.prompt_frames + self.Tg) // 50} s total), top_k={self.top_k}, hipGraph={'on' if use_graph else 'off'}")
+
+    def s_mean(self):
+        return self.lx + self.prompt_frames + 1 + self.Tg / 2
+
+
+def configs_block(args, dev, sd830):
+    """The OTHER BASELINE configurations, each on its own engine after the headline's timed region: 1 warm-up + 2 timed whole calls
+    (host wall around each call, device idle on both sides), so that the driver's single bench line shows every configuration it names
+    (missing #3).  C3 is the headline itself; C5 is quoted as its per-GPU share (8 utterances of the 64)."""
+    specs = [
+        ("C2", "BASELINE config 2", dict(preset="giga330M", mode="tts", batch=1, lx=80, prompt_frames=150, top_k=40)),
+        ("C1", "BASELINE config 1's workload on the GPU (the config itself is the CPU reference run: cpu_baseline / BASELINE.md section 2)",
+         dict(preset="giga330M", mode="tts", batch=1, lx=40, prompt_frames=150, top_k=1)),
+        ("C4", "BASELINE config 4", dict(preset="giga830M", mode="edit", batch=1, lx=80, prompt_frames=150, top_k=40)),
+        ("C5_per_gpu_share", "BASELINE config 5: 64 utterances over 8 GPUs = 8 per GPU, this GPU's share",
+         dict(preset="giga830M", mode="tts", batch=8, lx=80, prompt_frames=150, top_k=40)),
+    ]
+    out = {}
+    sd_cache = {"giga830M": sd830} if sd830 is not None else {}
+    for key, what, kw in specs:
+        try:
+            wl = Workload(dtype=args.dtype, dev=dev, use_graph=not args.no_graph, sd=sd_cache.get(kw["preset"]), **kw)
+            sd_cache[kw["preset"]] = wl.sd
+            wl.call(100)
+            torch.cuda.synchronize()
+            tok = 0
+            wall = dec = pre = 0.0
+            steps = 0
+            n_calls = 2
+            for i in range(n_calls):
+                t0 = time.perf_counter()
+                tok += wl.call(1000 + i)[1]
+                torch.cuda.synchronize()
+                wall += time.perf_counter() - t0
+                tm = wl.eng.last_timing_ms()
+                dec += tm["decode_ms"]; pre += tm["prefill_ms"]; steps += wl.eng.last_steps
+            dstep = dec / max(1, steps)
+            sb = step_alg_bytes(wl.a, args.dtype, wl.B, wl.s_mean())
+            out[key] = {"config": what, "workload": wl.label(not args.no_graph), "value": round(tok / wall, 1), "unit": "codec-tokens/s",
+                        "calls": n_calls, "ms_per_call": round(wall / n_calls * 1e3, 2), "prefill_ms": round(pre / n_calls, 2),
+                        "decode_ms_per_step": round(dstep, 4), "rtf": round(wall / (tok / wl.K / 50.0), 4),
+                        "hbm_frac_in_loop": round(sb / (dstep * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if dstep > 0 else None}
+            del wl
+        except Exception as e:      # reporting only: never lose the headline to it
+            out[key] = {"config": what, "error": str(e)}
+    return out
+
+
 def ab_block(eng, one_step, spec, pairs):
     """In-process A/B of ONE engine option (vc_set_option): the same engine, the same process, the same box.  Whole calls
     are timed in interleaved pairs (A B, B A, A B ...: drift cancels), each arm's captured graph already warm; the figure
@@ -368,42 +515,14 @@ def main():
     assert args.gpus == n_gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from voicecraft_amd import dist as vdist
-    from voicecraft_amd import synth
-    from voicecraft_amd.engine import VoiceCraftEngine
-    a = synth.make_args(args.preset)
-    K = a.n_codebooks
-    sd = synth.make_state_dict(a, seed=0, perturb=False, mute_eos=True, fast=True)
-    edit = args.mode == "edit"
-    if edit:       # 16 s utterance (10 frames per phoneme), the middle quarter masked: generation runs to the
-        assert args.batch == 1, "editing is single-utterance (models/voicecraft.py:607)"   # reference's length cap y_len > 10*Lx
-        args.prompt_frames = 10 * args.lx
-        span = (args.prompt_frames * 3 // 8, args.prompt_frames * 4 // 8)        # [300,400) of 800 frames
-    # generated frames: TTS 10 Lx - T (the length cap); editing: the cap minus the rearranged prompt's columns
-    # (two shifted pieces of K extra columns each, two mask placeholders, the end token and the start column)
-    Tg = 10 * args.lx - args.prompt_frames if not edit else 10 * args.lx - (args.prompt_frames - (span[1] - span[0]) + 2 * K + 4) + 1
-    eng = VoiceCraftEngine(a, sd, device=dev, dtype=args.dtype, max_seqs=max(1, args.batch),
-                           max_positions=max(1024, args.lx + args.prompt_frames + Tg + 64), use_graph=not args.no_graph)
-    # utterance u of this rank = global utterance (u * world + rank); seed = 1 + global index
-    B = args.batch
-    prompts = [synth.random_prompt(a, args.lx, args.prompt_frames, seed=1 + (u * world + rank)) for u in range(B)]
-    xs = [p[0].to(dev) for p in prompts]
-    xls = [p[1].to(dev) for p in prompts]
-    ys = [p[2].to(dev) for p in prompts]
-    knobs = dict(top_k=args.top_k, top_p=1.0, temperature=1.0, stop_repetition=3)
+    wl = Workload(args.preset, args.mode, args.batch, args.lx, args.prompt_frames, args.top_k, args.dtype, dev,
+                  use_graph=not args.no_graph, rank=rank, world=world)
+    a, sd, eng, K, B, edit, span, Tg, prompts = wl.a, wl.sd, wl.eng, wl.K, wl.B, wl.edit, wl.span, wl.Tg, wl.prompts
+    args.prompt_frames = wl.prompt_frames          # (editing: the whole 16 s utterance is the prompt)
 
     def one_step(seed):
-        if edit:
-            mi = torch.tensor([[list(span)]], dtype=torch.int64)
-            res = eng.inference(xs[0], xls[0], ys[0], mi, silence_tokens=[1388, 1898, 131], _seed=seed, **knobs)
-            return (int(res.shape[2]) - (args.prompt_frames - (span[1] - span[0]))) * K
-        if B == 1:
-            res, gen = eng.inference_tts(xs[0], xls[0], ys[0], kvcache=1, silence_tokens=[1388, 1898, 131], _seed=seed, **knobs)
-            gens = [gen]
-        else:
-            outs = eng.inference_tts_multi([x[0] for x in xs], [y[0] for y in ys], silence_tokens=[1388, 1898, 131], _seed=seed, **knobs)
-            gens = [o[1] for o in outs]
-        n_tok = sum(int(g.shape[2]) * K for g in gens)
-        if dist is not None or args.dump:   # the single collective of the job: gather every rank's token block
+        gens, n_tok = wl.call(seed)
+        if not edit and (dist is not None or args.dump):   # the single collective of the job: gather every rank's token block
             tg0 = time.perf_counter()
             gathered[:] = vdist.gather_token_blocks([g[0] for g in gens], Tg + 8, n_slots=B, K=K, device=dev)
             gather_s[0] += time.perf_counter() - tg0      # host wall incl. the .to(int32) staging and the unpacking (it synchronises)
@@ -447,12 +566,7 @@ def main():
     if rank == 0:
         frames = tokens / K
         value = tokens / dt
-        d, L = a.d_model, a.num_decoder_layers
-        V, P = a.audio_vocab_size + a.n_special, a.audio_vocab_size // 2
-        esz = 2 if args.dtype == "bf16" else 4
-        w_bytes = esz * (L * (12 * d * d + 13 * d) + 2 * d + K * (d * P + P + P * V + V))
-        s_mean = args.lx + args.prompt_frames + 1 + Tg / 2
-        step_bytes = w_bytes + B * esz * 2 * L * d * (s_mean + 1)        # weights (once per step) + KV read + KV write of each of the B sequences
+        step_bytes = step_alg_bytes(a, args.dtype, B, wl.s_mean())      # weights (once per step) + KV read + KV write of each of the B sequences
         # dominant kernel: the FFN down-projection rows-GEMM (plain prologue, split-K partial slabs) - the largest share of
         # kernel time in every round-3 profile once the up-projection's first half is prefetched under the attention launch
         # (profiles/r03g_*: 22.4 % against 17.9 %); timed in isolation here, so in agreement with its in-situ rocprof average
@@ -463,13 +577,15 @@ def main():
         for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
             ms_, by_ = eng.bench_kernel(kn, n_rows=mb_rows, iters=64)
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
-        fr_form = 2 <= mb_rows <= 16 and "|fr0" not in eng.options()       # several-row steps: the finished-row producer is what runs
+        fr_form = 2 <= mb_rows <= 16 and "|fr=0," not in eng.options()       # several-row steps: the finished-row producer is what runs
         roof = {"bound": "hbm", "kernel": (("rows_gemm_fr_k<plain> (FFN down-projection, finished rows: 8-channel tiles over the whole K)" +
                                             ("" if B <= 16 else f"; microbenchmarked at 16 rows - this run's {B}-row steps use the wide-decode kernel rows_gemm_mt_k")) if fr_form
                                            else "rows_gemm_k<plain,split-K slabs> (FFN down-projection)"),
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn2", args),
-                "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2)}
+                "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2),
+                "measured": "isolated: the kernel back to back over rotating layers, HIP events on the launch stream (vc_bench_kernel)",
+                "in_situ": in_situ("ffn2", args)}
         # the prefill is GEMM-shaped: MFMA rooflines of its widest block GEMM (FFN up-projection) at the run's own pass
         # size and at a full 512-row pass, and of the MFMA tile attention
         own_rows = min(512, B * ((args.lx + (args.prompt_frames + 1 if not edit else args.prompt_frames - (span[1] - span[0]) + 2 * K + 4) + 15) // 16 * 16))
@@ -497,11 +613,7 @@ def main():
             "metric": "codec_tokens_per_sec", "value": round(value, 1), "unit": "codec-tokens/s", "n_gpus": n_gpus,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": (f"{args.preset} TTS, batch {B}/GPU, Lx={args.lx}, {args.prompt_frames} prompt frames -> "
-                                    f"{Tg} generated frames (16 s total), top_k={args.top_k}, hipGraph={'off' if args.no_graph else 'on'}")
-                                   if not edit else
-                                   (f"{args.preset} speech editing, Lx={args.lx}, {args.prompt_frames}-frame utterance, span "
-                                    f"{span} re-generated (~{Tg} frames, reference length cap), top_k={args.top_k}"),
+            "config": {"workload": wl.label(not args.no_graph),
                        "utterances_per_step": B * n_gpus, "parallelism": f"dp{n_gpus} (utterance-sharded, one all_gather)"},
             "rtf": round(dt / (frames / 50.0), 4),
             "decode_ms_per_token_step": round(dec_step_ms, 4), "prefill_ms": round(pre_ms / args.steps, 2),
@@ -513,7 +625,7 @@ def main():
         out["prefill_roofline"] = mfma
         # launch-shape options in force (prefetch roles of latency-bound launches, finished-row form, ...): additional work
         # inside the timed region where they add any, nothing skipped
-        out["config"]["engine_options"] = eng.options()
+        out["config"]["engine_options"] = options_object(eng.options())
         if dist is not None:
             out["collective"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "op": "all_gather of int32 [B,K,T+1] token blocks",
                                  "gather_ms": round(gather_s[0] / args.steps * 1e3, 3), "ranks_share_one_device": share}
@@ -530,6 +642,10 @@ def main():
                 out["ab"] = ab_block(eng, one_step, ab, max(3, args.ab_pairs))
             except Exception as e:   # reporting only
                 out["ab"] = {"error": str(e)}
+        if n_gpus == 1 and B == 1 and not edit and args.preset == "giga830M" and not args.no_configs:
+            # the other BASELINE configurations on their own engines (after the headline's timed region; ~20 s)
+            del eng, wl
+            out["configs"] = configs_block(args, dev, sd)
         if n_gpus == 1 and not args.no_codec:
             try:
                 out["codec"] = codec_block(dev)

@@ -71,6 +71,34 @@ def test_editing_prompt_and_a_ragged_batch_with_a_shared_prefix(model):
     assert rel_l2(got[2][0], got[1][0]).max() <= 1e-2, rel_l2(got[2][0], got[1][0])
 
 
+def test_pass_size_that_is_not_a_multiple_of_64_keeps_the_first_kernel(model):
+    """`prefill_rows` accepts any multiple of 16.  With 1040 rows per pass a 64-row block of the second pass would
+    straddle one prompt's tail padding and the next prompt's first rows; the engine must not pick tile_attn64_k then (census) and
+    the ragged batch's first-step logits must equal the default pass size's."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = model
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=4, max_positions=1024, use_graph=False)
+    prompts = [synth.random_prompt(a, 20 + 5 * u, 790 - 250 * u, seed=90 + u) for u in range(4)]      # 811 + 566 + 321 + 76 rows: one >= 768
+    xs, ys = [p[0][0] for p in prompts], [p[2][0] for p in prompts]
+    run = lambda: eng.inference_tts_multi(xs, ys, top_k=1, stop_repetition=3, _logit_steps=1, _seed=3)[1].cpu().numpy()
+    eng.set_option("tile_attn", "2,768")
+    c0 = eng.launch_counts()
+    base = run()
+    assert eng.launch_counts()["tile_attn64"] - c0["tile_attn64"] == a.num_decoder_layers          # the default pass size: one pass, second kernel
+    eng.set_option("prefill_rows", "1040")
+    c0 = eng.launch_counts()
+    got = run()
+    c = {k: eng.launch_counts()[k] - c0[k] for k in c0}
+    eng.set_option("prefill_rows", "2048")
+    assert c["tile_attn"] == 2 * a.num_decoder_layers and c["tile_attn64"] == 0, c          # two passes, both on tile_attn_k
+    assert rel_l2(got[0], base[0]).max() <= 1e-2, rel_l2(got[0], base[0])
+    for u in (1, 3):
+        tr = []
+        orc.inference_tts(prompts[u][0], prompts[u][1], prompts[u][2], top_k=1, stop_repetition=3, trace=tr, max_steps=1)
+        assert rel_l2(got[0, u][None], tr[0]["logits"][0].numpy()[None]).max() <= 2e-2, u
+
+
 def test_attention_microbenchmark_of_both_kernels(model, capsys):
     from voicecraft_amd import synth
     from voicecraft_amd.engine import VoiceCraftEngine
@@ -83,7 +111,7 @@ def test_attention_microbenchmark_of_both_kernels(model, capsys):
         t = both(eng, lambda: eng.bench_kernel("pf_attn", n_rows=rows, iters=32))
         lines.append(f"pf_attn {rows} rows: tile_attn_k {t[1][0] * 1e3:.1f} us, tile_attn64_k {t[2][0] * 1e3:.1f} us ({t[1][1] / (t[2][0] * 1e-3) / 1e12:.0f} TFLOP/s)")
     with capsys.disabled():
-        print("\\n" + "\\n".join(lines))
+        print("\n" + "\n".join(lines))
     import os
     os.makedirs("gpurun_out", exist_ok=True)
-    open("gpurun_out/r04o_attn64_probe.log", "w").write("\\n".join(lines) + "\\n")
+    open("gpurun_out/attn64_probe.log", "w").write("\n".join(lines) + "\n")

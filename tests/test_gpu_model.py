@@ -412,8 +412,13 @@ def test_full_size_giga830M_long_context_bench_shape():
     torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
     want = VoiceCraftOracle(a, sd).tts_logits_for_trajectory(x, y, toks, steps=steps).numpy()
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=1, max_positions=1024, use_graph=True)
+    c0 = eng.launch_counts()
     res, gen, lg = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=40, stop_repetition=3, _forced=toks, _logit_steps=n)
+    c = {k: eng.launch_counts()[k] - c0[k] for k in c0}
     assert gen.shape[2] == 650 and eng.last_steps >= 654
+    # round 5: at this width the one-row step's FFN down-projection finishes its row (row_gemm_fr1_k, once per layer and captured
+    # step) unless the form is preset off (VC_FR_ONE=0)
+    assert c["row_gemm_fr1"] >= a.num_decoder_layers or "|r1=0," in eng.options(), c
     got = lg.cpu().numpy()[steps]
     rel = rel_l2(got, want)
     assert rel.max() <= 2e-2, dict(zip(steps, rel.tolist()))

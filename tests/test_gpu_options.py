@@ -49,7 +49,7 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
     for mode in ("on", "on1", "off"):              # on: two weight tiles per consumer workgroup (the default); on1: one
         eng.set_option("finished_rows", 0 if mode == "off" else 16)
         eng.set_option("lnw_tiles", 1 if mode == "on1" else 2)
-        assert ("fr0" if mode == "off" else "fr16") in eng.options()
+        assert ("|fr=0," if mode == "off" else "|fr=16,") in eng.options()
         c0 = eng.launch_counts()
         outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3,
                                            _forced=forced, _logit_steps=n)

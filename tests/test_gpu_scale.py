@@ -94,7 +94,7 @@ def test_c5_share_eight_utterances_one_prefill_stream(giga):
     L = a.num_decoder_layers
     assert c["big256"] == 3 * L and c["blk128_sbs"] == L and c["tile_attn"] == L, c   # one 1 920-row pass; the out-projection stays on 128 x 128
     assert c["rows_gemm"] > 0 and c["mt2"] + c["mt4"] == 0, c                 # 8-row decode: the rows-GEMM, not the wide form
-    if "|fr0" not in eng.options():                                           # (a VC_FINISHED_ROWS=0 preset runs the slab form: still correct, other census)
+    if "|fr=0," not in eng.options():                                           # (a VC_FINISHED_ROWS=0 preset runs the slab form: still correct, other census)
         assert c["rows_gemm_fr"] > 0 and c["ln_rows"] == 2 * L, c             # ... in the finished-row form: the only LayerNorm launches are the prefill pass's
     lg = lg.cpu().numpy()
     worst = {}
@@ -210,7 +210,7 @@ def test_giga330M_eight_utterances_and_a_576_row_editing_prefill(giga330):
     outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
                                        _forced=forced, _logit_steps=n)
     c = delta(eng.launch_counts(), c0)
-    assert ("|fr0" in eng.options() or c["rows_gemm_fr"] >= 2 * L * (n - 1)) and c["tile_attn"] == L, c    # eager: every decode launch is counted
+    assert ("|fr=0," in eng.options() or c["rows_gemm_fr"] >= 2 * L * (n - 1)) and c["tile_attn"] == L, c    # eager: every decode launch is counted
     lg = lg.cpu().numpy()
     worst = {}
     for u in (0, 3, 7):
@@ -252,7 +252,7 @@ def test_twelve_row_decode_in_the_two_half_finished_row_form(giga):
     outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
                                        _forced=forced, _logit_steps=n)
     c = delta(eng.launch_counts(), c0)
-    if "|fr0" not in eng.options():
+    if "|fr=0," not in eng.options():
         assert c["rows_gemm_fr"] >= 2 * a.num_decoder_layers * (n - 1) and c["mt2"] + c["mt4"] == 0, c
     lg = lg.cpu().numpy()
     steps = [0, 4, n - 1]

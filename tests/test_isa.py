@@ -59,6 +59,7 @@ def test_kernels_use_no_scratch(kern):
 
 
 def test_kernels_are_built_around_the_intended_instructions(kern):
+    import re
     for name, (body, _, vgpr) in pick(kern, "rows_gemm_big_k<").items():
         assert body.count("global_load_lds_dwordx4") >= 4 and body.count("v_mfma_f32_16x16x32_bf16") >= 32, name
         assert "s_waitcnt vmcnt(8)" in body and vgpr <= 256, name        # counted wait of the 4-stage ring; two waves per SIMD
@@ -74,7 +75,7 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
         assert ";;#ASMSTART" in body and "global_load_dwordx4" in body.split(";;#ASMSTART")[1].split(";;#ASMEND")[0], name
     for name, (body, _, _) in pick(kern, "ln_rows_k<").items():
         assert ";;#ASMSTART" in body, name                                # the prefetch role of several-row decode steps
-    decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false>")         # FFN-up of a one-row step
+    decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false, 2>")      # FFN-up of a one-row step (h + the out-projection's two slabs)
     for name, (body, _, _) in decode.items():
         assert body.count("v_mfma_f32_16x16x32_bf16") >= 2 and " nt" in body, name     # non-temporal weight stream
     # finished-row form (2..16-row decode steps): the FFN down-projection streams a wave's whole share (32 fragments) in ONE burst
@@ -84,7 +85,18 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
         assert vgpr <= 256, (name, vgpr)
     for name, (body, _, vgpr) in pick(kern, "rows_gemm_fr2_k<bf16_t, 16>").items():      # 9..16 rows: both halves' fragments up front
         assert body.count(" nt") >= 32 and body.count("v_mfma_f32_16x16x32_bf16") == 32 and vgpr <= 256, (name, vgpr)
-    for prefix in ("rows_gemm_k<bf16_t, 16, 3, 0, 2, true, false>", "rows_gemm_k<bf16_t, 16, 3, 2, 2, true, false>"):
+    # one-row finished-row producer (round 5): the FFN down-projection at d = 2048 - 16 fragment PAIRS per wave (every lane's 16 bytes
+    # used: two k-tiles per MFMA), all non-temporal, one MFMA per KB
+    for name, (body, _, vgpr) in pick(kern, "row_gemm_fr1_k<bf16_t, 16, true>").items():
+        assert len(re.findall(r"global_load_dwordx4[^\n]* nt", body)) == 16 and body.count("v_mfma_f32_16x16x32_bf16") == 16, name
+        assert vgpr <= 128, (name, vgpr)
+    # the trimmed LayerNorm prologues: every slab the prologue does not request is two 16-byte loads per thread and row less
+    n_plain = {}
+    for np_ in ("0", "2", "4"):
+        for name, (body, _, _) in pick(kern, f"rows_gemm_k<bf16_t, 16, 0, 0, 1, true, false, {np_}>").items():
+            n_plain[np_] = len(re.findall(r"global_load_dwordx4 ", body)) - len(re.findall(r"global_load_dwordx4[^\n]* nt", body))
+    assert n_plain["0"] + 4 <= n_plain["2"] and n_plain["2"] + 4 <= n_plain["4"], n_plain
+    for prefix in ("rows_gemm_k<bf16_t, 16, 3, 0, 2, true, false, 4>", "rows_gemm_k<bf16_t, 16, 3, 2, 2, true, false, 4>"):
         for name, (body, _, vgpr) in pick(kern, prefix).items():
             assert vgpr <= 128 and " nt" in body, (name, vgpr)             # 8 waves per workgroup, two workgroups per CU
 
@@ -97,7 +109,7 @@ def test_the_non_temporal_hint_survives_in_every_decode_gemm(kern):
     import re
     seen = 0
     for name, (body, _, _) in pick(kern, "rows_gemm_k<").items():
-        m = re.search(r"rows_gemm_k<(\w+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false)>", name)
+        m = re.search(r"rows_gemm_k<(\w+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)>", name)
         assert m, name
         ktw, nt = int(m.group(2)), m.group(6) == "true"
         n = len(re.findall(r"global_load_dwordx4[^\n]* nt", body))

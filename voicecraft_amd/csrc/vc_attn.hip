@@ -44,10 +44,21 @@ __device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
 // NT: K/V rows are requested with the non-temporal hint (every cached row is read exactly once per step and never again before
 // the next step's 1.7 GB of weights have gone through the caches) - a template parameter so that the hint cannot be merged away
 // (vc_gemm.hip rows_gemm_k), chosen per launch from AttnArgs.nt (option "attn_nt").
-template <typename WT, bool NT>
+// FAST (round 5; option "attn_fast", default on): the in-kernel stamps of round 4 put half of the one-row launch's in-kernel time
+// (3 916 of 8 016 clk) into "wave merge + block sync + final + store" - online-softmax bookkeeping, not K/V.  Here a wave takes the
+// MAXIMUM of a batch's scores over all of its lanes before any exponential, so every lane of the wave carries the same running
+// maximum: no rescaling per visit (one per batch of 4), and the position groups of a wave merge by plain additions (no
+// exponentials, no multiplies).  In bf16 mode the exponentials are hardware exp2 (v_exp_f32, q pre-scaled by log2 e; the exported
+// maximum is converted back to natural units for the out-projection's merge); the exact fp32 mode keeps expf.
+template <typename WT, bool NT, bool FAST>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;
   constexpr int NW = VC_ATT_WAVES;
+  constexpr bool X2 = sizeof(WT) == 2;        // FAST: base-2 exponentials in bf16 mode
+  auto ex = [](float x) -> float {
+    if constexpr (FAST && X2) return __builtin_amdgcn_exp2f(x);
+    else return expf(x);
+  };
   __shared__ float s_m[NW], s_l[NW];
   __shared__ float s_o[NW][128];
   VC_KTS_DECL();
@@ -112,13 +123,44 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     __builtin_amdgcn_sched_barrier(0);
     VC_KTS(2);
     float q[EPL];
+    const float qs = (FAST && X2) ? a.scale * 1.4426950408889634f : a.scale;
 #pragma unroll
     for (int j = 0; j < EPL / 4; ++j) {
-      q[4 * j] = qv[j].x * a.scale; q[4 * j + 1] = qv[j].y * a.scale;
-      q[4 * j + 2] = qv[j].z * a.scale; q[4 * j + 3] = qv[j].w * a.scale;
+      q[4 * j] = qv[j].x * qs; q[4 * j + 1] = qv[j].y * qs;
+      q[4 * j + 2] = qv[j].z * qs; q[4 * j + 3] = qv[j].w * qs;
     }
     VC_KTS(3);
     for (int pb = p0;;) {
+      if constexpr (FAST) {
+        float sc[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          float kf[EPL];
+          unpack16<WT>(ku[it], kf);
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) t += q[j] * kf[j];
+          if (LPR == 4) t = quad_sum(t);
+          else if (LPR == 8) t = half_row_sum(t);
+          else { t = row_sum(t); if (LPR == 32) t += __shfl_xor(t, 16, 64); }
+          sc[it] = (pp[it] < p1) ? t : -INFINITY;
+        }
+        const float mn = fmaxf(m, wave_max(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]))));    // wave-uniform
+        if (mn > -INFINITY) {
+          const float corr = ex(m - mn);             // m = -inf before the first valid position -> 0
+          float pw[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) pw[it] = ex(sc[it] - mn);    // -inf (beyond the chunk) -> 0
+          l = l * corr + ((pw[0] + pw[1]) + (pw[2] + pw[3]));
+          float vf[4][EPL];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) unpack16<WT>(vu[it], vf[it]);
+#pragma unroll
+          for (int j = 0; j < EPL; ++j)
+            o[j] = o[j] * corr + ((pw[0] * vf[0][j] + pw[1] * vf[1][j]) + (pw[2] * vf[2][j] + pw[3] * vf[3][j]));
+          m = mn;
+        }
+      } else {
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
         float kf[EPL], vf[EPL];
@@ -140,6 +182,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
           m = mn;
         }
       }
+      }
       pb += step;
       if (pb >= p1) break;
       VC_KV_LOADS(pb);
@@ -148,6 +191,13 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     VC_KTS(4);
   }
   // merge the PPW position groups of this wave (same li, different sub)
+  if constexpr (FAST) {       // one running maximum per wave: the groups merge by plain sums
+    for (int off = LPR; off < 64; off <<= 1) {
+      l += __shfl_xor(l, off, 64);
+#pragma unroll
+      for (int j = 0; j < EPL; ++j) o[j] += __shfl_xor(o[j], off, 64);
+    }
+  } else
   for (int off = LPR; off < 64; off <<= 1) {
     const float m2 = __shfl_xor(m, off, 64);
     const float l2 = __shfl_xor(l, off, 64);
@@ -177,10 +227,11 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     float L = 0.f, O = 0.f;
 #pragma unroll
     for (int w = 0; w < NW; ++w) {
-      const float c = (s_m[w] == -INFINITY) ? 0.f : expf(s_m[w] - M);
+      const float c = (s_m[w] == -INFINITY) ? 0.f : ex(s_m[w] - M);
       L += c * s_l[w];
       O += c * s_o[w][tid];
     }
+    if constexpr (FAST && X2) M *= 0.6931471805599453f;      // back to natural units: the out-projection merges with expf
     if (a.x_out) {      // unsplit pass (prefill): the block saw every position, so it normalises itself
       WTr<WT>::st(reinterpret_cast<WT*>(a.x_out) + (long)r * a.d + h * hd + tid, (L > 0.f) ? O / L : 0.f);
     } else {
@@ -196,13 +247,15 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s) {
   dim3 grid(rows_cap, a.H, a.nsplit + a.pf_z);
   ++vc_launch_counts[VC_LC_ROWS_ATTN];
+#define VC_ATTN_GO(WT_, NT_, F_) hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a)
   if (dtype == VC_DTYPE_BF16) {
-    if (a.nt) hipLaunchKernelGGL((rows_attn_k<bf16_t, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
-    else hipLaunchKernelGGL((rows_attn_k<bf16_t, false>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
+    if (a.fast) { if (a.nt) VC_ATTN_GO(bf16_t, true, true); else VC_ATTN_GO(bf16_t, false, true); }
+    else { if (a.nt) VC_ATTN_GO(bf16_t, true, false); else VC_ATTN_GO(bf16_t, false, false); }
   } else {
-    if (a.nt) hipLaunchKernelGGL((rows_attn_k<float, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
-    else hipLaunchKernelGGL((rows_attn_k<float, false>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a);
+    if (a.fast) { if (a.nt) VC_ATTN_GO(float, true, true); else VC_ATTN_GO(float, false, true); }
+    else { if (a.nt) VC_ATTN_GO(float, true, false); else VC_ATTN_GO(float, false, false); }
   }
+#undef VC_ATTN_GO
   return hipGetLastError();
 }
 
@@ -706,6 +759,7 @@ __global__ __launch_bounds__(256) void tile_attn64_k(const AttnArgs a) {
 hipError_t vc_launch_tile_attn64(const AttnArgs& a, hipStream_t s) {
   if (!a.x_out || a.hd != 128) return hipErrorInvalidValue;
   ++vc_launch_counts[VC_LC_TILE_ATTN];
+  ++vc_launch_counts[VC_LC_TILE_ATTN64];        // (also counted as a tile attention launch: the tests written before this slot read that one)
   hipLaunchKernelGGL(tile_attn64_k, dim3(a.H, (a.n_rows + 63) / 64), dim3(256), 4 * VC_TA2_KEYS * 128 * 2, s, a);
   return hipGetLastError();
 }

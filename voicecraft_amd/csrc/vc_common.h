@@ -263,6 +263,7 @@ struct GemmArgs {
   int n_parts;
   const float* prev_bias;   // always a readable [d] vector; added only when has_prev_bias
   int has_prev_bias;
+  int ln_trim;              // 1: the LayerNorm prologue requests only as many slabs as n_parts needs (0 / 2 / 4; rows_gemm_k NP)
   const float* wg;          // LN prologue: [group][N] row sums of the folded weights (W . gamma), see vc_gemm.hip
   const int* gather_rows;   // optional indirection on h_in/parts rows (logit rows for the heads)
   int d;                    // row width of h / parts
@@ -314,6 +315,7 @@ struct AttnArgs {
   PfSeg pf[2];
   int pf_z;
   int nt;                   // rows_attn_k: K/V rows requested with the non-temporal hint
+  int fast;                 // rows_attn_k: 1 = the round-5 form (wave maximum before any exponential; bf16 mode: hardware exp2)
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence
@@ -408,16 +410,19 @@ hipError_t vc_launch_fold_vecs(const float* W, const float* gamma, const float* 
                                float* cb, int N, int K, int dtype, hipStream_t s);
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s);
+hipError_t vc_launch_gemm_blk(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, hipStream_t s);   // prefill passes (vc_gemm_pf.hip)
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
 hipError_t vc_launch_gemm_fr(const GemmArgs& a, int dtype, int pro, hipStream_t s);   // finished-row producers (vc_gemm.hip)
 size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype);
 int vc_gemm_fr_form(int rows, int N, int K, int dtype, int pro, int nsplit);   // 0 none, 1 one piece, 2 K in two halves
+hipError_t vc_launch_gemm_fr1(const GemmArgs& a, int dtype, hipStream_t s);           // one-row finished-row producer (vc_gemm.hip row_gemm_fr1_k)
+int vc_gemm_fr1_ok(int N, int K, int dtype);
 extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production
 // Launch census (process-wide, host side): which kernel FORM each launcher picked.  Read through
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one
 // they compared with the oracle.
 enum { VC_LC_ROWS_GEMM = 0, VC_LC_MT2 = 1, VC_LC_MT4 = 2, VC_LC_BLK64 = 3, VC_LC_BLK128_SBS = 4, VC_LC_BLK128_2X2 = 5,
-       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_N = 16 };
+       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_N = 16 };
 extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);

@@ -134,6 +134,16 @@ struct vc_engine {
   // 512 / 800 / 2048 causal rows: 14.3 / 24.6 / 86.7 us (first kernel) against 15.5 / 21.0 / 52.5 us (second).
   int tile_attn = 2, tile_attn_min_rows = 768;
   int fr_split_rows = VC_FR_MAX_ROWS;   // option "fr_split_rows": passes of more rows run the attention unsplit (it normalises itself, plain out-projection prologue)
+  // option "fr_one" (round 5): ONE-row steps - bit 0: the FFN down-projection finishes its row (row_gemm_fr1_k: 8-channel tiles over the
+  // whole K, two k-tiles per MFMA fragment, residual + bias added) instead of leaving 4 split-K slabs, so the next layer's QKV
+  // projection (and heads-1) reads one 8 KB row instead of h + bias + 4 slabs = 40 KB in each of its 512 workgroups
+  int fr_one = 1;
+  // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
+  // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
+  int ln_trim = 1;
+  // option "attn_fast": decode attention with the wave's maximum taken before any exponential (no online rescaling inside a wave) and,
+  // in bf16 mode, hardware exp2 (v_exp_f32) instead of expf
+  int attn_fast = 1;
   int attn_blocks_multi = 512, attn_blocks_one = 256;   // VC_ATTN_BLOCKS / VC_ATTN_BLOCKS1: attention workgroups aimed at (several rows / one row)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
@@ -292,7 +302,16 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
+  g.ln_trim = e->ln_trim;
   return g;
+}
+
+// ONE-row steps whose FFN down-projection finishes the row (option "fr_one" bit 0): the launcher's own statement of what it takes
+// fr_one = 1 (default): only where the producer's d/8 workgroups fill the chip (d >= 2048: in-process A/Bs of round 5, profiles/r05a_*:
+// giga830M -2.13 % +- 0.01 per step; giga330M, 128 workgroups on 256 CUs, +1.5 % +- 0.09); 2: wherever the kernel can run
+inline bool fd_one(const vc_engine* e, int rows) {
+  if (rows != 1 || e->fr_one == 0 || (e->fr_one == 1 && e->d / VC_TH_RES < 256)) return false;
+  return !e->layers.empty() && e->layers[0].W28 != nullptr && vc_gemm_fr1_ok(e->d, 4 * e->d, e->dtype) != 0;
 }
 
 inline int attn_nt_for(const vc_engine* e, int rows) { return e->attn_nt == 1 || (e->attn_nt == 2 && rows >= 2); }
@@ -354,6 +373,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
+      a.fast = e->attn_fast;
       if (rs.nsplit == 1) a.x_out = e->xn;        // unsplit (9..16 rows): the workgroup saw every position and normalises itself
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -402,17 +422,23 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   // in every one of the 384-512 workgroups): from ln_split_rows rows on, a per-row LayerNorm launch
   // plus the plain prologue is cheaper (measured: 8 rows 20 us -> ~12 us per GEMM).
   const bool split_ln = rs.n_rows >= e->ln_split_rows;
+  // one row, option fr_one: the FFN down-projection writes the FINISHED residual row into hB (row_gemm_fr1_k), so the row entering a
+  // layer is whole: the QKV prologue reads it alone and writes nothing, the FFN-up prologue adds the out-projection's two slabs to
+  // it and leaves h' in hA for the down-projection's epilogue
+  const bool fd = fd_one(e, rs.n_rows);
+  e->finished_rows_h = fd;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
+    const float* h_res = (l == 0) ? rs.h_in : e->hB;
     {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv;
-      g.h_in = (l == 0) ? rs.h_in : e->hB;
-      g.h_out = e->hA;
+      g.h_in = h_res;
+      g.h_out = fd ? nullptr : e->hA;
       g.parts = e->parts;
-      g.n_parts = (l == 0) ? 0 : e->p_f2.ksplit;
+      g.n_parts = (l == 0 || fd) ? 0 : e->p_f2.ksplit;
       g.prev_bias = (l == 0) ? ly.bo : e->layers[l - 1].b2;    // (any readable [d] vector when unused)
-      g.has_prev_bias = (l == 0) ? 0 : 1;
+      g.has_prev_bias = (l == 0 || fd) ? 0 : 1;
       g.wg = ly.wg_qkv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
@@ -441,6 +467,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
+      a.fast = e->attn_fast;
       if (e->apf_z > 0 && e->apf_scale > 0 && rs.n_rows == 1 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0) {
         // one row: the launch leaves HBM mostly idle - extra workgroups pull the next two matrices' tiles into the L2 of
         // the XCD that will read them (prefetch_role)
@@ -464,7 +491,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1;
-      g.h_in = e->hA; g.h_out = e->hB;
+      g.h_in = fd ? h_res : e->hA; g.h_out = fd ? e->hA : e->hB;
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.wg = ly.wg_1;
       g.out = e->act; g.out_ld = 4 * d;
@@ -483,7 +510,13 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
       }
     }
-    {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
+    if (fd) {  // h'' = h' + b2 + W2 a: the finished row (one row, row_gemm_fr1_k)
+      GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
+      g.Wp = ly.W28; g.bias = ly.b2;
+      g.x_in = e->act; g.x_ld = 4 * d;
+      g.h_in = e->hA; g.h_out = e->hB;
+      HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, s));
+    } else {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W2; nt_bit(e, g, NT_F2);
       g.x_in = e->act; g.x_ld = 4 * d;
@@ -568,6 +601,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
       a.nt = rs.n_active != nullptr ? attn_nt_for(e, rs.n_rows) : 0;      // wide decode passes stream their K/V once, prefill passes re-read it
+      a.fast = e->attn_fast;
       if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
       if (rs.tiled == 2 && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn64(a, s));
       else if (rs.tiled && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
@@ -622,7 +656,10 @@ int prefill_batch(vc_engine* e, std::vector<PromptArgs>& pas, const std::vector<
     // either way, profiles/r04p_default_attn64.log), so they stay on the first kernel and 16-row boundaries
     long longest = 0;
     for (const PromptArgs& pa : pas) longest = std::max<long>(longest, pa.Lx + pa.n_cols - pa.skip);
-    const bool attn64 = e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128 && longest >= e->tile_attn_min_rows && !getenv("VC_NO_TILE_ATTN");
+    // (... and only when the passes are cut on 64-row boundaries: with a `prefill_rows` option that is not a multiple of 64 a block of
+    // a later pass would straddle one prompt's tail padding and the next prompt's first rows - ADVICE r04)
+    const bool attn64 = e->tile_attn == 2 && e->dtype == VC_DTYPE_BF16 && e->hd == 128 && longest >= e->tile_attn_min_rows && chunk % 64 == 0 &&
+                        !getenv("VC_NO_TILE_ATTN");
     const int al = attn64 ? 64 : 16;
     auto rows_of = [al](const PromptArgs& pa) { return ((pa.Lx + pa.n_cols - pa.skip) + al - 1) & ~(al - 1); };
     while (i1 < pas.size() && (i1 == i0 || R + rows_of(pas[i1]) <= e->emb_cap)) {
@@ -739,10 +776,10 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
 void refresh_opt_state(vc_engine* e);
 
 int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, const vc_sample_cfg* sc,
-                int max_steps, int* steps_run, hipStream_t s, int pos0 = 0) {
+                int max_steps, int* steps_run, hipStream_t s, int pos0 = 0, bool precapture_only = false) {
   const int G = std::max(1, e->steps_per_graph);
   const double t0 = now_ms();
-  e->host_ms[1] = e->host_ms[2] = 0;
+  if (precapture_only) e->host_ms[1] = e->host_ms[2] = 0;
   // One captured graph per (shape, option state).  The only thing that varies INSIDE a call is the prefetch length of the one-row
   // attention launch: it is worth most while the context is short (the launch's own K/V traffic grows with the position and the
   // window it leaves shrinks), so the host - which knows how many steps it has launched - picks full / half / none per graph of G
@@ -780,11 +817,24 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
     refresh_opt_state(e);
     return rc;
   };
-  const bool one_row = B * rps == 1 && e->apf_z > 0;
+  // (the role's own preconditions - forward_rows - are part of the rule: where it cannot apply every scale is the same step, one graph)
+  const bool one_row = B * rps == 1 && e->apf_z > 0 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0;
   auto scale_at = [&](int pos) {
     if (!one_row || e->apf_cut2 <= 0) return 4;
     return (pos >= e->apf_cut2 || pos < e->apf_cut0) ? 0 : pos >= e->apf_cut1 ? 2 : 4;
   };
+  if (precapture_only) {       // every graph this call can need, captured before the caller starts its decode timer
+    if (!sc->use_graph) return VC_OK;
+    int last = -1, rc0 = VC_OK;
+    for (int k = 0; k < max_steps && rc0 == VC_OK; k += G) {
+      const int sc_k = scale_at(pos0 + k);
+      if (sc_k == last) continue;
+      last = sc_k;
+      hipGraphExec_t exec = nullptr;
+      rc0 = exec_for(sc_k, &exec);
+    }
+    return rc0;
+  }
   const double t1 = now_ms();
   volatile int* live = e->h_flag + 8;
   int launched = 0, rc = VC_OK, batch = 0;
@@ -885,7 +935,13 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     if (n >= 2) e->tile_attn_min_rows = std::max(64, v1);
   } else if (name == "fr_split_rows") { e->fr_split_rows = std::max(1, std::min(v0, VC_FR_MAX_ROWS));
   } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
-  } else if (name == "finished_rows") { e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
+  } else if (name == "finished_rows" || name == "fr_one") {
+    if (v0 > 0 && !e->layers.empty() && !e->layers[0].W28)
+      return fail(e, VC_ESTATE, "option '%s': this engine was created with VC_FINISHED_ROWS=0 and VC_FR_ONE=0 and holds no 8-channel weight images", name.c_str());
+    if (name == "fr_one") e->fr_one = std::max(0, std::min(v0, 2));
+    else e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
+  } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
+  } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
@@ -897,9 +953,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf%d,%d,%d,s%d,c%d,%d,%d|lpf%d,%d,%d|g%d|ls%d|ab%d,%d|nt%d,%d|fr%d,%d,%d|ta%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|lpf=%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d|ta=%d,%d|r1=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->tile_attn, e->tile_attn_min_rows);
+           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->tile_attn, e->tile_attn_min_rows,
+           e->fr_one, e->ln_trim, e->attn_fast);
   e->opt_state = buf;
 }
 
@@ -1051,6 +1108,9 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     HIPCHK(e, hipMemcpy(e->pe, pe.data(), pe.size() * 4, hipMemcpyHostToDevice));
   }
   // ---- decoder layers
+  const char* env_fr = getenv("VC_FINISHED_ROWS");
+  const char* env_f1 = getenv("VC_FR_ONE");
+  const bool want_fr8 = !(env_fr && atoi(env_fr) == 0 && env_f1 && atoi(env_f1) == 0);
   e->layers.resize(L);
   for (int l = 0; l < L; ++l) {
     const std::string pre = "decoder.layers." + std::to_string(l) + ".";
@@ -1062,8 +1122,13 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if ((rc = pack_folded(e, pre + "linear1.weight", pre + "linear1.bias", pre + "norm2.", 4 * d, d,
                           &ly.W1, &ly.wg_1, &ly.b1))) return rc;
     if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W2))) return rc;
-    if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo8, VC_TH_RES))) return rc;
-    if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W28, VC_TH_RES))) return rc;
+    // the second, 8-channel-tile image of the two row-producing matrices (finished-row forms): + 10 d^2 elements per layer = + 0.67 GB
+    // at giga830M in bf16.  An engine created with BOTH forms preset off (VC_FINISHED_ROWS=0 and VC_FR_ONE=0) does not pack them,
+    // and refuses to switch the forms on later (apply_option).
+    if (want_fr8) {
+      if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo8, VC_TH_RES))) return rc;
+      if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W28, VC_TH_RES))) return rc;
+    }
     if ((rc = keep_vec(e, pre + "linear2.bias", d, &ly.b2))) return rc;
     const size_t cache_bytes = (size_t)e->B_max * e->H * e->S_max * e->hd * e->esz;
     char* kc; char* vc;
@@ -1177,9 +1242,13 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
-                         std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn")})
-    if (const char* v = getenv(kv.first))
+                         std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+    if (const char* v = getenv(kv.first)) {
+      // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
+      if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
       if ((rc = apply_option(e, kv.second, v))) return rc;
+    }
   refresh_opt_state(e);
   HIPCHK(e, hipDeviceSynchronize());
   e->finalized = true;
@@ -1267,11 +1336,13 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   if (rc) return rc;
   // ---- first sample comes from the prefill logits, then the decode loop
   SampleArgs sa = make_sample_args(e, B, 1);
-  HIPCHK(e, vc_launch_sample(sa, grouped, s));
-  HIPCHK(e, hipEventRecord(e->ev[1], s));
   int steps_run = 0;
   int pos0 = 0;
   for (const TtsJob& j : jobs) pos0 = std::max(pos0, j.Lx + j.T + 1);
+  // (a first call of this shape / option state captures its decode graphs here, outside the decode timer)
+  if ((rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, nullptr, s, pos0, true))) return rc;
+  HIPCHK(e, vc_launch_sample(sa, grouped, s));
+  HIPCHK(e, hipEventRecord(e->ev[1], s));
   rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s, pos0);
   if (rc) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
@@ -1438,6 +1509,7 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   if (rc) return rc;
   const int rps = (M > 1) ? 3 : 1;
   SampleArgs sa = make_sample_args(e, 1, rps);
+  if ((rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, nullptr, s, Lx + col, true))) return rc;
   HIPCHK(e, vc_launch_sample(sa, false, s));
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   int steps_run = 0;
@@ -1790,6 +1862,10 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       g.prev_bias = ly.bo; g.has_prev_bias = 1; g.wg = ly.wg_1; g.out = e->act; g.out_ld = 4 * d;
       if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s)); }
       else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
+    } else if (w == "ffn2" && fd_one(e, n_rows)) {     // one row, finished by the producer (forward_rows, option fr_one)
+      GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
+      g.Wp = ly.W28; g.bias = ly.b2; g.x_in = e->act; g.x_ld = 4 * d; g.h_in = e->hA; g.h_out = e->hB;
+      HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, s));
     } else if (w == "ffn2") {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W2; nt_bit(e, g, NT_F2); g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts;
@@ -1798,6 +1874,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.h_in = e->hB; g.h_out = e->hA; g.parts = e->parts; g.n_parts = e->p_f2.ksplit;
       g.prev_bias = ly.b2; g.has_prev_bias = 1; g.wg = ly.wg_qkv; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      if (fd_one(e, n_rows)) { g.h_out = nullptr; g.n_parts = 0; g.has_prev_bias = 0; }       // the row in hB is finished
       if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s)); }
       else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
     } else if (w == "oproj") {
@@ -1811,6 +1888,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = attn_nt_for(e, rs.n_rows);
+      a.fast = e->attn_fast;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "pf_ffn1") {      // the prefill pass's FFN up-projection on the MFMA block GEMM (X = xn, n_rows rows)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);

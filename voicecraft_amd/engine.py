@@ -441,9 +441,11 @@ class VoiceCraftEngine:
         check(self.lib.vc_set_option(self._h, str(name).encode(), str(value).encode()), self._h, f"vc_set_option({name})")
 
     def options(self) -> str:
-        """The engine's option state as text: apf = attention-launch prefetch (slices, out-proj KB, FFN-up KB), lpf = LayerNorm-
-        launch prefetch (workgroups, QKV KB, FFN-up KB), g = steps per graph, ls = ln_split_rows, ab = attention workgroups aimed
-        at (several rows, one row), nt, fr = finished-row form up to this many rows."""
+        """The engine's option state as text, `key=v,v,...|key=...`: apf = attention-launch prefetch (slices, out-proj KB, FFN-up KB,
+        quarters in force, cuts p1, p2, p0), lpf = LayerNorm-launch prefetch (workgroups, QKV KB, FFN-up KB), g = steps per graph,
+        ls = ln_split_rows, ab = attention workgroups aimed at (several rows, one row), nt = (weight mask, K/V rows), fr = finished-row
+        form (max rows, consumer tiles, split rows), ta = prefill attention (kernel, min rows), r1 = one-row step (fr_one, ln_trim,
+        attn_fast).  bench.py turns it into a JSON object (`config.engine_options`)."""
         return bytes(self.debug_read("options", (256,), torch.uint8).tolist()).split(b"\0")[0].decode()
 
     def last_timing_ms(self):
@@ -458,7 +460,7 @@ class VoiceCraftEngine:
         return ms.value, nbytes.value
 
     LAUNCH_FORMS = ("rows_gemm", "mt2", "mt4", "blk64", "blk128_sbs", "blk128_2x2", "blk64_occ2", "ln_rows", "rows_attn",
-                    "tile_attn", "rows_gemm_fr", "big256", "big128")
+                    "tile_attn", "rows_gemm_fr", "big256", "big128", "row_gemm_fr1", "tile_attn64")
 
     def launch_counts(self) -> dict:
         """Process-wide census of the kernel FORMS launched so far (vc_common.h VC_LC_*): the parity tests take the
