@@ -101,6 +101,58 @@ def in_situ(kernel, args):
         return None
 
 
+# option name -> (key of the option-state text, positions of its values there)
+OPTION_STATE = {"attn_pf": ("apf", (0, 1, 2)), "attn_pf_cut": ("apf", (4, 5, 6)), "ln_pf": ("lpf", (0, 1, 2)), "graph_steps": ("g", (0,)),
+                "ln_split_rows": ("ls", (0,)), "attn_blocks": ("ab", (0,)), "attn_blocks1": ("ab", (1,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)),
+                "finished_rows": ("fr", (0,)), "lnw_tiles": ("fr", (1,)), "fr_split_rows": ("fr", (2,)), "tile_attn": ("ta", (0, 1)),
+                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "gemm_pf": ("gpf", (0, 1, 2))}
+
+
+def option_value(text, knob):
+    """The value of one option in the engine's option-state text, as vc_set_option takes it; None for an option the text does not carry."""
+    try:
+        key, idx = OPTION_STATE[knob]
+        parts = dict(p.split("=", 1) for p in text.split("|"))
+        vals = parts[key].split(",")
+        return ",".join(vals[i] for i in idx)
+    except Exception:
+        return None
+
+
+def box_block(dev):
+    """What a LONE workgroup sees on this box (vc_box_probe): the sampler at one sequence is one, and its time varied 2x between boxes
+    for the same code (DESIGN 4.3 f).  Reported so that the driver's line carries the box's state next to the sampler's time."""
+    from voicecraft_amd.engine import box_probe
+    try:
+        return box_probe(dev)
+    except Exception as e:      # reporting only
+        return {"error": str(e)}
+
+
+def sampler_block(wl, box):
+    """The sampler launch of the one-sequence step, from its own in-kernel stamps (VC_SAMPLER_TS: chip-wide 100 MHz counter at entry
+    and exit of the workgroup, and the mean of its shader-clock phases over every step of one extra call)."""
+    import numpy as np
+    os.environ["VC_SAMPLER_TS"] = "1"
+    try:
+        wl.call(4242)
+        ts = wl.eng.debug_read("kernel_ts", (64,), dtype=torch.int64).numpy()
+    finally:
+        os.environ.pop("VC_SAMPLER_TS", None)
+    wall = ts[32:34]
+    acc = ts[48:59]
+    names = ["state_parked_row_in_lds", "edits_argmax", "filter_draw", "cond_sync", "advance_thread0", "next_row_embedding", "store_state"]
+    out = {"last_step_in_kernel_us": round(float(wall[1] - wall[0]) / 100.0, 2)}
+    if acc[8] > 0:
+        mhz = (box or {}).get("shader_mhz_l2_walk") or 0
+        out["mean_in_kernel_shader_clk"] = int(acc[7] / acc[8])
+        out["mean_phases_shader_clk"] = {n: int(v / acc[8]) for n, v in zip(names, acc[:7])}
+        if mhz:
+            out["mean_in_kernel_us_at_probe_clock"] = round(float(acc[7] / acc[8]) / mhz, 2)
+        out["steps_averaged"] = int(acc[8])
+    return out
+
+
 def options_object(text):
     """The engine's option state (a compact text, vc_debug_read "options") as a JSON object."""
     names = {"apf": ("attn_pf", ["slices", "wo_kb", "w1_kb", "scale_quarters", "cut1", "cut2", "cut0"]), "lpf": ("ln_pf", ["workgroups", "qkv_kb", "w1_kb"]),
@@ -437,6 +489,7 @@ def ab_block(eng, one_step, spec, pairs):
     spread_pct in a driver-run line."""
     knob, vals = spec.split("=", 1)
     va, vb = vals.split(":", 1)
+    prior = option_value(eng.options(), knob)      # the value in force before the A/B (an env preset, or the default): restored afterwards
 
     def timed(v, seed):
         eng.set_option(knob, v)
@@ -450,7 +503,7 @@ def ab_block(eng, one_step, spec, pairs):
         t = {v: timed(v, 2000 + i) for v in order}
         a_ms.append(t[va]); b_ms.append(t[vb])
         deltas.append((t[vb] - t[va]) / t[va] * 100.0)
-    eng.set_option(knob, vb)
+    eng.set_option(knob, prior if prior is not None else vb)
     med = lambda xs: sorted(xs)[len(xs) // 2]
     m = med(deltas)
     mad = 1.4826 * med([abs(d - m) for d in deltas])          # robust sigma of one pair's delta: a call hit by a host hiccup does not define it
@@ -515,6 +568,7 @@ def main():
     assert args.gpus == n_gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from voicecraft_amd import dist as vdist
+    box = box_block(dev) if (rank == 0 and world == 1) else None
     wl = Workload(args.preset, args.mode, args.batch, args.lx, args.prompt_frames, args.top_k, args.dtype, dev,
                   use_graph=not args.no_graph, rank=rank, world=world)
     a, sd, eng, K, B, edit, span, Tg, prompts = wl.a, wl.sd, wl.eng, wl.K, wl.B, wl.edit, wl.span, wl.Tg, wl.prompts
@@ -629,6 +683,13 @@ def main():
         if dist is not None:
             out["collective"] = {"backend": dist.get_backend(), "world": dist.get_world_size(), "op": "all_gather of int32 [B,K,T+1] token blocks",
                                  "gather_ms": round(gather_s[0] / args.steps * 1e3, 3), "ranks_share_one_device": share}
+        if box is not None:
+            out["box"] = box
+            if B == 1 and not edit:
+                try:
+                    out["sampler"] = sampler_block(wl, box)
+                except Exception as e:   # reporting only
+                    out["sampler"] = {"error": str(e)}
         if n_gpus == 1 and B == 1 and not edit and not args.no_codec:
             try:
                 out["one_sample"] = one_sample_block(eng, a, dev, args)

@@ -101,13 +101,22 @@ const char* vc_version(void);
  *   "nt"           bit mask of the weight matrices streamed with the non-temporal hint (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down, 16 / 32
  *                  heads); "attn_nt" 0 / 1 / 2 = the decode attention's K/V loads never / always / from two rows per step
  *   "finished_rows" rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs (0 = off, max 16);
+ *   "fr_one"       ONE-row steps: 1 (default) = the FFN down-projection finishes its row (no split-K slabs) where its d / 8 workgroups
+ *                  fill the chip (d >= 2048), 2 = at every width, 0 = off;  "ln_trim" 1 = the LayerNorm prologue requests only the slabs
+ *                  a pass has;  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
+ *   "gemm_pf"      "workgroups[,FFN-down KB[,QKV KB]]"  prefetch roles hosted by the one-row out-projection / FFN-up launches, 0 = off
  *   "lnw_tiles"    weight tiles per workgroup of that form's consumers (0 = by row count, 1, 2)
  *   "tile_attn"    "k[,min_rows]"  prefill attention kernel (1: 16 query rows per wave; 2: 64 per workgroup, P in registers - bf16,
  *                  head_dim 128, calls whose longest prompt has at least min_rows rows); "fr_split_rows" rows up to which that form's
  *                  attention stays split
  *   "graph_steps"  decode steps captured per hipGraph;  "ln_split_rows", "attn_blocks", "attn_blocks1", "prefill_rows"
- * Results never depend on an option (tests/test_gpu_options.py).  Captured decode graphs are kept per option state, so an
- * in-process A/B (bench.py --ab) pays for capture once per state.  Unknown names / malformed values: VC_EINVAL. */
+ * What an option may change: nothing in the exact fp32 mode's greedy tokens (tests/test_gpu_options.py, test_gpu_one_row.py); in bf16
+ * mode the forms that re-order sums or round at another place ("finished_rows", "fr_split_rows", "attn_blocks*", "fr_one",
+ * "attn_fast") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can differ between option
+ * states; the prefetch / cache-policy options ("attn_pf*", "ln_pf", "gemm_pf", "nt", "attn_nt", "ln_trim", "graph_steps") change no value.
+ * The non-temporal mask "nt" has no bit for the finished-row producers (rows_gemm_fr_k, rows_gemm_fr2_k, row_gemm_fr1_k): they always
+ * stream with the hint.  Captured decode graphs are kept per option state, so an in-process A/B (bench.py --ab) pays for capture once
+ * per state.  Unknown names / malformed values: VC_EINVAL. */
 int vc_set_option(vc_engine* e, const char* name, const char* value);
 
 /* ---- weights: replaces get_model()/load_state_dict (inference_tts_scale.py:107-125).
@@ -210,6 +219,11 @@ int vc_pattern_unshift(const int64_t* span_dev, int N, int K, int64_t* out_dev, 
  * Only top_k / top_p / temperature / seed of `sc` are read.  No engine needed. */
 int vc_debug_sample(const float* logits_dev, int V, const vc_sample_cfg* sc, int n_draws,
                     int32_t* out_dev, void* stream);
+/* Diagnosis of the BOX, not of the model (no engine needed): ONE thread walks `hops` dependent loads over a ring of `bytes` bytes and
+ * stamps the per-XCD shader clock and the chip-wide 100 MHz counter around the walk.  res[0] = ns per dependent load as a lone
+ * workgroup on an otherwise idle chip sees it, res[1] = the shader clock (MHz) that workgroup really ran at.  The one-sequence
+ * sampler launch is exactly such a workgroup; bench.py prints both numbers (`box`) next to the sampler's time. */
+int vc_box_probe(long long bytes, int hops, float res[2], void* stream);
 /* Host-only (no engine, no GPU): how a decode pass of `rows` rows is launched for this model shape and compute dtype.
  * out[0] rows up to which the finished-row form applies; out[1] form of this pass (0 slabs + rows-GEMM, 1 finished rows, 2 wide
  * decode); out[2] attention splits; out[3] consumer kernel shape (GemmArgs.mt) or -1; out[4] / out[5] producer form of the
@@ -221,9 +235,11 @@ int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int64_t nbytes
 /* Timing of the last vc_tts/vc_edit call, measured with HIP events on `stream`:
  * ms[0] = prompt build + prefill, ms[1] = decode loop, ms[2] = whole call. */
 int vc_last_timing(const vc_engine* e, float ms[3]);
-/* Average duration in ms of the dominant decode kernel (FFN up-projection rows-GEMM)
- * measured with HIP events over `iters` back-to-back launches on `stream`, and the
- * algorithmic bytes one launch moves.  Used by bench.py for the roofline object. */
+/* Average duration in ms of ONE kernel of the decode step - `which` = "qkv" | "attn" | "oproj" | "ffn1" | "ffn2" (the FFN
+ * down-projection: the dominant kernel bench.py's roofline object quotes), "<name>_hot" (the same layer every launch: cache-resident),
+ * "pf_ffn1" / "pf_attn" (prefill block GEMM / tile attention, FLOPs instead of bytes) or "step" (a whole decode step without the
+ * sampler) - in the form a step of `n_rows` rows really launches, measured with HIP events over `iters` back-to-back launches on
+ * `stream` (layers rotate: cold caches), and the algorithmic bytes (FLOPs) one launch moves. */
 int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int iters, float* avg_ms,
                     double* alg_bytes, void* stream);
 

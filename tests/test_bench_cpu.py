@@ -41,3 +41,33 @@ def test_cpu_leg_times_the_unmodified_reference_when_its_tree_is_named(tmp_path)
         assert ref["kind"] == "reference" and ref["value"] > 0 and ref["port_speed_over_reference"] > 0
     finally:       # the run merges its ratio into the committed file: this tiny configuration does not belong there
         open(os.path.join(ROOT, "profiles", "cpu_reference_vs_port.json"), "w").write(before)
+
+
+def test_option_state_text_round_trips_through_the_bench_helpers():
+    """The engine's option state (`key=v,v|...`) as the bench line's JSON object, and the value of one option as vc_set_option
+    takes it (what an in-process A/B restores afterwards)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    t = "apf=8,0,-1,4,400,700,128|lpf=248,24,24|g=8|ls=3|ab=512,256|nt=63,2|fr=16,0,8|ta=2,768|r1=1,1,1|gpf=0,0,0"
+    o = bench.options_object(t)
+    assert o["text"] == t and o["attn_pf"]["cut1"] == 400 and o["graph_steps"] == 8 and o["ln_split_rows"] == 3
+    assert o["one_row"] == {"fr_one": 1, "ln_trim": 1, "attn_fast": 1} and o["nt"] == {"weights_mask": 63, "attn_kv": 2}
+    assert bench.option_value(t, "attn_pf") == "8,0,-1" and bench.option_value(t, "attn_pf_cut") == "400,700,128"
+    assert bench.option_value(t, "fr_one") == "1" and bench.option_value(t, "attn_nt") == "2" and bench.option_value(t, "no_such") is None
+
+
+def test_in_situ_figure_is_quoted_only_for_the_configuration_it_was_traced_on(tmp_path, monkeypatch):
+    sys.path.insert(0, ROOT)
+    import argparse
+    import bench
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    cfg = {"preset": "giga830M", "dtype": "bf16", "batch": 1, "lx": 80, "prompt_frames": 150, "mode": "tts"}
+    (prof / "in_situ.json").write_text(json.dumps({"source": "x", "config": cfg, "kernels": {
+        "ffn2": {"name": "k", "calls": 10, "avg_us": 7.0, "algorithmic_bytes": 33579008}}}))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    a = argparse.Namespace(**cfg)
+    got = bench.in_situ("ffn2", a)
+    assert got["avg_us"] == 7.0 and abs(got["frac"] - 33579008 / 7e-6 / 8e12) < 1e-3
+    a.batch = 8
+    assert bench.in_situ("ffn2", a) is None

@@ -71,8 +71,16 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
         assert body.count("v_cvt_pk_bf16_f32") >= 8 and vgpr <= 256, (name, vgpr)
     for name, (body, _, _) in pick(kern, "tile_attn_k<float, 128").items():
         assert "ds_read_b64_tr_b16" not in body and body.count("v_mfma_f32_16x16x4_f32") >= 64, name
-    for name, (body, _, _) in pick(kern, "rows_attn_k<").items():
-        assert ";;#ASMSTART" in body and "global_load_dwordx4" in body.split(";;#ASMSTART")[1].split(";;#ASMEND")[0], name
+    for name, (body, _, _) in pick(kern, "rows_attn_k<").items():      # <WT, NT, FAST, PF>: the prefetch role exists in the PF forms only
+        has_role = "global_load_dwordx4" in "".join(blk.split(";;#ASMEND")[0] for blk in body.split(";;#ASMSTART")[1:])
+        if name.rstrip(")").split("(")[0].rstrip().endswith("true>"):
+            assert has_role, name
+            # ... and is decided from the workgroup id: no kernel-argument load in front of the role branch
+            assert "s_load" not in body.split("s_cbranch")[0], name
+        else:
+            assert not has_role, name
+        # the four words every address depends on come in ONE scalar batch
+        assert len(re.findall(r"s_load_dword s\d+, s\[\d+:\d+\], 0x0\n\ts_load_dword s\d+, s\[\d+:\d+\], 0x0\n\ts_load_dword", body)) >= 1, name
     for name, (body, _, _) in pick(kern, "ln_rows_k<").items():
         assert ";;#ASMSTART" in body, name                                # the prefetch role of several-row decode steps
     decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false, 2>")      # FFN-up of a one-row step (h + the out-projection's two slabs)

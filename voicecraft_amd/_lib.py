@@ -58,6 +58,7 @@ PROTOTYPES = {
     "vc_pattern_revert": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int64, C.c_void_p, C.c_void_p]),
     "vc_pattern_unshift": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vc_debug_plan": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int32)]),
+    "vc_box_probe": (C.c_int, [C.c_longlong, C.c_int, C.POINTER(C.c_float), C.c_void_p]),
     "vc_debug_read": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]),
     "vc_last_timing": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "vc_bench_kernel": (C.c_int, [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_float),

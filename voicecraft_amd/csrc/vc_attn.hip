@@ -10,6 +10,7 @@
 // leaves an un-normalised (max, sum, acc[hd]) partial that the out-projection's prologue merges.
 // A cached row (hd elements) is spread over LPR = hd*sizeof/16 lanes with 16-byte loads, so a wave
 // reads 64/LPR consecutive positions = one contiguous 1 KiB burst per K (and V) instruction.
+#include <math.h>
 #include "vc_common.h"
 
 template <typename WT>
@@ -36,9 +37,15 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 // half the CUs), and the launches behind it start cold: the FFN up-projection takes 5.1 us instead of 9.1 when its weights are
 // still in L2 (profiles/r03_prefetch_probe.log).  The launch carries pf_z extra grid.z slices of workgroups that read the
 // leading bytes of up to two matrices' tiles (vc_common.h vc_prefetch_tiles).
+// Which workgroups take the role is decided from blockIdx alone (round 5): the role exists only in the PF instantiation, whose launches
+// have EXACTLY VC_MAX_NSPLIT split slices (every one-row launch: min(256 / heads, 8)), so the test is `blockIdx.z >= 8` against a
+// constant.  It used to be `blockIdx.z >= a.nsplit` - a kernel argument - and the compiler put that scalar load, its wait and the
+// branch in front of every other argument load of the attention path (one more dependent scalar round trip per launch).  The
+// prefetch slices stay BEHIND the split slices in launch order (interleaving them - odd z - measured +1.85 % per step with the role
+// on, profiles/r05b_ab_prefetch_roles_830M.log: the prefetchers then compete with the first attention workgroups' own K/V requests).
 __device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
   const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  vc_prefetch_tiles(a.pf, 2, lin, gridDim.x * gridDim.y * (unsigned)a.nsplit, gridDim.x * gridDim.y * (unsigned)a.pf_z);
+  vc_prefetch_tiles(a.pf, 2, lin, gridDim.x * gridDim.y * (unsigned)VC_MAX_NSPLIT, gridDim.x * gridDim.y * (gridDim.z - (unsigned)VC_MAX_NSPLIT));
 }
 
 // NT: K/V rows are requested with the non-temporal hint (every cached row is read exactly once per step and never again before
@@ -50,7 +57,7 @@ __device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
 // maximum: no rescaling per visit (one per batch of 4), and the position groups of a wave merge by plain additions (no
 // exponentials, no multiplies).  In bf16 mode the exponentials are hardware exp2 (v_exp_f32, q pre-scaled by log2 e; the exported
 // maximum is converted back to natural units for the out-projection's merge); the exact fp32 mode keeps expf.
-template <typename WT, bool NT, bool FAST>
+template <typename WT, bool NT, bool FAST, bool PF>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;
   constexpr int NW = VC_ATT_WAVES;
@@ -63,20 +70,27 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
   __shared__ float s_o[NW][128];
   VC_KTS_DECL();
   VC_KTS(0);
+  if constexpr (PF) {
+    if (blockIdx.z >= VC_MAX_NSPLIT) { prefetch_role(a); return; }     // (wave-uniform, decided from the workgroup id alone)
+  }
   const int r = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;     // grid.x == n_rows
-  if (sp >= a.nsplit) { prefetch_role(a); return; }              // (wave-uniform, kernel arguments only)
-  // one scalar round trip for everything the addresses depend on (no early exit in between: a
-  // branch would let the compiler serialise these three loads)
-  const int active = *a.n_active;
-  const int pos = a.row_pos[r];
-  const int seq = a.row_seq[r];
-  const int share = *a.share_len;
+  // ONE scalar round trip for everything the addresses depend on.  Written as plain C these four came out as VECTOR loads (the
+  // compiler cannot prove them invariant) and `share` was sunk behind the branch below - two dependent vector round trips before the
+  // first K/V request (seen in the ISA, round 5).  All four are wave-uniform words that earlier launches of the step wrote (the
+  // scalar cache is invalidated at every kernel start): one batch of s_load, one wait.
+  int active, pos, seq, share;
+  asm volatile("s_load_dword %0, %4, 0x0\n\ts_load_dword %1, %5, 0x0\n\ts_load_dword %2, %6, 0x0\n\ts_load_dword %3, %7, 0x0\n\ts_waitcnt lgkmcnt(0)"
+               : "=&s"(active), "=&s"(pos), "=&s"(seq), "=&s"(share)
+               : "s"(a.n_active), "s"(a.row_pos + r), "s"(a.row_seq + r), "s"(a.share_len)
+               : "memory");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int hd = a.hd;
-  const int LPR = hd / EPL;            // lanes per cached row: 4 (bf16, head_dim 32), 8, 16 or 32
-  const int PPW = 64 / LPR;            // positions per wave per step
-  const int sub = lane / LPR, li = lane - sub * LPR;
+  constexpr int EPL_SH = EPL == 8 ? 3 : 2;
+  const int lpr_sh = a.hd_shift - EPL_SH;   // (head_dim is a power of two: shifts, not the divisions the compiler would expand)
+  const int LPR = 1 << lpr_sh;         // lanes per cached row: 4 (bf16, head_dim 32), 8, 16 or 32
+  const int PPW = 64 >> lpr_sh;        // positions per wave per step
+  const int sub = lane >> lpr_sh, li = lane & (LPR - 1);
 
   float m = -INFINITY, l = 0.f;
   float o[EPL];
@@ -87,7 +101,11 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
                                                // tested only so that its load is not sunk behind the branch)
     VC_KTS(1);
     const int S = pos + 1;
-    const int chunk = (S + a.nsplit - 1) / a.nsplit;
+    // ceil(S / nsplit) without the integer division the compiler expands into ~25 dependent instructions: a.inv_nsplit is 1 / nsplit
+    // rounded UP, so the product never falls below the quotient; a chunk that came out one too large only leaves the last split fewer
+    // positions (any chunk with chunk * nsplit >= S partitions [0, S))
+    int chunk = (int)((float)(S + a.nsplit - 1) * a.inv_nsplit);
+    if (chunk * a.nsplit < S) ++chunk;
     const int p0 = sp * chunk;
     const int p1 = min(S, p0 + chunk);
     const int step = 4 * NW * PPW;
@@ -245,15 +263,21 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 }
 
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s) {
-  dim3 grid(rows_cap, a.H, a.nsplit + a.pf_z);
+  // prefetch role: pf_z extra slices behind the split slices; only in launches of exactly VC_MAX_NSPLIT split slices (the role's test
+  // is against that constant) and where a workgroup's XCD follows from its (row, head) index
+  const bool pf = a.pf_z > 0 && (a.pf[0].len > 0 || a.pf[1].len > 0) && a.nsplit == VC_MAX_NSPLIT && ((rows_cap * a.H) % 8 == 0);
+  dim3 grid(rows_cap, a.H, a.nsplit + (pf ? a.pf_z : 0));
   ++vc_launch_counts[VC_LC_ROWS_ATTN];
-#define VC_ATTN_GO(WT_, NT_, F_) hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_>), grid, dim3(64 * VC_ATT_WAVES), 0, s, a)
+  AttnArgs b = a;
+  b.inv_nsplit = nextafterf(1.0f / (float)a.nsplit, 2.0f);
+#define VC_ATTN_GO(WT_, NT_, F_) { if (pf) hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b); \
+                                   else hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_, false>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b); }
   if (dtype == VC_DTYPE_BF16) {
-    if (a.fast) { if (a.nt) VC_ATTN_GO(bf16_t, true, true); else VC_ATTN_GO(bf16_t, false, true); }
-    else { if (a.nt) VC_ATTN_GO(bf16_t, true, false); else VC_ATTN_GO(bf16_t, false, false); }
+    if (a.fast) { if (a.nt) VC_ATTN_GO(bf16_t, true, true) else VC_ATTN_GO(bf16_t, false, true) }
+    else { if (a.nt) VC_ATTN_GO(bf16_t, true, false) else VC_ATTN_GO(bf16_t, false, false) }
   } else {
-    if (a.fast) { if (a.nt) VC_ATTN_GO(float, true, true); else VC_ATTN_GO(float, false, true); }
-    else { if (a.nt) VC_ATTN_GO(float, true, false); else VC_ATTN_GO(float, false, false); }
+    if (a.fast) { if (a.nt) VC_ATTN_GO(float, true, true) else VC_ATTN_GO(float, false, true) }
+    else { if (a.nt) VC_ATTN_GO(float, true, false) else VC_ATTN_GO(float, false, false) }
   }
 #undef VC_ATTN_GO
   return hipGetLastError();

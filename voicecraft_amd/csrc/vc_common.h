@@ -276,6 +276,7 @@ struct GemmArgs {
   const float* att_o;       // [VC_ROWS][H][nsplit][hd]
   const float* att_ml;      // [VC_ROWS][H][nsplit][2]
   int nsplit, H, hd;
+  int hd_shift;             // log2(hd): head_dim is a power of two (vc_create), so head / element of a channel are a shift and a mask
   int att_q4_shift;         // log2 of (K slice / 4) when a power of two, else -1 (set by the launcher)
   // epilogues
   void* out;                // RELU/GELU: WT [r][out_ld]; LOGITS: float [r][group][N]
@@ -289,8 +290,8 @@ struct GemmArgs {
   float* part_out;          // PART: [ksplit][rows_cap][N]
   void* x_out;              // ln_rows_k: normalised rows, WT [rows][d]
   long long* dbg_ts;        // shader-clock stamps (diagnostic builds with -DVC_KERNEL_TS only)
-  PfSeg pf;                 // ln_rows_k only: pf_blocks extra workgroups prefetch the head of this matrix's tiles (vc_prefetch_tiles); 0 = none
-  int pf_blocks;
+  PfSeg pf;                 // ln_rows_k, rows_gemm_k (one tile per workgroup), row_gemm_fr1_k: pf_blocks extra workgroups (per K slice)
+  int pf_blocks;            // prefetch the head of this matrix's tiles (vc_prefetch_tiles); 0 = none
 };
 
 struct AttnArgs {
@@ -299,6 +300,8 @@ struct AttnArgs {
   const void* vcache;
   long cache_seq_stride;
   int S_max, H, hd, d, nsplit;
+  int hd_shift;             // log2(hd)
+  float inv_nsplit;         // 1 / nsplit rounded up (set by the launcher)
   float scale;
   const int* row_seq;
   const int* row_pos;
@@ -310,8 +313,8 @@ struct AttnArgs {
   float* att_ml;
   void* x_out;              // nsplit == 1 only: normalised output rows, WT [rows][d] (the out-projection then takes the plain prologue)
   long long* dbg_ts;        // diagnostic builds only
-  // rows_attn_k only: pf_z extra grid.z slices of workgroups that do no attention - they pull the head of the NEXT launches'
-  // weight tiles into the L2 of the XCD whose workgroups will read them (vc_attn.hip, "piggyback prefetch"); 0 = none
+  // rows_attn_k only: pf_z extra grid.z slices of workgroups BEHIND the VC_MAX_NSPLIT split slices that do no attention - they pull the
+  // head of the NEXT launches' weight tiles into the L2 of the XCD whose workgroups will read them (vc_attn.hip); 0 = none
   PfSeg pf[2];
   int pf_z;
   int nt;                   // rows_attn_k: K/V rows requested with the non-temporal hint

@@ -138,6 +138,10 @@ struct vc_engine {
   // whole K, two k-tiles per MFMA fragment, residual + bias added) instead of leaving 4 split-K slabs, so the next layer's QKV
   // projection (and heads-1) reads one 8 KB row instead of h + bias + 4 slabs = 40 KB in each of its 512 workgroups
   int fr_one = 1;
+  // option "gemm_pf" = "blocks,f2_kb,qkv_kb" (round 5): prefetch roles hosted by the one-row GEMM launches that leave HBM idle - the
+  // out-projection launch pulls the first f2_kb KB of every FFN down-projection tile, the FFN-up launch the first qkv_kb KB of the NEXT
+  // layer's QKV tiles (d <= 1024 models: every launch is latency); `blocks` extra workgroups per K slice.  0 = off.
+  int gpf_blocks = 0, gpf_f2_kb = 0, gpf_qkv_kb = 0;
   // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
   // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
   int ln_trim = 1;
@@ -300,6 +304,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.n_active = rs.n_active ? rs.n_active : e->one;
   g.nt = (rs.n_active != nullptr || rs.nt) ? 1 : 0;   // decode steps (and the kernel microbenchmarks) stream once; per matrix: nt_bit
   g.d = e->d; g.H = e->H; g.hd = e->hd; g.S_max = e->S_max;
+  g.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7;            // head_dim is 32, 64 or 128 (vc_create)
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
   g.ln_trim = e->ln_trim;
@@ -367,7 +372,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       memset(&a, 0, sizeof a);
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc;
       a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
-      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit;
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7; a.d = d; a.nsplit = rs.nsplit;
       a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
@@ -461,7 +466,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       memset(&a, 0, sizeof a);
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc;
       a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
-      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit;
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7; a.d = d; a.nsplit = rs.nsplit;
       a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts;
@@ -486,6 +491,18 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wo; nt_bit(e, g, NT_O);
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
+      if (e->gpf_blocks > 0 && e->gpf_f2_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr) {
+        // prefetch role: the head of every FFN down-projection tile of this layer, as the launch after next will read them
+        const int KT2 = 4 * d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16);
+        if (fd) {     // row_gemm_fr1_k: workgroup x reads 8-channel tile x
+          const int tile_b = KT2 * 4 * VC_TH_RES * 16;
+          g.pf = PfSeg{(const char*)ly.W28, d / VC_TH_RES, tile_b, std::min(tile_b, e->gpf_f2_kb * 1024), 1};
+        } else {      // slab form: workgroup (x, y) reads the y-th K slice of 16-channel tile x
+          const int ks = e->p_f2.ksplit, sub_b = KT2 * 64 * 16 / ks;
+          g.pf = PfSeg{(const char*)ly.W2, e->p_f2.n_tiles * ks, sub_b, std::min(sub_b, e->gpf_f2_kb * 1024 / ks), ks};
+        }
+        g.pf_blocks = e->gpf_blocks;
+      }
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
@@ -495,6 +512,11 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.wg = ly.wg_1;
       g.out = e->act; g.out_ld = 4 * d;
+      if (!split_ln && e->gpf_blocks > 0 && e->gpf_qkv_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr && l + 1 < e->L) {
+        const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * VC_TH_QKV;
+        g.pf = PfSeg{(const char*)e->layers[l + 1].Wqkv, e->p_qkv.n_tiles, tile_b, std::min(tile_b, e->gpf_qkv_kb * 1024), 1};
+        g.pf_blocks = e->gpf_blocks;
+      }
       if (split_ln) {
         g.x_out = e->xn;
         if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_f1.n_tiles % 8 == 0) {
@@ -597,7 +619,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       AttnArgs a;
       memset(&a, 0, sizeof a);
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
-      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
       a.nt = rs.n_active != nullptr ? attn_nt_for(e, rs.n_rows) : 0;      // wide decode passes stream their K/V once, prefill passes re-read it
@@ -940,6 +962,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
       return fail(e, VC_ESTATE, "option '%s': this engine was created with VC_FINISHED_ROWS=0 and VC_FR_ONE=0 and holds no 8-channel weight images", name.c_str());
     if (name == "fr_one") e->fr_one = std::max(0, std::min(v0, 2));
     else e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
+  } else if (name == "gemm_pf") {
+    e->gpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
+    if (n >= 2) e->gpf_f2_kb = std::max(0, v1);
+    if (n >= 3) e->gpf_qkv_kb = std::max(0, v2);
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
@@ -953,10 +979,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|lpf=%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d|ta=%d,%d|r1=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|lpf=%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d|ta=%d,%d|r1=%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast);
+           e->fr_one, e->ln_trim, e->attn_fast, e->gpf_blocks, e->gpf_f2_kb, e->gpf_qkv_kb);
   e->opt_state = buf;
 }
 
@@ -1243,7 +1269,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1885,7 +1911,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       AttnArgs a;
       memset(&a, 0, sizeof a);
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
-      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7; a.d = d; a.nsplit = rs.nsplit; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = attn_nt_for(e, rs.n_rows);
       a.fast = e->attn_fast;
@@ -1902,7 +1928,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       AttnArgs a;
       memset(&a, 0, sizeof a);
       a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
-      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.d = d; a.nsplit = 1; a.scale = 1.0f / sqrtf((float)e->hd);
+      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7; a.d = d; a.nsplit = 1; a.scale = 1.0f / sqrtf((float)e->hd);
       a.row_seq = e->pre_row_seq; a.row_pos = e->pre_row_pos; a.n_rows = n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.x_out = e->xn;
       // (the kernel a prompt of this many rows would get: prefill_batch's rule)

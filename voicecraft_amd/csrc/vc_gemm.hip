@@ -28,6 +28,7 @@
 // kernel's LayerNorm prologue sums (launch-boundary reduce: no atomics, deterministic) - the form of ONE-row steps.
 // Steps of 2..16 rows keep whole residual rows instead (finished-row form, round 4): rows_gemm_fr_k / rows_gemm_fr2_k produce
 // them, the PRO_LNW prologue of rows_gemm_k folds their LayerNorm one wave per row.
+#include <algorithm>
 #include "vc_common.h"
 
 // ------------------------------------------------------------------ packing
@@ -151,6 +152,20 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
 
   VC_KTS_DECL();
   VC_KTS(0);
+  // Prefetch role (round 5, option "gemm_pf"; GemmArgs.pf / pf_blocks as in ln_rows_k): a launch that leaves HBM idle - the one-row
+  // out-projection waits for the attention partials and streams 8.4 MB in 4.3 us; every launch of a d = 1024 model - is launched
+  // with a SECOND grid.z layer of workgroups that do none of its work: the first pf_blocks of them pull the head of a LATER launch's
+  // weight tiles into the L2 of the XCD whose workgroups will read them (vc_common.h vc_prefetch_tiles), the rest exit at once.
+  // The role is decided from blockIdx.z alone - a test against a kernel argument would put a scalar load, its wait and a branch in
+  // front of every other argument load of the GEMM path (seen in the ISA of the first build).  grid.x * grid.y is a multiple of
+  // 8, so a workgroup's XCD is its index within the layer & 7.  (The heads' second linears use grid.z for their groups: no role.)
+  if constexpr (NTW == 1 && !R2 && EPI != EPI_LOGITS) {
+    if (blockIdx.z != 0) {
+      const unsigned idx = blockIdx.x + gridDim.x * blockIdx.y;
+      if (idx < (unsigned)a.pf_blocks) vc_prefetch_tiles(&a.pf, 1, idx, 0u, (unsigned)a.pf_blocks);
+      return;
+    }
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = (NTW == 1) ? wv : (wv & 3);    // K quarter of the tile
@@ -417,7 +432,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
       const int ic_ = on##S[ib_] ? idx_ : 0;                                                     \
       r##S[ib_] = (qsh >= 0) ? (ic_ >> qsh) : (ic_ / q4);                                        \
       c##S[ib_] = k0 + (ic_ - r##S[ib_] * q4) * 4;                                               \
-      const int h_ = c##S[ib_] / a.hd, e_ = c##S[ib_] - h_ * a.hd;                               \
+      const int h_ = c##S[ib_] >> a.hd_shift, e_ = c##S[ib_] & (a.hd - 1);                      \
       const float2* ml_ = reinterpret_cast<const float2*>(a.att_ml) + (long)(r##S[ib_] * a.H + h_) * a.nsplit; \
       const float* op_ = a.att_o + ((long)(r##S[ib_] * a.H + h_) * a.nsplit) * a.hd + e_;        \
       _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                        \
@@ -616,7 +631,7 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr_k(const GemmArg
       const int i_ = on[ib] ? idx : 0;
       ir[ib] = (qsh >= 0) ? (i_ >> qsh) : (i_ / q4);
       ic[ib] = (i_ - ir[ib] * q4) * 4;
-      const int h_ = ic[ib] / a.hd, e_ = ic[ib] - h_ * a.hd;
+      const int h_ = ic[ib] >> a.hd_shift, e_ = ic[ib] & (a.hd - 1);
       const float2* mp = reinterpret_cast<const float2*>(a.att_ml) + (long)(ir[ib] * a.H + h_) * a.nsplit;
       const float* op = a.att_o + ((long)(ir[ib] * a.H + h_) * a.nsplit) * a.hd + e_;
 #pragma unroll
@@ -913,6 +928,10 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void row_gemm_fr1_k(const GemmArg
   using T = WTr<WT>;
   constexpr int NW = VC_FR_WAVES, NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;   // SPT = 16-byte units per (tile, k-tile) = 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  if (blockIdx.y != 0) {     // prefetch role, as in rows_gemm_k: a second layer of workgroups, decided from the workgroup id alone
+    if (blockIdx.x < (unsigned)a.pf_blocks) vc_prefetch_tiles(&a.pf, 1, blockIdx.x, 0u, (unsigned)a.pf_blocks);
+    return;
+  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x;
@@ -979,7 +998,10 @@ static hipError_t launch_fr1_n(const GemmArgs& a, hipStream_t s) {
   auto kern = (a.KT == 2 * VC_FR_WAVES * NPW) ? row_gemm_fr1_k<WT, NPW, true> : row_gemm_fr1_k<WT, NPW, false>;
   const size_t lds = (size_t)a.K * sizeof(WT) + (size_t)VC_FR_WAVES * 4 * sizeof(f32x4);
   ++vc_launch_counts[VC_LC_ROW_GEMM_FR1];
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(64 * VC_FR_WAVES), lds, s, a);
+  GemmArgs b = a;
+  if (b.pf_blocks <= 0 || b.pf.len <= 0 || a.n_tiles % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
+  b.pf_blocks = std::min(b.pf_blocks, a.n_tiles);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles, b.pf_blocks > 0 ? 2 : 1), dim3(64 * VC_FR_WAVES), lds, s, b);
   return hipGetLastError();
 }
 // 1 when the one-row finished-row producer can take an [N x K] matrix in this dtype (the engine's planning and the launcher agree on it)
@@ -1113,7 +1135,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
       const int q4 = kblk >> 2;
       for (int idx = tid; idx < nr * q4; idx += NT) {
         const int r = idx / q4, c = k0 + (idx - r * q4) * 4;
-        const int h = c / a.hd, e = c - h * a.hd;
+        const int h = c >> a.hd_shift, e = c & (a.hd - 1);
         const float2* ml = reinterpret_cast<const float2*>(a.att_ml) + (long)((row0 + r) * a.H + h) * a.nsplit;
         const float* op = a.att_o + ((long)((row0 + r) * a.H + h) * a.nsplit) * a.hd + e;
         float M = -INFINITY;
@@ -1296,7 +1318,10 @@ static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int gr
     }
   }
   ++vc_launch_counts[VC_LC_ROWS_GEMM];
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles / NTW, ksplit, groups), dim3(256 * NTW), lds, s, b);
+  // (prefetch role: extra workgroups behind the tiles; only where the tile -> XCD rule holds)
+  if (NTW != 1 || R2 || EPI == EPI_LOGITS || groups != 1 || b.pf_blocks <= 0 || b.pf.len <= 0 || (a.n_tiles * ksplit) % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
+  b.pf_blocks = std::min(b.pf_blocks, a.n_tiles * ksplit);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles / NTW, ksplit, b.pf_blocks > 0 ? 2 : groups), dim3(256 * NTW), lds, s, b);
   return hipGetLastError();
 }
 

@@ -68,9 +68,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int 
       if (n < d) {
         store4(a.q_out + (long)mg * d + n, acc);
       } else {
-        const int which = (n - d) / d;
+        const int which = (n - d) >= d ? 1 : 0;          // n < 3 d: K or V
         const int c = (n - d) - which * d;
-        const int h = c / a.hd, e = c - h * a.hd;
+        const int h = c >> a.hd_shift, e = c & (a.hd - 1);
         if (pos >= 0) {
           WT* base = reinterpret_cast<WT*>(which ? a.vcache : a.kcache) +
                      (long)seq * a.cache_seq_stride + ((long)h * a.S_max + pos) * a.hd + e;
@@ -134,8 +134,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT
       const int c0 = max(n[j] - d, 0);
       isv[j] = c0 >= d;
       const int c = c0 - (isv[j] ? d : 0);
-      const int h = c / a.hd;
-      choff[j] = (long)h * a.S_max * a.hd + (c - h * a.hd);
+      const int h = c >> a.hd_shift;
+      choff[j] = (long)h * a.S_max * a.hd + (c & (a.hd - 1));
     }
 #pragma unroll
     for (int i = 0; i < MT; ++i) rowoff[i] = (pos[i] >= 0) ? (long)seq[i] * a.cache_seq_stride + (long)pos[i] * a.hd : -1;

@@ -708,6 +708,50 @@ extern "C" int vc_debug_sample(const float* logits_dev, int V, const vc_sample_c
   return hipGetLastError() == hipSuccess ? VC_OK : VC_EHIP;
 }
 
+// =============================================================== box probe (diagnosis)
+// ONE thread walks a dependent chain of loads (next = ring[next]) and stamps both clocks around it: the per-XCD shader clock
+// (clock64) and the chip-wide 100 MHz counter (wall_clock64).  hops / wall = the latency one dependent load costs a lone
+// workgroup on an otherwise idle chip; shader clocks / wall = the clock that workgroup really ran at.  The sampler at one
+// sequence is exactly such a workgroup (DESIGN 4.3 f: 12.5 us on one box, 26 us on another, same code): bench.py reports these
+// numbers next to the sampler's time so that boxes can be told apart.
+__global__ void box_probe_init_k(unsigned* ring, unsigned n_mask, unsigned stride) {
+  const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i <= n_mask) ring[(size_t)i * 16] = ((i * 5u + stride) & n_mask);      // full period: multiplier = 1 mod 4, odd increment; one entry per 64 B
+}
+__global__ void box_probe_k(const unsigned* __restrict__ ring, int hops, long long* out) {
+  if (threadIdx.x != 0) return;
+  unsigned p = 0;
+  for (int i = 0; i < 64; ++i) p = ring[(size_t)p * 16];                     // (lands somewhere in the ring: warms nothing but the TLB entry of the start)
+  const long long w0 = wall_clock64(), c0 = clock64();
+  for (int i = 0; i < hops; ++i) p = __builtin_nontemporal_load(ring + (size_t)p * 16);
+  const long long c1 = clock64(), w1 = wall_clock64();
+  out[0] = w1 - w0; out[1] = c1 - c0; out[2] = p;
+}
+// res[0] = ns per dependent load over a `bytes`-sized ring, res[1] = shader clock in MHz during the walk
+extern "C" int vc_box_probe(long long bytes, int hops, float res[2], void* stream) {
+  if (bytes < 4096 || hops < 1 || !res) return VC_EINVAL;
+  unsigned n = 1;
+  while ((long long)n * 2 * 64 <= bytes) n *= 2;
+  unsigned* ring = nullptr;
+  long long* out = nullptr;
+  if (hipMalloc((void**)&ring, (size_t)n * 64) != hipSuccess) return VC_EHIP;
+  if (hipMalloc((void**)&out, 64) != hipSuccess) { (void)hipFree(ring); return VC_EHIP; }
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(box_probe_init_k, dim3((n + 255) / 256), dim3(256), 0, s, ring, n - 1, 12345u | 1u);
+  long long h[3] = {0, 0, 0};
+  hipError_t e = hipSuccess;
+  for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {       // the second walk is the one reported
+    hipLaunchKernelGGL(box_probe_k, dim3(1), dim3(64), 0, s, ring, hops, out);
+    e = hipMemcpyAsync(h, out, sizeof h, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+  }
+  (void)hipFree(ring); (void)hipFree(out);
+  if (e != hipSuccess || h[0] <= 0) return VC_EHIP;
+  res[0] = (float)((double)h[0] * 10.0 / hops);              // 100 MHz ticks -> ns
+  res[1] = (float)((double)h[1] / ((double)h[0] * 0.01));    // shader clocks per microsecond
+  return VC_OK;
+}
+
 // =============================================================== output assembly
 // res = cat(non-mask pieces of y, un-shifted generated spans) (voicecraft.py:1141-1153, :890-898).
 __global__ void assemble_k(const AssembleArgs a) {

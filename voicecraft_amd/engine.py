@@ -21,7 +21,7 @@ from typing import Iterable
 import torch
 
 from . import _lib
-from ._lib import ModelCfg, SampleCfg, check
+from ._lib import EngineError, ModelCfg, SampleCfg, check
 
 _DTYPES = {"bf16": _lib.VC_DTYPE_BF16, "bfloat16": _lib.VC_DTYPE_BF16, torch.bfloat16: _lib.VC_DTYPE_BF16,
            "fp32": _lib.VC_DTYPE_F32, "float32": _lib.VC_DTYPE_F32, torch.float32: _lib.VC_DTYPE_F32}
@@ -437,7 +437,8 @@ class VoiceCraftEngine:
     # ------------------------------------------------------------------ measurement hooks
     def set_option(self, name: str, value) -> None:
         """Run-time launch-shape option of the decode step (include/vc_engine.h vc_set_option), e.g. ("attn_pf", "0") or
-        ("attn_pf", "8,0,32").  Results do not depend on it; bench.py --ab toggles one inside a process."""
+        ("attn_pf", "8,0,32").  Exact-mode tokens never depend on one; bf16 logits move by rounding where a form re-orders sums
+        (include/vc_engine.h).  bench.py --ab toggles one inside a process."""
         check(self.lib.vc_set_option(self._h, str(name).encode(), str(value).encode()), self._h, f"vc_set_option({name})")
 
     def options(self) -> str:
@@ -489,6 +490,24 @@ def debug_sample(logits: torch.Tensor, n_draws: int, top_k: int = -100, top_p: f
                              C.c_void_p(out.data_ptr()), C.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream))
     if rc != 0:
         raise AssertionError(f"vc_debug_sample rejected its arguments (code {rc})")
+    return out
+
+
+def box_probe(device="cuda:0", hops: int = 256) -> dict:
+    """The box's dependent-load latency as ONE workgroup on an idle chip sees it (vc_box_probe): over a 128 KB ring (cache-resident)
+    and a 256 MB ring (memory), plus the shader clock that lone workgroup ran at."""
+    lib = _lib.load()
+    dev = torch.device(device)
+    out = {}
+    with torch.cuda.device(dev):
+        s = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        for name, nbytes in (("l2", 128 << 10), ("hbm", 256 << 20)):
+            res = (C.c_float * 2)()
+            rc = lib.vc_box_probe(C.c_longlong(nbytes), int(hops), res, s)
+            if rc != 0:
+                raise EngineError(f"vc_box_probe failed (code {rc})")
+            out[f"dependent_load_ns_{name}"] = round(float(res[0]), 1)
+            out[f"shader_mhz_{name}_walk"] = round(float(res[1]), 0)
     return out
 
 
