@@ -105,7 +105,7 @@ def in_situ(kernel, args):
 OPTION_STATE = {"attn_pf": ("apf", (0, 1, 2)), "attn_pf_cut": ("apf", (4, 5, 6)), "ln_pf": ("lpf", (0, 1, 2)), "graph_steps": ("g", (0,)),
                 "ln_split_rows": ("ls", (0,)), "attn_blocks": ("ab", (0,)), "attn_blocks1": ("ab", (1,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)),
                 "finished_rows": ("fr", (0,)), "lnw_tiles": ("fr", (1,)), "fr_split_rows": ("fr", (2,)), "tile_attn": ("ta", (0, 1)),
-                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "gemm_pf": ("gpf", (0, 1, 2))}
+                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "gemm_pf": ("gpf", (0, 1, 2))}
 
 
 def option_value(text, knob):
@@ -158,7 +158,7 @@ def options_object(text):
     names = {"apf": ("attn_pf", ["slices", "wo_kb", "w1_kb", "scale_quarters", "cut1", "cut2", "cut0"]), "lpf": ("ln_pf", ["workgroups", "qkv_kb", "w1_kb"]),
              "g": ("graph_steps", None), "ls": ("ln_split_rows", None), "ab": ("attn_blocks", ["several_rows", "one_row"]),
              "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "lnw_tiles", "split_rows"]),
-             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast"])}
+             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "gpf": ("gemm_pf", ["workgroups", "ffn_down_kb", "qkv_kb"])}
     out = {"text": text}
     try:
         for part in text.split("|"):
@@ -625,7 +625,9 @@ def main():
         # kernel time in every round-3 profile once the up-projection's first half is prefetched under the attention launch
         # (profiles/r03g_*: 22.4 % against 17.9 %); timed in isolation here, so in agreement with its in-situ rocprof average
         mb_rows = min(B, 16)       # the kernel microbenchmarks drive the <=16-row decode kernels
+        c0 = eng.launch_counts()
         k_ms, k_bytes = eng.bench_kernel("ffn2", n_rows=mb_rows, iters=64)
+        fr1_form = eng.launch_counts()["row_gemm_fr1"] > c0["row_gemm_fr1"]      # which form the microbenchmark (= the step) really launched
         step_ms, _ = eng.bench_kernel("step", n_rows=mb_rows, iters=8)
         kernels = {}
         for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
@@ -634,6 +636,7 @@ def main():
         fr_form = 2 <= mb_rows <= 16 and "|fr=0," not in eng.options()       # several-row steps: the finished-row producer is what runs
         roof = {"bound": "hbm", "kernel": (("rows_gemm_fr_k<plain> (FFN down-projection, finished rows: 8-channel tiles over the whole K)" +
                                             ("" if B <= 16 else f"; microbenchmarked at 16 rows - this run's {B}-row steps use the wide-decode kernel rows_gemm_mt_k")) if fr_form
+                                           else "row_gemm_fr1_k<plain, residual> (FFN down-projection of a one-row step, finished row: 8-channel tiles over the whole K, two k-tiles per MFMA fragment)" if fr1_form
                                            else "rows_gemm_k<plain,split-K slabs> (FFN down-projection)"),
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn2", args),
@@ -696,13 +699,26 @@ def main():
             except Exception as e:   # reporting only
                 out["one_sample"] = {"error": str(e)}
         ab = args.ab
-        if ab == "auto":       # every default-ON feature has to show its gain in the line the driver records
-            ab = ("attn_pf=0:8,0,-1" if B == 1 else "finished_rows=0:16" if B <= 16 else "attn_nt=0:2") if not edit else "attn_pf=0:8,0,-1"
+        more = []
+        if ab == "auto":       # every default-ON feature has to show its gain in the line the driver records: the largest one in `ab`,
+            # the other one-row forms of round 5 in `ab_more` (fewer pairs).  The attention launch's prefetch role is default OFF since
+            # round 5 (it costs 0.4-1.9 % next to the leaner kernels, profiles/r05b_*, r05c_*): its A/B stays in `ab_more` as the standing check
+            ab = ("fr_one=0:1" if B == 1 else "finished_rows=0:16" if B <= 16 else "attn_nt=0:2")
+            if B == 1:
+                more = ["qkv_p8=0:1", "ln_trim=0:1", "gemm_pf=0:128,-1,0", "attn_pf=0:8,0,-1"]
         if n_gpus == 1 and ab and ab != "none":
             try:
                 out["ab"] = ab_block(eng, one_step, ab, max(3, args.ab_pairs))
             except Exception as e:   # reporting only
                 out["ab"] = {"error": str(e)}
+            out["ab_more"] = []
+            for spec in more:
+                try:
+                    r = ab_block(eng, one_step, spec, max(3, min(5, args.ab_pairs)))
+                    r.pop("metric", None)
+                    out["ab_more"].append(r)
+                except Exception as e:   # reporting only
+                    out["ab_more"].append({"knob": spec, "error": str(e)})
         if n_gpus == 1 and B == 1 and not edit and args.preset == "giga830M" and not args.no_configs:
             # the other BASELINE configurations on their own engines (after the headline's timed region; ~20 s)
             del eng, wl

@@ -10,15 +10,21 @@ cfg = {"preset": cfg.get("preset", "giga830M"), "dtype": cfg.get("dtype", "bf16"
 d = 2048
 alg = {"ffn1": 4 * d * d * 2 + d * 4 + 4 * d * 2, "ffn2": 4 * d * d * 2 + 4 * d * 2 + d * 4, "qkv": 3 * d * d * 2 + d * 4 + 3 * d * 2,
        "oproj": d * d * 2 + d * 4 * 2}
-pat = {"ffn1": r"rows_gemm_k<bf16_t, 16, 0, 2,", "ffn2": r"rows_gemm_k<bf16_t, 16, 1, 1,", "qkv": r"rows_gemm_k<bf16_t, 16, 0, 0,",
-       "oproj": r"rows_gemm_k<bf16_t, 8, 2, 1,"}      # (template tail: tiles per workgroup, non-temporal)
+# first pattern that matches wins (the forms a one-row step launches since round 5, then the round-4 forms)
+pat = {"ffn1": [r"rows_gemm_k<bf16_t, 16, 0, 2,"], "ffn2": [r"row_gemm_fr1_k<bf16_t, 16, true, 8, 1, 5>", r"rows_gemm_k<bf16_t, 16, 1, 1,"],
+       "qkv": [r"row_gemm_fr1_k<bf16_t, 8, true, 4, 0, 0>", r"rows_gemm_k<bf16_t, 16, 0, 0,"], "oproj": [r"rows_gemm_k<bf16_t, 8, 2, 1,"]}
 out = {"source": f"{src} (rocprofv3 --pmc FETCH_SIZE --kernel-trace, own pass of `python bench.py --steps 1 --warmup 0`; FETCH_SIZE[KB] * 1024 * 2)",
        "config": cfg, "kernels": {}}
-for line in open(src):
-    for k, p in pat.items():
-        if line.startswith(p) and "FETCH_SIZE" in line:
-            f = line.split("FETCH_SIZE")[1].split()
-            out["kernels"][k] = {"name": p, "calls": int(f[0]), "fetch_bytes_per_launch": int(round(2 * float(f[1]) * 1024)),
-                                 "algorithmic_bytes": alg[k]}
+lines = [l for l in open(src) if "FETCH_SIZE" in l]
+for k, ps in pat.items():
+    for p in ps:
+        hit = [l for l in lines if l.startswith(p)]
+        if hit:
+            calls = tot = 0
+            for l in hit:
+                f = l.split("FETCH_SIZE")[1].split()
+                calls += int(f[0]); tot += int(f[0]) * float(f[1])
+            out["kernels"][k] = {"name": p, "calls": calls, "fetch_bytes_per_launch": int(round(2 * tot / calls * 1024)), "algorithmic_bytes": alg[k]}
+            break
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

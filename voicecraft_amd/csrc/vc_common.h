@@ -418,8 +418,8 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
 hipError_t vc_launch_gemm_fr(const GemmArgs& a, int dtype, int pro, hipStream_t s);   // finished-row producers (vc_gemm.hip)
 size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype);
 int vc_gemm_fr_form(int rows, int N, int K, int dtype, int pro, int nsplit);   // 0 none, 1 one piece, 2 K in two halves
-hipError_t vc_launch_gemm_fr1(const GemmArgs& a, int dtype, hipStream_t s);           // one-row finished-row producer (vc_gemm.hip row_gemm_fr1_k)
-int vc_gemm_fr1_ok(int N, int K, int dtype);
+hipError_t vc_launch_gemm_fr1(const GemmArgs& a, int dtype, int pro, int epi, hipStream_t s);   // one-row paired kernel (vc_gemm.hip row_gemm_fr1_k)
+int vc_gemm_fr1_ok(int N, int K, int dtype, int nw);
 extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production
 // Launch census (process-wide, host side): which kernel FORM each launcher picked.  Read through
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one

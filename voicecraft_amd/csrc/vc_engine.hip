@@ -32,6 +32,7 @@ struct RawTensor {
 struct Layer {
   uint4 *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;
   uint4 *Wo8 = nullptr, *W28 = nullptr;                                 // Wo / W2 once more in 8-channel tiles (finished-row producers, vc_gemm.hip)
+  uint4 *Wqkv8 = nullptr;                                               // Wqkv . gamma in 8-channel tiles (one-row paired QKV kernel, option "qkv_p8")
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;   // bqkv / b1 hold the FOLDED biases (W beta + b)
   float *wg_qkv = nullptr, *wg_1 = nullptr;                             // row sums of the folded weights W . gamma
   void *kc = nullptr, *vc = nullptr;   // KV cache of this layer: WT [max_seqs][H][S_max][hd]
@@ -105,7 +106,10 @@ struct vc_engine {
   // round 4: 0.4 us no effect, 0.8 us +1.7 %, 1.7 us +2.8 % per step - profiles/r04c_bench_apf_delay*.json.log; not carried)
   // FFN-up KB < 0 (default): HALF of every tile - 32 KB at d = 2048 (re-swept in round 4 with the hint on every matrix: 24 / 40 / 48 /
   // 64 KB cost +1.0 / +1.2 / +3.0 / +4.0 % against 32), 16 KB at d = 1024 (giga330M: 16 against 32 KB -4.2 % +- 0.03; r04e_bench_*apf*)
-  int apf_z = 8, apf_wo_kb = 0, apf_w1_kb = -1;
+  // Round 5: default OFF.  With the one-row kernels of this round (finished rows, trimmed prologues, scalar batch in the attention
+  // launch) the role costs more than it saves on every box measured: +1.85 % +- 0.004 (slices interleaved), +0.87 % +- 0.3 / +0.36 % at
+  // giga330M / 0.0 % editing (slices behind the splits) in in-process A/Bs, profiles/r05b_*, r05c_*.  The option stays.
+  int apf_z = 0, apf_wo_kb = 0, apf_w1_kb = -1;
   int apf_scale = 4;                    // quarters of the configured length in force (decode_loop: per graph, by context length)
   // option "attn_pf_cut" = "p1,p2[,p0]": half the length from cached position p1, none from p2, none below p0; 0,0 = never cut.
   // Measured per context range on a box where the uncut role gained only 0.2 % over a whole utterance (profiles/r04h_*): positions
@@ -141,7 +145,13 @@ struct vc_engine {
   // option "gemm_pf" = "blocks,f2_kb,qkv_kb" (round 5): prefetch roles hosted by the one-row GEMM launches that leave HBM idle - the
   // out-projection launch pulls the first f2_kb KB of every FFN down-projection tile, the FFN-up launch the first qkv_kb KB of the NEXT
   // layer's QKV tiles (d <= 1024 models: every launch is latency); `blocks` extra workgroups per K slice.  0 = off.
-  int gpf_blocks = 0, gpf_f2_kb = 0, gpf_qkv_kb = 0;
+  // Measured with the attention launch's role off (profiles/r05c_ab_gemm_pf_attention_role_off_830M.log, r05c_*330M*): 128 workgroups x
+  // 16 KB of every FFN-down tile -0.57 % +- 0.06 at giga830M (32 KB: 0.0), giga330M 32 KB -0.84 % +- 0.06 / 16 KB -0.53 %; the QKV
+  // matrix under the FFN-up launch LOSES (+3.8 % at giga330M).  f2_kb < 0 = by width: 16 KB at d >= 2048, 32 KB below.
+  int gpf_blocks = 128, gpf_f2_kb = -1, gpf_qkv_kb = 0;
+  // option "qkv_p8" (round 5): one-row steps behind a finished row (fr_one) run the QKV projection on 8-channel tiles with two k-tiles
+  // per MFMA fragment (row_gemm_fr1_k<PRO_LN, EPI_QKV>: every lane's 16 bytes are weights) instead of 12-channel tiles
+  int qkv_p8 = 1;
   // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
   // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
   int ln_trim = 1;
@@ -316,7 +326,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
 // giga830M -2.13 % +- 0.01 per step; giga330M, 128 workgroups on 256 CUs, +1.5 % +- 0.09); 2: wherever the kernel can run
 inline bool fd_one(const vc_engine* e, int rows) {
   if (rows != 1 || e->fr_one == 0 || (e->fr_one == 1 && e->d / VC_TH_RES < 256)) return false;
-  return !e->layers.empty() && e->layers[0].W28 != nullptr && vc_gemm_fr1_ok(e->d, 4 * e->d, e->dtype) != 0;
+  return !e->layers.empty() && e->layers[0].W28 != nullptr && vc_gemm_fr1_ok(e->d, 4 * e->d, e->dtype, VC_FR_WAVES) != 0;
 }
 
 inline int attn_nt_for(const vc_engine* e, int rows) { return e->attn_nt == 1 || (e->attn_nt == 2 && rows >= 2); }
@@ -446,7 +456,11 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.has_prev_bias = (l == 0 || fd) ? 0 : 1;
       g.wg = ly.wg_qkv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
+      if (fd && e->qkv_p8 && ly.Wqkv8 && !split_ln) {
+        // the row entering the layer is finished (layer 0: the sampler's dec_h row): 8-channel tiles, two k-tiles per fragment
+        g.Wp = ly.Wqkv8;
+        HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_LN, EPI_QKV, s));
+      } else if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
         if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_qkv.n_tiles % 8 == 0) {
           const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * VC_TH_QKV;
@@ -491,15 +505,16 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wo; nt_bit(e, g, NT_O);
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
-      if (e->gpf_blocks > 0 && e->gpf_f2_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr) {
+      const int f2_kb = e->gpf_f2_kb < 0 ? (d >= 2048 ? 16 : 32) : e->gpf_f2_kb;
+      if (e->gpf_blocks > 0 && f2_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr) {
         // prefetch role: the head of every FFN down-projection tile of this layer, as the launch after next will read them
         const int KT2 = 4 * d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16);
         if (fd) {     // row_gemm_fr1_k: workgroup x reads 8-channel tile x
           const int tile_b = KT2 * 4 * VC_TH_RES * 16;
-          g.pf = PfSeg{(const char*)ly.W28, d / VC_TH_RES, tile_b, std::min(tile_b, e->gpf_f2_kb * 1024), 1};
+          g.pf = PfSeg{(const char*)ly.W28, d / VC_TH_RES, tile_b, std::min(tile_b, f2_kb * 1024), 1};
         } else {      // slab form: workgroup (x, y) reads the y-th K slice of 16-channel tile x
           const int ks = e->p_f2.ksplit, sub_b = KT2 * 64 * 16 / ks;
-          g.pf = PfSeg{(const char*)ly.W2, e->p_f2.n_tiles * ks, sub_b, std::min(sub_b, e->gpf_f2_kb * 1024 / ks), ks};
+          g.pf = PfSeg{(const char*)ly.W2, e->p_f2.n_tiles * ks, sub_b, std::min(sub_b, f2_kb * 1024 / ks), ks};
         }
         g.pf_blocks = e->gpf_blocks;
       }
@@ -537,7 +552,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.W28; g.bias = ly.b2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.h_in = e->hA; g.h_out = e->hB;
-      HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, s));
+      HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_PLAIN, EPI_RES, s));
     } else {  // W2 a -> partial slabs, folded into the next LayerNorm prologue together with b2
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W2; nt_bit(e, g, NT_F2);
@@ -964,8 +979,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     else e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
   } else if (name == "gemm_pf") {
     e->gpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
-    if (n >= 2) e->gpf_f2_kb = std::max(0, v1);
+    if (n >= 2) e->gpf_f2_kb = v1;                      // < 0: by width
     if (n >= 3) e->gpf_qkv_kb = std::max(0, v2);
+  } else if (name == "qkv_p8") { e->qkv_p8 = v0 ? 1 : 0;
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
@@ -979,10 +995,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|lpf=%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d|ta=%d,%d|r1=%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|lpf=%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->gpf_blocks, e->gpf_f2_kb, e->gpf_qkv_kb);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_qkv_kb);
   e->opt_state = buf;
 }
 
@@ -1154,6 +1170,12 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     if (want_fr8) {
       if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo8, VC_TH_RES))) return rc;
       if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W28, VC_TH_RES))) return rc;
+      // (the one-row paired QKV kernel reads the folded matrix in 8-channel tiles: only where its form can run, i.e. behind fr_one)
+      if (vc_gemm_fr1_ok(3 * d, d, e->dtype, 4)) {
+        const RawTensor* tg1;
+        if ((rc = need(e, pre + "norm1.weight", {d}, &tg1))) return rc;
+        if ((rc = pack_matrix(e, pre + "self_attn.in_proj_weight", 3 * d, d, &ly.Wqkv8, VC_TH_RES, tg1->dev))) return rc;
+      }
     }
     if ((rc = keep_vec(e, pre + "linear2.bias", d, &ly.b2))) return rc;
     const size_t cache_bytes = (size_t)e->B_max * e->H * e->S_max * e->hd * e->esz;
@@ -1269,7 +1291,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1891,7 +1913,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     } else if (w == "ffn2" && fd_one(e, n_rows)) {     // one row, finished by the producer (forward_rows, option fr_one)
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W28; g.bias = ly.b2; g.x_in = e->act; g.x_ld = 4 * d; g.h_in = e->hA; g.h_out = e->hB;
-      HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, s));
+      HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_PLAIN, EPI_RES, s));
     } else if (w == "ffn2") {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W2; nt_bit(e, g, NT_F2); g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts;
@@ -1901,6 +1923,11 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.h_in = e->hB; g.h_out = e->hA; g.parts = e->parts; g.n_parts = e->p_f2.ksplit;
       g.prev_bias = ly.b2; g.has_prev_bias = 1; g.wg = ly.wg_qkv; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       if (fd_one(e, n_rows)) { g.h_out = nullptr; g.n_parts = 0; g.has_prev_bias = 0; }       // the row in hB is finished
+      if (fd_one(e, n_rows) && e->qkv_p8 && ly.Wqkv8 && !split_ln) {                          // ... and the step runs the paired 8-channel form
+        g.Wp = ly.Wqkv8;
+        HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_LN, EPI_QKV, s));
+        return VC_OK;
+      }
       if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s)); }
       else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
     } else if (w == "oproj") {

@@ -922,11 +922,18 @@ hipError_t vc_launch_gemm_fr(const GemmArgs& a0, int dtype, int pro, hipStream_t
 // 8 channels over the whole K (d/8 workgroups), its 8 waves stream K/8 each in one burst, the row of X is staged once in LDS,
 // and the epilogue adds residual + bias and writes the finished channels: the consumer's LayerNorm prologue reads ONE 8 KB row.
 // NPW = fragment pairs per wave (K / KW / 16, rounded up; pairs beyond the matrix are zeroed).
-// EXACT: the matrix has exactly 8 NPW fragment pairs per tile (every real model width): no clamped addresses, no zeroed fragments.
-template <typename WT, int NPW, bool EXACT>
-__global__ __launch_bounds__(64 * VC_FR_WAVES) void row_gemm_fr1_k(const GemmArgs a) {
+// EXACT: the matrix has exactly NW * NPW fragment pairs per tile (every real model width): no clamped addresses, no zeroed fragments.
+// NW waves per workgroup, each streaming NPW consecutive fragment pairs (KB) in one burst.
+// PRO_PLAIN / EPI_RES (the FFN down-projection): X = a.x_in (WT [K]), h_out = h_in + bias + W x.
+// PRO_LN / EPI_QKV (the QKV projection behind a FINISHED row, option "qkv_p8"): X = the row of h_in, centred and rounded (LayerNorm
+//   fold, rows_gemm_k above), epilogue = rstd / mean correction + folded bias, q to a buffer, K / V into the cache.  The 12-channel
+//   tiles of rows_gemm_k leave a quarter of every fragment's lanes idle: the QKV launch pays the vector-memory instructions of a
+//   33.6 MB stream for 25.2 MB; here every lane's 16 bytes are weights (3d / 8 workgroups: three per CU at d = 2048).
+template <typename WT, int NPW, bool EXACT, int NW, int PRO, int EPI>
+__global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
   using T = WTr<WT>;
-  constexpr int NW = VC_FR_WAVES, NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;   // SPT = 16-byte units per (tile, k-tile) = 32
+  static_assert((PRO == PRO_PLAIN && EPI == EPI_RES) || (PRO == PRO_LN && EPI == EPI_QKV), "one-row paired forms");
+  constexpr int NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;   // SPT = 16-byte units per (tile, k-tile) = 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
   if (blockIdx.y != 0) {     // prefetch role, as in rows_gemm_k: a second layer of workgroups, decided from the workgroup id alone
     if (blockIdx.x < (unsigned)a.pf_blocks) vc_prefetch_tiles(&a.pf, 1, blockIdx.x, 0u, (unsigned)a.pf_blocks);
@@ -939,21 +946,35 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void row_gemm_fr1_k(const GemmArg
   const int npairs = a.KT >> 1;                    // KT even (host contract)
   char* xl = smem;                                 // the row: K elements of WT
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)K * sizeof(WT));     // [NW][4] partial quads
+  float* stat = reinterpret_cast<float*>(red + NW * 4);                     // PRO_LN: [NW] row sums, then [NW][2] statistics of the rounded row
   const int active = *a.n_active;
   const int m = lane & 15, kg = lane >> 4;
-  // epilogue operands first (a wave's loads return in order): residual and bias of channels 4 t .. 4 t + 3 for the two finishing threads
+  // epilogue operands first (a wave's loads return in order): for the two finishing threads, channels 4 t .. 4 t + 3 of the tile
   const int nfin = nt * TH + 4 * (tid & 1);
-  const float4 eres = *reinterpret_cast<const float4*>(a.h_in + nfin);
+  float4 eres = make_float4(0.f, 0.f, 0.f, 0.f), ewg = eres;
   const float4 eb = *reinterpret_cast<const float4*>(a.bias + nfin);
-  // X row as 16-byte units: a fragment pair covers 64 of them, so a thread carries NPW / 8 (at least one)
-  constexpr int NXU = NPW >= 8 ? NPW / 8 : 1;
-  const int units = K * (int)sizeof(WT) / 16;
-  const char* src = reinterpret_cast<const char*>(a.x_in);
+  int epos = -1, eseq = 0;
+  if constexpr (EPI == EPI_RES) eres = *reinterpret_cast<const float4*>(a.h_in + nfin);
+  else { ewg = *reinterpret_cast<const float4*>(a.wg + nfin); epos = a.row_pos[0]; eseq = a.row_seq[0]; }
+  // the operand row: PLAIN - 16-byte units of X (a fragment pair covers 64 of them); LN - float4 columns of the residual row
+  // (a fragment pair = two k-tiles = 128 bytes of WT = 8 units; K = NW * NPW pairs when EXACT)
+  constexpr int NXU = (NPW * 8 + 63) / 64;                               // 16-byte units of the WT row per thread
+  constexpr int NXQ = ((sizeof(WT) == 2 ? 16 : 8) * NPW + 63) / 64;      // float4 columns of the fp32 row per thread
+  static_assert(NXU <= 4 && (PRO != PRO_LN || NXQ <= 4), "the operand row fits four staging registers per thread");
+  const int units = K * (int)sizeof(WT) / 16, nq = K >> 2;
   // (explicit scalars: an indexed array is demoted to scratch memory by the compiler)
   uint4 xu0 = make_uint4(0u, 0u, 0u, 0u), xu1 = xu0, xu2 = xu0, xu3 = xu0;
+  float4 xq0 = make_float4(0.f, 0.f, 0.f, 0.f), xq1 = xq0, xq2 = xq0, xq3 = xq0;
+  if constexpr (PRO == PRO_PLAIN) {
+    const char* src = reinterpret_cast<const char*>(a.x_in);
 #define VC_FR1_XLOAD(j, dst) if constexpr (NXU > (j)) dst = *reinterpret_cast<const uint4*>(src + (size_t)min(tid + (j) * NTHR, units - 1) * 16);
-  VC_FR1_XLOAD(0, xu0) VC_FR1_XLOAD(1, xu1) VC_FR1_XLOAD(2, xu2) VC_FR1_XLOAD(3, xu3)
+    VC_FR1_XLOAD(0, xu0) VC_FR1_XLOAD(1, xu1) VC_FR1_XLOAD(2, xu2) VC_FR1_XLOAD(3, xu3)
 #undef VC_FR1_XLOAD
+  } else {
+#define VC_FR1_QLOAD(j, dst) if constexpr (NXQ > (j)) dst = *reinterpret_cast<const float4*>(a.h_in + (size_t)min(tid + (j) * NTHR, nq - 1) * 4);
+    VC_FR1_QLOAD(0, xq0) VC_FR1_QLOAD(1, xq1) VC_FR1_QLOAD(2, xq2) VC_FR1_QLOAD(3, xq3)
+#undef VC_FR1_QLOAD
+  }
   // the wave's whole share of the weights in one burst: pair p of wave w = fragment pair (NPW w + p)
   const int wunit = (m >> 3) * SPT + kg * TH + (m & 7);
   const uint4* wbase = a.Wp + ((long)nt * a.KT + 2 * NPW * wave) * SPT;    // wave-uniform: a wave streams NPW consecutive KB
@@ -965,9 +986,40 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void row_gemm_fr1_k(const GemmArg
   }
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
+  if constexpr (PRO == PRO_PLAIN) {
 #define VC_FR1_XPARK(j, val) if constexpr (NXU > (j)) { if (tid + (j) * NTHR < units) *reinterpret_cast<uint4*>(xl + (size_t)(tid + (j) * NTHR) * 16) = val; }
-  VC_FR1_XPARK(0, xu0) VC_FR1_XPARK(1, xu1) VC_FR1_XPARK(2, xu2) VC_FR1_XPARK(3, xu3)
+    VC_FR1_XPARK(0, xu0) VC_FR1_XPARK(1, xu1) VC_FR1_XPARK(2, xu2) VC_FR1_XPARK(3, xu3)
 #undef VC_FR1_XPARK
+  } else {
+    // LayerNorm fold of the finished row (see the top of this file): centred BEFORE it is rounded, statistics of the rounded values
+    float t = 0.f;
+#define VC_FR1_QSUM(j, v) if constexpr (NXQ > (j)) { if (tid + (j) * NTHR < nq) t += (v.x + v.y) + (v.z + v.w); }
+    VC_FR1_QSUM(0, xq0) VC_FR1_QSUM(1, xq1) VC_FR1_QSUM(2, xq2) VC_FR1_QSUM(3, xq3)
+#undef VC_FR1_QSUM
+    t = wave_sum(t);
+    if (lane == 0) stat[wave] = t;
+    __syncthreads();
+    float mu = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) mu += stat[w];
+    mu *= 1.0f / (float)K;
+    float s1 = 0.f, s2 = 0.f;
+    WT* xr = reinterpret_cast<WT*>(xl);
+#define VC_FR1_QPARK(j, v)                                                                     \
+    if constexpr (NXQ > (j)) {                                                                 \
+      if (tid + (j) * NTHR < nq) {                                                             \
+        const f32x4 y_ = {v.x - mu, v.y - mu, v.z - mu, v.w - mu};                             \
+        const f32x4 q_ = store4r(xr + (size_t)(tid + (j) * NTHR) * 4, y_);                     \
+        s1 += (q_[0] + q_[1]) + (q_[2] + q_[3]);                                               \
+        s2 += (q_[0] * q_[0] + q_[1] * q_[1]) + (q_[2] * q_[2] + q_[3] * q_[3]);               \
+      }                                                                                        \
+    }
+    VC_FR1_QPARK(0, xq0) VC_FR1_QPARK(1, xq1) VC_FR1_QPARK(2, xq2) VC_FR1_QPARK(3, xq3)
+#undef VC_FR1_QPARK
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    if (lane == 0) { stat[NW + 2 * wave] = s1; stat[NW + 2 * wave + 1] = s2; }
+  }
   __syncthreads();
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // B operand: column m = 0 reads x over k-tile 2 gp, column 1 over k-tile 2 gp + 1 (the other columns repeat these: cross terms)
@@ -989,42 +1041,67 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void row_gemm_fr1_k(const GemmArg
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int w = 0; w < NW; ++w) sum += red[w * 4 + tid] + red[w * 4 + tid + 2];
-    const f32x4 o = {eres.x + eb.x + sum[0], eres.y + eb.y + sum[1], eres.z + eb.z + sum[2], eres.w + eb.w + sum[3]};
-    store4(a.h_out + nfin, o);
+    if constexpr (EPI == EPI_RES) {
+      const f32x4 o = {eres.x + eb.x + sum[0], eres.y + eb.y + sum[1], eres.z + eb.z + sum[2], eres.w + eb.w + sum[3]};
+      store4(a.h_out + nfin, o);
+    } else {
+      float q1 = 0.f, q2 = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) { q1 += stat[NW + 2 * w]; q2 += stat[NW + 2 * w + 1]; }
+      const float inv_d = 1.0f / (float)K;
+      const float mean = q1 * inv_d;
+      const float var = fmaxf(q2 * inv_d - mean * mean, 0.f);
+      const float rstd = 1.0f / sqrtf(var + 1e-5f);      // eps 1e-5 (transformer.py:30)
+      sum[0] = rstd * (sum[0] - mean * ewg.x); sum[1] = rstd * (sum[1] - mean * ewg.y);
+      sum[2] = rstd * (sum[2] - mean * ewg.z); sum[3] = rstd * (sum[3] - mean * ewg.w);
+      gemm_epilogue<WT, EPI_QKV>(a, sum, 0, nfin, 0, 0, 1, eb, epos, eseq);
+    }
   }
 }
-template <typename WT, int NPW>
+template <typename WT, int NPW, int NW, int PRO, int EPI>
 static hipError_t launch_fr1_n(const GemmArgs& a, hipStream_t s) {
-  auto kern = (a.KT == 2 * VC_FR_WAVES * NPW) ? row_gemm_fr1_k<WT, NPW, true> : row_gemm_fr1_k<WT, NPW, false>;
-  const size_t lds = (size_t)a.K * sizeof(WT) + (size_t)VC_FR_WAVES * 4 * sizeof(f32x4);
+  auto kern = (a.KT == 2 * NW * NPW) ? row_gemm_fr1_k<WT, NPW, true, NW, PRO, EPI> : row_gemm_fr1_k<WT, NPW, false, NW, PRO, EPI>;
+  const size_t lds = (size_t)a.K * sizeof(WT) + (size_t)NW * 4 * sizeof(f32x4) + (size_t)NW * 3 * sizeof(float);
   ++vc_launch_counts[VC_LC_ROW_GEMM_FR1];
   GemmArgs b = a;
   if (b.pf_blocks <= 0 || b.pf.len <= 0 || a.n_tiles % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
   b.pf_blocks = std::min(b.pf_blocks, a.n_tiles);
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles, b.pf_blocks > 0 ? 2 : 1), dim3(64 * VC_FR_WAVES), lds, s, b);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles, b.pf_blocks > 0 ? 2 : 1), dim3(64 * NW), lds, s, b);
   return hipGetLastError();
 }
-// 1 when the one-row finished-row producer can take an [N x K] matrix in this dtype (the engine's planning and the launcher agree on it)
-int vc_gemm_fr1_ok(int N, int K, int dtype) {
+// 1 when the one-row paired kernel can take an [N x K] matrix in this dtype with `nw` waves per workgroup (the engine's planning and
+// the launcher agree on it)
+int vc_gemm_fr1_ok(int N, int K, int dtype, int nw) {
   const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16, esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
-  if (N % VC_TH_RES != 0 || K % (2 * KW) != 0) return 0;
-  const int npairs = K / KW / 2, npw = (npairs + VC_FR_WAVES - 1) / VC_FR_WAVES;
-  if (npw > 32 || (long)K * esz > 64L * 1024) return 0;      // a wave's fragments fit its registers (the row then fits 4 staging units per thread)
+  if (N % VC_TH_RES != 0 || K % (2 * KW) != 0 || (nw != 4 && nw != 8)) return 0;
+  const int npairs = K / KW / 2, npw = (npairs + nw - 1) / nw;
+  int cap = 1;
+  while (cap < npw) cap <<= 1;
+  if (cap > (nw == 4 ? 16 : 32) || (long)K * esz > 64L * 1024) return 0;      // a wave's fragments fit its registers; the row <= 4 staging registers per thread
   return 1;
 }
-// h_out[n] = h_in[n] + bias[n] + sum_k W[n][k] x[k] for ONE row; a.Wp = the 8-channel-tile image, a.x_in = the row (WT [K])
-hipError_t vc_launch_gemm_fr1(const GemmArgs& a0, int dtype, hipStream_t s) {
-  if (!vc_gemm_fr1_ok(a0.N, a0.K, dtype) || a0.n_rows != 1) return hipErrorInvalidValue;
+// ONE row.  pro / epi = PRO_PLAIN / EPI_RES: h_out[n] = h_in[n] + bias[n] + sum_k W[n][k] x[k] (a.x_in = the row, WT [K]; 8 waves);
+// PRO_LN / EPI_QKV: the QKV projection of the finished row a.h_in (LayerNorm fold; 4 waves).  a.Wp = the 8-channel-tile image.
+hipError_t vc_launch_gemm_fr1(const GemmArgs& a0, int dtype, int pro, int epi, hipStream_t s) {
+  const bool qkv = pro == PRO_LN && epi == EPI_QKV;
+  if (!qkv && !(pro == PRO_PLAIN && epi == EPI_RES)) return hipErrorInvalidValue;
+  const int nw = qkv ? 4 : VC_FR_WAVES;
+  if (!vc_gemm_fr1_ok(a0.N, a0.K, dtype, nw) || a0.n_rows != 1) return hipErrorInvalidValue;
   GemmArgs a = a0;
   const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16;
   a.n_tiles = a.N / VC_TH_RES;
   a.KT = a.K / KW;
-  const int npairs = a.KT / 2, npw = (npairs + VC_FR_WAVES - 1) / VC_FR_WAVES;
+  const int npairs = a.KT / 2, npw = (npairs + nw - 1) / nw;
   int cap = 1;
   while (cap < npw) cap <<= 1;
-#define VC_FR1_CASE(P_) case P_: return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_>(a, s) : launch_fr1_n<float, P_>(a, s);
+#define VC_FR1_CASE(P_) case P_:                                                                                        \
+    if (qkv) return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, 4, PRO_LN, EPI_QKV>(a, s) : launch_fr1_n<float, P_, 4, PRO_LN, EPI_QKV>(a, s);   \
+    return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s) : launch_fr1_n<float, P_, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s);
   switch (cap) {
-    VC_FR1_CASE(1) VC_FR1_CASE(2) VC_FR1_CASE(4) VC_FR1_CASE(8) VC_FR1_CASE(16) VC_FR1_CASE(32)
+    VC_FR1_CASE(1) VC_FR1_CASE(2) VC_FR1_CASE(4) VC_FR1_CASE(8) VC_FR1_CASE(16)
+    case 32:
+      if (qkv) return hipErrorInvalidValue;      // (K <= 2048 there: at most 16 pairs per wave of four)
+      return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, 32, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s) : launch_fr1_n<float, 32, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s);
     default: return hipErrorInvalidValue;
   }
 #undef VC_FR1_CASE

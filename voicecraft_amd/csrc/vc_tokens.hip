@@ -718,10 +718,10 @@ __global__ void box_probe_init_k(unsigned* ring, unsigned n_mask, unsigned strid
   const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n_mask) ring[(size_t)i * 16] = ((i * 5u + stride) & n_mask);      // full period: multiplier = 1 mod 4, odd increment; one entry per 64 B
 }
-__global__ void box_probe_k(const unsigned* __restrict__ ring, int hops, long long* out) {
+__global__ void box_probe_k(const unsigned* __restrict__ ring, unsigned start, int warm, int hops, long long* out) {
   if (threadIdx.x != 0) return;
-  unsigned p = 0;
-  for (int i = 0; i < 64; ++i) p = ring[(size_t)p * 16];                     // (lands somewhere in the ring: warms nothing but the TLB entry of the start)
+  unsigned p = start;
+  for (int i = 0; i < warm; ++i) p = ring[(size_t)p * 16];                   // untimed: a whole lap of a small ring (cache-resident walk), nothing of a large one
   const long long w0 = wall_clock64(), c0 = clock64();
   for (int i = 0; i < hops; ++i) p = __builtin_nontemporal_load(ring + (size_t)p * 16);
   const long long c1 = clock64(), w1 = wall_clock64();
@@ -740,8 +740,12 @@ extern "C" int vc_box_probe(long long bytes, int hops, float res[2], void* strea
   hipLaunchKernelGGL(box_probe_init_k, dim3((n + 255) / 256), dim3(256), 0, s, ring, n - 1, 12345u | 1u);
   long long h[3] = {0, 0, 0};
   hipError_t e = hipSuccess;
-  for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {       // the second walk is the one reported
-    hipLaunchKernelGGL(box_probe_k, dim3(1), dim3(64), 0, s, ring, hops, out);
+  // a ring of up to 4 MB is walked once round untimed (every line then sits in the probing XCD's L2: the timed hops are cache hits);
+  // a larger one is entered at a different place in each of the two launches (the first warms code and TLB, the second - reported -
+  // touches lines nothing has read since the init kernel wrote them: memory latency)
+  const bool small = (long long)n * 64 <= (4LL << 20);
+  for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
+    hipLaunchKernelGGL(box_probe_k, dim3(1), dim3(64), 0, s, ring, small ? 0u : (rep ? n / 2 + 77u : 0u), small ? (int)n : 0, hops, out);
     e = hipMemcpyAsync(h, out, sizeof h, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
   }
