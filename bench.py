@@ -95,8 +95,10 @@ def in_situ(kernel, args):
         if j.get("config") != want:
             return None
         k = j["kernels"][kernel]
-        return {"kernel": k["name"], "avg_us": k["avg_us"], "calls": k["calls"], "frac": round(k["algorithmic_bytes"] / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
-                "source": j.get("source")}
+        out = {"kernel": k["name"], "avg_us": k["avg_us"], "calls": k["calls"], "source": j.get("source")}
+        if k.get("algorithmic_bytes"):
+            out["frac"] = round(k["algorithmic_bytes"] / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        return out
     except Exception:
         return None
 
@@ -621,28 +623,40 @@ def main():
         frames = tokens / K
         value = tokens / dt
         step_bytes = step_alg_bytes(a, args.dtype, B, wl.s_mean())      # weights (once per step) + KV read + KV write of each of the B sequences
-        # dominant kernel: the FFN down-projection rows-GEMM (plain prologue, split-K partial slabs) - the largest share of
-        # kernel time in every round-3 profile once the up-projection's first half is prefetched under the attention launch
-        # (profiles/r03g_*: 22.4 % against 17.9 %); timed in isolation here, so in agreement with its in-situ rocprof average
+        # dominant kernel = the largest share of a step's kernel time.  Every decode kernel runs once per layer, so it is the one with the
+        # longest launch: each is timed in isolation here (layers rotate: cold caches), the longest becomes the `roofline` object - the
+        # FFN up-projection since round 5 (profiles/r05d_rocprof_kernel_stats.txt: 23.4 % against 20.4 % for the down-projection, which
+        # was the dominant one through round 4), and `in_situ` carries the committed rocprof average of the same kernel
         mb_rows = min(B, 16)       # the kernel microbenchmarks drive the <=16-row decode kernels
         c0 = eng.launch_counts()
-        k_ms, k_bytes = eng.bench_kernel("ffn2", n_rows=mb_rows, iters=64)
-        fr1_form = eng.launch_counts()["row_gemm_fr1"] > c0["row_gemm_fr1"]      # which form the microbenchmark (= the step) really launched
         step_ms, _ = eng.bench_kernel("step", n_rows=mb_rows, iters=8)
-        kernels = {}
+        kernels, kraw = {}, {}
         for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
             ms_, by_ = eng.bench_kernel(kn, n_rows=mb_rows, iters=64)
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
-        fr_form = 2 <= mb_rows <= 16 and "|fr=0," not in eng.options()       # several-row steps: the finished-row producer is what runs
-        roof = {"bound": "hbm", "kernel": (("rows_gemm_fr_k<plain> (FFN down-projection, finished rows: 8-channel tiles over the whole K)" +
-                                            ("" if B <= 16 else f"; microbenchmarked at 16 rows - this run's {B}-row steps use the wide-decode kernel rows_gemm_mt_k")) if fr_form
-                                           else "row_gemm_fr1_k<plain, residual> (FFN down-projection of a one-row step, finished row: 8-channel tiles over the whole K, two k-tiles per MFMA fragment)" if fr1_form
-                                           else "rows_gemm_k<plain,split-K slabs> (FFN down-projection)"),
+            kraw[kn] = (ms_, by_)
+        c1 = eng.launch_counts()
+        fr1_form = c1["row_gemm_fr1"] > c0["row_gemm_fr1"]      # which forms the microbenchmarks (= the step) really launched
+        fr_form = c1["rows_gemm_fr"] > c0["rows_gemm_fr"]
+        dom = max(("ffn1", "ffn2", "qkv"), key=lambda k: kraw[k][0])
+        k_ms, k_bytes = kraw[dom]
+        what = {"ffn1": "FFN up-projection", "ffn2": "FFN down-projection", "qkv": "QKV projection"}[dom]
+        if fr_form:
+            form = {"ffn2": "rows_gemm_fr_k<plain> (finished rows: 8-channel tiles over the whole K)", "ffn1": "rows_gemm_k<LayerNorm fold of finished rows, ReLU>",
+                    "qkv": "rows_gemm_k<LayerNorm fold of finished rows, QKV>"}[dom] + ("" if B <= 16 else f"; microbenchmarked at 16 rows - this run's {B}-row steps use the wide-decode kernel rows_gemm_mt_k")
+        elif fr1_form:
+            form = {"ffn2": "row_gemm_fr1_k<plain, residual> (finished row: 8-channel tiles over the whole K, two k-tiles per MFMA fragment)",
+                    "ffn1": "rows_gemm_k<LayerNorm fold of h + 2 slabs, ReLU> (16-channel tiles)",
+                    "qkv": "row_gemm_fr1_k<LayerNorm fold, QKV> (8-channel tiles, two k-tiles per MFMA fragment)"}[dom]
+        else:
+            form = {"ffn2": "rows_gemm_k<plain, split-K slabs>", "ffn1": "rows_gemm_k<LayerNorm fold, ReLU>", "qkv": "rows_gemm_k<LayerNorm fold, QKV>"}[dom]
+        roof = {"bound": "hbm", "kernel": f"{form} ({what}; the longest of the step's per-layer launches)",
                 "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic("ffn2", args),
+                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args),
                 "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2),
                 "measured": "isolated: the kernel back to back over rotating layers, HIP events on the launch stream (vc_bench_kernel)",
-                "in_situ": in_situ("ffn2", args)}
+                "in_situ": in_situ(dom, args),
+                "per_layer_launches": {k: {"isolated_us": kernels[k]["avg_us"], "in_situ": in_situ(k, args)} for k in ("qkv", "attn", "oproj", "ffn1", "ffn2")}}
         # the prefill is GEMM-shaped: MFMA rooflines of its widest block GEMM (FFN up-projection) at the run's own pass
         # size and at a full 512-row pass, and of the MFMA tile attention
         own_rows = min(512, B * ((args.lx + (args.prompt_frames + 1 if not edit else args.prompt_frames - (span[1] - span[0]) + 2 * K + 4) + 15) // 16 * 16))
