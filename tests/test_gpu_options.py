@@ -46,18 +46,23 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256, use_graph=False)
     L = a.num_decoder_layers
     got = {}
-    for mode in ("on", "on1", "off"):              # on: two weight tiles per consumer workgroup (the default); on1: one
+    for mode in ("on", "on1", "unpaired", "off"):   # on: two weight tiles per consumer workgroup (the default); on1: one; unpaired: round 4's FFN-down producer
         eng.set_option("finished_rows", 0 if mode == "off" else 16)
         eng.set_option("lnw_tiles", 1 if mode == "on1" else 2)
+        eng.set_option("fr_pair", 0 if mode == "unpaired" else 1)
         assert ("|fr=0," if mode == "off" else "|fr=16,") in eng.options()
         c0 = eng.launch_counts()
         outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3,
                                            _forced=forced, _logit_steps=n)
         c = _delta(eng.launch_counts(), c0)
-        if mode != "off":
-            assert c["rows_gemm_fr"] >= 2 * L * (n - 1), c           # (the first of the n samples comes from the prefill's logits)
+        if mode == "unpaired":
+            assert c["rows_gemm_frp"] == 0 and c["rows_gemm_fr"] >= 2 * L * (n - 1), c
+        elif mode != "off":
+            assert c["rows_gemm_fr"] + c["rows_gemm_frp"] >= 2 * L * (n - 1), c           # (the first of the n samples comes from the prefill's logits)
+            if B <= 8 and mode != "unpaired":      # round 5: the FFN down-projection of 2..8 rows in the paired form (two k-tiles per MFMA fragment)
+                assert c["rows_gemm_frp"] >= L * (n - 1), c
         else:
-            assert c["rows_gemm_fr"] == 0 and (B < 3 or c["ln_rows"] >= 2 * L * (n - 1)), c
+            assert c["rows_gemm_fr"] + c["rows_gemm_frp"] == 0 and (B < 3 or c["ln_rows"] >= 2 * L * (n - 1)), c
         lg = lg.cpu().numpy()
         worst = 0.0
         for b, tr in enumerate(traces):
@@ -68,6 +73,7 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
         got[mode] = lg
     assert np.abs(got["on"] - got["off"])[np.abs(got["off"]) < 1e3].max() < 0.25      # two roundings of the same numbers
     assert np.array_equal(got["on"], got["on1"])               # one or two tiles per workgroup: the same sums in the same order
+    assert np.abs(got["on"] - got["unpaired"])[np.abs(got["off"]) < 1e3].max() < 0.25    # paired / unpaired producer: another order of the same sums
 
 
 @pytest.mark.parametrize("preset,B", [("tiny_h16", 2), ("tiny_h16", 4), ("tiny128", 3), ("tiny_h16", 11), ("tiny128", 16)])
@@ -83,7 +89,8 @@ def test_finished_row_form_fp32_tokens_equal_the_oracle(preset, B):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=B, max_positions=256)
     c0 = eng.launch_counts()
     outs = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3)
-    assert _delta(eng.launch_counts(), c0)["rows_gemm_fr"] > 0
+    c = _delta(eng.launch_counts(), c0)
+    assert c["rows_gemm_fr"] + c["rows_gemm_frp"] > 0, c
     orc = VoiceCraftOracle(a, sd)
     for (xx, xl, yy), (res, gen) in zip(prompts, outs):
         want = orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3)[0].numpy()

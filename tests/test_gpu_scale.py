@@ -95,7 +95,7 @@ def test_c5_share_eight_utterances_one_prefill_stream(giga):
     assert c["big256"] == 3 * L and c["blk128_sbs"] == L and c["tile_attn"] == L, c   # one 1 920-row pass; the out-projection stays on 128 x 128
     assert c["rows_gemm"] > 0 and c["mt2"] + c["mt4"] == 0, c                 # 8-row decode: the rows-GEMM, not the wide form
     if "|fr=0," not in eng.options():                                           # (a VC_FINISHED_ROWS=0 preset runs the slab form: still correct, other census)
-        assert c["rows_gemm_fr"] > 0 and c["ln_rows"] == 2 * L, c             # ... in the finished-row form: the only LayerNorm launches are the prefill pass's
+        assert c["rows_gemm_fr"] + c["rows_gemm_frp"] > 0 and c["ln_rows"] == 2 * L, c             # ... in the finished-row form: the only LayerNorm launches are the prefill pass's
     lg = lg.cpu().numpy()
     worst = {}
     for u in range(B):
@@ -164,7 +164,7 @@ def test_c2_giga330M_16s_decode_bf16_and_fp32_first_step(giga330):
     c = delta(eng.launch_counts(), c0)
     L = a.num_decoder_layers
     assert gen.shape == (1, a.n_codebooks, 650)
-    assert c["rows_gemm"] >= 4 * L + 2 and c["rows_attn"] >= L and c["mt2"] + c["mt4"] + c["rows_gemm_fr"] == 0, c   # (a captured graph launches nothing the census sees)
+    assert c["rows_gemm"] >= 4 * L + 2 and c["rows_attn"] >= L and c["mt2"] + c["mt4"] + c["rows_gemm_fr"] + c["rows_gemm_frp"] == 0, c   # (a captured graph launches nothing the census sees)
     assert c["blk64"] + c["blk128_sbs"] == 4 * L and c["tile_attn"] == L, c           # the 240-row prefill pass
     rel = rel_l2(lg.cpu().numpy()[steps], want)
     assert rel.max() <= 2e-2, dict(zip(steps, rel.tolist()))
@@ -210,7 +210,7 @@ def test_giga330M_eight_utterances_and_a_576_row_editing_prefill(giga330):
     outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
                                        _forced=forced, _logit_steps=n)
     c = delta(eng.launch_counts(), c0)
-    assert ("|fr=0," in eng.options() or c["rows_gemm_fr"] >= 2 * L * (n - 1)) and c["tile_attn"] == L, c    # eager: every decode launch is counted
+    assert ("|fr=0," in eng.options() or c["rows_gemm_fr"] + c["rows_gemm_frp"] >= 2 * L * (n - 1)) and c["tile_attn"] == L, c    # eager: every decode launch is counted
     lg = lg.cpu().numpy()
     worst = {}
     for u in (0, 3, 7):
@@ -253,7 +253,7 @@ def test_twelve_row_decode_in_the_two_half_finished_row_form(giga):
                                        _forced=forced, _logit_steps=n)
     c = delta(eng.launch_counts(), c0)
     if "|fr=0," not in eng.options():
-        assert c["rows_gemm_fr"] >= 2 * a.num_decoder_layers * (n - 1) and c["mt2"] + c["mt4"] == 0, c
+        assert c["rows_gemm_fr"] + c["rows_gemm_frp"] >= 2 * a.num_decoder_layers * (n - 1) and c["mt2"] + c["mt4"] == 0, c
     lg = lg.cpu().numpy()
     steps = [0, 4, n - 1]
     worst = 0.0

@@ -102,6 +102,10 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
     for name, (body, _, vgpr) in pick(kern, "row_gemm_fr1_k<bf16_t, 8, true, 4, 0, 0>").items():
         assert len(re.findall(r"global_load_dwordx4[^\n]* nt", body)) == 8 and body.count("v_mfma_f32_16x16x32_bf16") == 8, name
         assert vgpr <= 128, (name, vgpr)
+    # ... and the FFN down-projection of 2..8-row steps: 16 full-KB fragments per wave instead of 32 half-filled ones
+    for name, (body, _, vgpr) in pick(kern, "rows_gemm_frp_k<bf16_t, 16, 8>").items():
+        assert len(re.findall(r"global_load_dwordx4[^\n]* nt", body)) == 16 and body.count("v_mfma_f32_16x16x32_bf16") == 16, name
+        assert vgpr <= 256, (name, vgpr)
     # the trimmed LayerNorm prologues: every slab the prologue does not request is two 16-byte loads per thread and row less
     n_plain = {}
     for np_ in ("0", "2", "4"):

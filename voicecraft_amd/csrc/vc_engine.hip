@@ -148,7 +148,10 @@ struct vc_engine {
   // Measured with the attention launch's role off (profiles/r05c_ab_gemm_pf_attention_role_off_830M.log, r05c_*330M*): 128 workgroups x
   // 16 KB of every FFN-down tile -0.57 % +- 0.06 at giga830M (32 KB: 0.0), giga330M 32 KB -0.84 % +- 0.06 / 16 KB -0.53 %; the QKV
   // matrix under the FFN-up launch LOSES (+3.8 % at giga330M).  f2_kb < 0 = by width: 16 KB at d >= 2048, 32 KB below.
-  int gpf_blocks = 128, gpf_f2_kb = -1, gpf_qkv_kb = 0;
+  int gpf_blocks = 128, gpf_f2_kb = -1, gpf_qkv_kb = 0, gpf_f1_kb = 0;      // (f1_kb: the head of the FFN-up tiles - the NEXT launch - under the out-projection too)
+  // option "fr_pair" (round 5): the FFN down-projection of 2..8-row steps with two k-tiles per MFMA fragment (rows_gemm_frp_k) instead
+  // of half-filled 8-channel fragments (rows_gemm_fr_k)
+  int fr_pair = 1;
   // option "qkv_p8" (round 5): one-row steps behind a finished row (fr_one) run the QKV projection on 8-channel tiles with two k-tiles
   // per MFMA fragment (row_gemm_fr1_k<PRO_LN, EPI_QKV>: every lane's 16 bytes are weights) instead of 12-channel tiles
   int qkv_p8 = 1;
@@ -417,7 +420,8 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.W28; g.bias = ly.b2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.h_in = e->hA; g.h_out = e->hB;
-      HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
+      if (e->fr_pair && vc_gemm_frp_ok(rs.n_rows, d, 4 * d, e->dtype)) HIPCHK(e, vc_launch_gemm_frp(g, e->dtype, s));      // 2..8 rows: two k-tiles per fragment
+      else HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
     }
   }
   return VC_OK;
@@ -459,6 +463,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       if (fd && e->qkv_p8 && ly.Wqkv8 && !split_ln) {
         // the row entering the layer is finished (layer 0: the sampler's dec_h row): 8-channel tiles, two k-tiles per fragment
         g.Wp = ly.Wqkv8;
+        g.mt = e->qkv_p8 == 2 ? 8 : 0;
         HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_LN, EPI_QKV, s));
       } else if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
@@ -516,6 +521,11 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
           const int ks = e->p_f2.ksplit, sub_b = KT2 * 64 * 16 / ks;
           g.pf = PfSeg{(const char*)ly.W2, e->p_f2.n_tiles * ks, sub_b, std::min(sub_b, f2_kb * 1024 / ks), ks};
         }
+        g.pf_blocks = e->gpf_blocks;
+      }
+      if (e->gpf_blocks > 0 && e->gpf_f1_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr) {
+        const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * 16;
+        g.pf2 = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->gpf_f1_kb * 1024), 1};
         g.pf_blocks = e->gpf_blocks;
       }
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
@@ -948,8 +958,8 @@ int check_err_flag(vc_engine* e, hipStream_t s) {
 
 // One option by name (vc_set_option, and the VC_* environment variables at creation).
 int apply_option(vc_engine* e, const std::string& name, const char* value) {
-  int v0 = 0, v1 = 0, v2 = 0;
-  const int n = sscanf(value ? value : "", "%d,%d,%d", &v0, &v1, &v2);
+  int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+  const int n = sscanf(value ? value : "", "%d,%d,%d,%d", &v0, &v1, &v2, &v3);
   if (n < 1) return fail(e, VC_EINVAL, "option '%s': '%s' is not a number list", name.c_str(), value ? value : "(null)");
   if (name == "attn_pf") {            // slices[,out-projection KB[,FFN-up KB]] of the one-row attention launch's prefetch role; 0 = off
     e->apf_z = std::max(0, std::min(v0, 16));
@@ -981,7 +991,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->gpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->gpf_f2_kb = v1;                      // < 0: by width
     if (n >= 3) e->gpf_qkv_kb = std::max(0, v2);
-  } else if (name == "qkv_p8") { e->qkv_p8 = v0 ? 1 : 0;
+    e->gpf_f1_kb = n >= 4 ? std::max(0, v3) : 0;
+  } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
+  } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
@@ -995,10 +1007,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|lpf=%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|lpf=%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
            e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_qkv_kb);
+           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_qkv_kb, e->gpf_f1_kb);
   e->opt_state = buf;
 }
 
@@ -1291,7 +1303,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1895,7 +1907,8 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       } else if (w == "ffn2") {
         GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
         g.Wp = ly.W28; g.bias = ly.b2; g.x_in = e->act; g.x_ld = 4 * d; g.h_in = e->hA; g.h_out = e->hB;
-        HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
+        if (e->fr_pair && vc_gemm_frp_ok(n_rows, d, 4 * d, e->dtype)) HIPCHK(e, vc_launch_gemm_frp(g, e->dtype, s));
+        else HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
       } else {
         GemmArgs g = base_args(e, rs, e->p_o, d, d);
         g.Wp = ly.Wo8; g.bias = ly.bo; g.h_in = e->hB; g.h_out = e->hA;

@@ -162,7 +162,10 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   if constexpr (NTW == 1 && !R2 && EPI != EPI_LOGITS) {
     if (blockIdx.z != 0) {
       const unsigned idx = blockIdx.x + gridDim.x * blockIdx.y;
-      if (idx < (unsigned)a.pf_blocks) vc_prefetch_tiles(&a.pf, 1, idx, 0u, (unsigned)a.pf_blocks);
+      if (idx < (unsigned)a.pf_blocks) {
+        const PfSeg segs[2] = {a.pf, a.pf2};
+        vc_prefetch_tiles(segs, 2, idx, 0u, (unsigned)a.pf_blocks);
+      }
       return;
     }
   }
@@ -1085,7 +1088,7 @@ int vc_gemm_fr1_ok(int N, int K, int dtype, int nw) {
 hipError_t vc_launch_gemm_fr1(const GemmArgs& a0, int dtype, int pro, int epi, hipStream_t s) {
   const bool qkv = pro == PRO_LN && epi == EPI_QKV;
   if (!qkv && !(pro == PRO_PLAIN && epi == EPI_RES)) return hipErrorInvalidValue;
-  const int nw = qkv ? 4 : VC_FR_WAVES;
+  const int nw = (qkv && a0.mt != 8) ? 4 : VC_FR_WAVES;        // (GemmArgs.mt == 8: the QKV form with eight waves - the comparison arm of option qkv_p8 = 2)
   if (!vc_gemm_fr1_ok(a0.N, a0.K, dtype, nw) || a0.n_rows != 1) return hipErrorInvalidValue;
   GemmArgs a = a0;
   const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16;
@@ -1095,6 +1098,7 @@ hipError_t vc_launch_gemm_fr1(const GemmArgs& a0, int dtype, int pro, int epi, h
   int cap = 1;
   while (cap < npw) cap <<= 1;
 #define VC_FR1_CASE(P_) case P_:                                                                                        \
+    if (qkv && nw == 8) return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, 8, PRO_LN, EPI_QKV>(a, s) : launch_fr1_n<float, P_, 8, PRO_LN, EPI_QKV>(a, s);   \
     if (qkv) return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, 4, PRO_LN, EPI_QKV>(a, s) : launch_fr1_n<float, P_, 4, PRO_LN, EPI_QKV>(a, s);   \
     return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s) : launch_fr1_n<float, P_, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s);
   switch (cap) {
@@ -1105,6 +1109,141 @@ hipError_t vc_launch_gemm_fr1(const GemmArgs& a0, int dtype, int pro, int epi, h
     default: return hipErrorInvalidValue;
   }
 #undef VC_FR1_CASE
+}
+
+// ------------------------------------------------------------------ finished-row producer of 2..8-row steps, paired (round 5)
+// The same two-k-tiles-per-fragment trick for up to EIGHT rows: the B operand has 16 columns, so row r takes columns 2r (x over
+// k-tile 2p) and 2r + 1 (x over k-tile 2p + 1); D[c][2r] + D[c + 8][2r + 1] is channel c of row r.  rows_gemm_fr_k (above) issues one
+// 512-byte fragment per wave instruction for the same 8-channel tiles; here every instruction is a full KB - half the vector-memory
+// instructions of the FFN down-projection of config 5's per-GPU share (8 rows).  X rows sit in LDS at r K + 16 (r & 3) + 128 (r >> 2)
+// bytes, so that the sixteen 16-byte reads of a lane group (8 rows x 2 k-tile parities) fall into sixteen different bank quads.
+// RMAX = rows the staging is unrolled for (4 or 8); K x sizeof(WT) / 16 is a power of two (host contract).
+template <typename WT, int NPW, int RMAX>
+__global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_frp_k(const GemmArgs a) {
+  using T = WTr<WT>;
+  constexpr int NW = VC_FR_WAVES, NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = blockIdx.x;
+  const int n_rows = a.n_rows;                      // 2..RMAX (host contract)
+  const int Kb = a.K * (int)sizeof(WT);             // bytes of one X row = NW * NPW * 128
+  char* xl = smem;
+  f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)RMAX * Kb + 256);      // [NW][RMAX][4]
+  const int active = *a.n_active;
+  const int m = lane & 15, kg = lane >> 4;
+  // epilogue operands first: thread t < 2 RMAX finishes channels 4 (t & 1) .. of row t >> 1
+  const int frow = min(tid >> 1, n_rows - 1);
+  const int nfin = nt * TH + 4 * (tid & 1);
+  const float4 eres = *reinterpret_cast<const float4*>(a.h_in + (long)frow * a.d + nfin);
+  const float4 eb = *reinterpret_cast<const float4*>(a.bias + nfin);
+  // X rows as 16-byte units, flat index = row * upr + unit; RMAX * NPW / 8 units per thread
+  constexpr int NXU = RMAX * ((NPW * 8 + 63) / 64);
+  const int ush = a.x_upr_shift;                    // log2(units per row)
+  const int upr = 1 << ush, total = n_rows * upr;
+  const char* src = reinterpret_cast<const char*>(a.x_in);
+  const long rstride = (long)a.x_ld * (long)sizeof(WT);
+  // (explicit scalars: an indexed array is demoted to scratch memory by the compiler)
+  uint4 x0, x1, x2, x3, x4, x5, x6, x7, x8, x9, x10, x11, x12, x13, x14, x15;
+  static_assert(NXU <= 16, "staging registers per thread");
+#define VC_FRP_LOAD(j, dst)                                                                      \
+  if constexpr (NXU > (j)) {                                                                     \
+    const int i_ = min(tid + (j) * NTHR, total - 1);                                             \
+    const int r_ = i_ >> ush;                                                                    \
+    dst = *reinterpret_cast<const uint4*>(src + (long)r_ * rstride + (long)(i_ - (r_ << ush)) * 16); \
+  }
+#define VC_FRP_PARK(j, val)                                                                      \
+  if constexpr (NXU > (j)) {                                                                     \
+    const int i_ = tid + (j) * NTHR;                                                             \
+    if (i_ < total) {                                                                            \
+      const int r_ = i_ >> ush;                                                                  \
+      *reinterpret_cast<uint4*>(xl + (size_t)r_ * Kb + 16 * (r_ & 3) + 128 * (r_ >> 2) + (size_t)(i_ - (r_ << ush)) * 16) = val; \
+    }                                                                                            \
+  }
+  VC_FRP_LOAD(0, x0) VC_FRP_LOAD(1, x1) VC_FRP_LOAD(2, x2) VC_FRP_LOAD(3, x3) VC_FRP_LOAD(4, x4) VC_FRP_LOAD(5, x5) VC_FRP_LOAD(6, x6) VC_FRP_LOAD(7, x7)
+  VC_FRP_LOAD(8, x8) VC_FRP_LOAD(9, x9) VC_FRP_LOAD(10, x10) VC_FRP_LOAD(11, x11) VC_FRP_LOAD(12, x12) VC_FRP_LOAD(13, x13) VC_FRP_LOAD(14, x14) VC_FRP_LOAD(15, x15)
+  const int wunit = (m >> 3) * SPT + kg * TH + (m & 7);
+  const uint4* wbase = a.Wp + ((long)nt * a.KT + 2 * NPW * wave) * SPT;
+  uint4 wf[NPW];
+#pragma unroll
+  for (int p = 0; p < NPW; ++p)
+    wf[p] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + (long)p * (2 * SPT) + wunit)));
+  __builtin_amdgcn_sched_barrier(0);
+  if (active == 0) return;
+  VC_FRP_PARK(0, x0) VC_FRP_PARK(1, x1) VC_FRP_PARK(2, x2) VC_FRP_PARK(3, x3) VC_FRP_PARK(4, x4) VC_FRP_PARK(5, x5) VC_FRP_PARK(6, x6) VC_FRP_PARK(7, x7)
+  VC_FRP_PARK(8, x8) VC_FRP_PARK(9, x9) VC_FRP_PARK(10, x10) VC_FRP_PARK(11, x11) VC_FRP_PARK(12, x12) VC_FRP_PARK(13, x13) VC_FRP_PARK(14, x14) VC_FRP_PARK(15, x15)
+#undef VC_FRP_LOAD
+#undef VC_FRP_PARK
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const int rl = min(m >> 1, n_rows - 1);           // (columns of rows the pass does not have repeat the last row: cross terms)
+  const char* xcol = xl + (size_t)rl * Kb + 16 * (rl & 3) + 128 * (rl >> 2) + ((size_t)(m & 1) * T::KW + (size_t)kg * T::EPL) * sizeof(WT);
+#pragma unroll
+  for (int p = 0; p < NPW; ++p) {
+    const int gp = NPW * wave + p;
+    const uint4 xf = *reinterpret_cast<const uint4*>(xcol + (size_t)gp * (2 * T::KW * sizeof(WT)));
+    acc = mfma_frag(wf[p], xf, acc, (WT*)nullptr);
+  }
+  // D[n = 4 kg + r][m]: row m >> 1; even columns hold the even k-tiles' channels 0..7 (kg 0 / 1), odd columns the odd k-tiles' (kg 2 / 3)
+  if ((m & 1) == (kg >> 1) && (m >> 1) < n_rows) red[(wave * RMAX + (m >> 1)) * 4 + kg] = acc;
+  __syncthreads();
+  if (tid < 2 * n_rows) {
+    const int r = tid >> 1, half = tid & 1;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int w = 0; w < NW; ++w) sum += red[(w * RMAX + r) * 4 + half] + red[(w * RMAX + r) * 4 + half + 2];
+    const f32x4 o = {eres.x + eb.x + sum[0], eres.y + eb.y + sum[1], eres.z + eb.z + sum[2], eres.w + eb.w + sum[3]};
+    store4(a.h_out + (long)r * a.d + nfin, o);
+  }
+}
+template <typename WT, int NPW, int RMAX>
+static hipError_t launch_frp_n(const GemmArgs& a, hipStream_t s) {
+  auto kern = rows_gemm_frp_k<WT, NPW, RMAX>;
+  const size_t lds = (size_t)RMAX * a.K * sizeof(WT) + 256 + (size_t)VC_FR_WAVES * RMAX * 4 * sizeof(f32x4);
+  if (lds > 64 * 1024) {
+    static size_t granted[16] = {0};   // per instantiation and device
+    int dev = 0;
+    if (hipError_t ge = hipGetDevice(&dev); ge != hipSuccess) return ge;
+    if (dev >= 0 && dev < 16 && lds > granted[dev]) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      granted[dev] = lds;
+    }
+  }
+  ++vc_launch_counts[VC_LC_ROWS_GEMM_FRP];
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(64 * VC_FR_WAVES), lds, s, a);
+  return hipGetLastError();
+}
+// 1 when the paired producer can take `rows` rows of an [N x K] matrix: whole fragment pairs per wave, a power-of-two unit count per
+// row, X within the LDS of one workgroup
+int vc_gemm_frp_ok(int rows, int N, int K, int dtype) {
+  const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16, esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
+  if (rows < 2 || rows > 8 || N % VC_TH_RES != 0 || K % (2 * KW * VC_FR_WAVES) != 0) return 0;
+  const int npw = K / (2 * KW * VC_FR_WAVES), upr = K * esz / 16, rmax = rows <= 4 ? 4 : 8;
+  if ((npw & (npw - 1)) != 0 || npw > 32 || (upr & (upr - 1)) != 0) return 0;
+  if (rmax * ((npw * 8 + 63) / 64) > 16) return 0;                                    // staging registers per thread
+  return (size_t)rmax * K * esz + 256 + (size_t)VC_FR_WAVES * rmax * 64 <= 160 * 1024 ? 1 : 0;
+}
+hipError_t vc_launch_gemm_frp(const GemmArgs& a0, int dtype, hipStream_t s) {
+  if (!vc_gemm_frp_ok(a0.n_rows, a0.N, a0.K, dtype)) return hipErrorInvalidValue;
+  GemmArgs a = a0;
+  const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16, esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
+  a.n_tiles = a.N / VC_TH_RES;
+  a.KT = a.K / KW;
+  const int npw = a.KT / (2 * VC_FR_WAVES), upr = a.K * esz / 16;
+  a.x_upr_shift = 0;
+  while ((1 << a.x_upr_shift) < upr) ++a.x_upr_shift;
+  const bool r4 = a.n_rows <= 4;
+#define VC_FRP_CASE(P_) case P_:                                                                                         \
+    if (r4) return (dtype == VC_DTYPE_BF16) ? launch_frp_n<bf16_t, P_, 4>(a, s) : launch_frp_n<float, P_, 4>(a, s);       \
+    return (dtype == VC_DTYPE_BF16) ? launch_frp_n<bf16_t, P_, 8>(a, s) : launch_frp_n<float, P_, 8>(a, s);
+  switch (npw) {
+    VC_FRP_CASE(1) VC_FRP_CASE(2) VC_FRP_CASE(4) VC_FRP_CASE(8) VC_FRP_CASE(16)
+    case 32: if (r4) return (dtype == VC_DTYPE_BF16) ? launch_frp_n<bf16_t, 32, 4>(a, s) : launch_frp_n<float, 32, 4>(a, s);
+             return hipErrorInvalidValue;
+    default: return hipErrorInvalidValue;
+  }
+#undef VC_FRP_CASE
 }
 
 // ------------------------------------------------------------------ wide decode passes: 17..64 rows
@@ -1396,7 +1535,7 @@ static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int gr
   }
   ++vc_launch_counts[VC_LC_ROWS_GEMM];
   // (prefetch role: extra workgroups behind the tiles; only where the tile -> XCD rule holds)
-  if (NTW != 1 || R2 || EPI == EPI_LOGITS || groups != 1 || b.pf_blocks <= 0 || b.pf.len <= 0 || (a.n_tiles * ksplit) % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
+  if (NTW != 1 || R2 || EPI == EPI_LOGITS || groups != 1 || b.pf_blocks <= 0 || (b.pf.len <= 0 && b.pf2.len <= 0) || (a.n_tiles * ksplit) % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
   b.pf_blocks = std::min(b.pf_blocks, a.n_tiles * ksplit);
   hipLaunchKernelGGL(kern, dim3(a.n_tiles / NTW, ksplit, b.pf_blocks > 0 ? 2 : groups), dim3(256 * NTW), lds, s, b);
   return hipGetLastError();
