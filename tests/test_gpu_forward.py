@@ -71,3 +71,23 @@ def test_forward_bf16_and_sample_by_sample():
         one = {"x": cu["x"][i: i + 1], "x_lens": cu["x_lens"][i: i + 1], "y": cu["y"][i: i + 1], "y_lens": cu["y_lens"][i: i + 1]}
         total += float(eng.forward(one, [spec["spans"][i]])["loss"])
     assert abs(total - float(out["loss"])) <= 1e-3 * abs(float(out["loss"]))
+
+
+def test_forward_takes_the_spans_from_a_caller_supplied_sampler():
+    """`model(batch)` of the reference samples its spans inside (prepare_mask_intervals); the engine takes that sampler as a hook
+    (`mask_sampler(y_lens)`), and without spans or sampler it says what it needs."""
+    name = "fwd_b3_ragged"
+    spec, args, sd, batch = build_forward_case(name)
+    eng = engine_for(args, sd, "fp32")
+    cu = {k: v.cuda() for k, v in batch.items()}
+    want = eng.forward(cu, spec["spans"])
+    seen = []
+
+    def sampler(y_lens):
+        seen.append([int(v) for v in y_lens])
+        return [torch.tensor(iv) for iv in spec["spans"]]          # (the reference returns tensors / nested lists: both are accepted)
+    got = eng.forward(cu, mask_sampler=sampler)
+    assert seen == [[int(v) for v in batch["y_lens"]]]
+    assert float(got["loss"]) == float(want["loss"]) and int(got["effective_ntoken"]) == int(want["effective_ntoken"])
+    with pytest.raises(TypeError):
+        eng.forward(cu)

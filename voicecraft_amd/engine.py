@@ -270,22 +270,27 @@ class VoiceCraftEngine:
 
     # ---- the training objective, teacher-forced
     @torch.no_grad()
-    def forward(self, batch, mask_intervals=None, mask_values=None, _per_row: bool = False):
+    def forward(self, batch, mask_intervals=None, mask_values=None, _per_row: bool = False, mask_sampler=None):
         """`VoiceCraft.forward` (models/voicecraft.py:472-559) as an evaluation pass: batch = {"x" [B,Lx], "x_lens" [B],
         "y" [B,K,T], "y_lens" [B]} exactly as the reference's collate gives it; returns the reference's dict
         (`loss` = sum over codebooks of weight * summed cross-entropy, `top10acc`, `top10acc_by_codebook`,
         `effective_ntoken`).  The reference SAMPLES the masked spans inside (`prepare_mask_intervals`, :198-237 - training
         data augmentation, out of this engine's scope); here they are an argument: `mask_intervals[i]` = the (start, end)
         frame pairs of utterance i.  `mask_values[i]` = the utterance's `emb_inds_use` (default 0..M-1; the reference
-        shuffles them when `shuffle_mask_embedding` is set).  No gradients: this engine does not train."""
+        shuffles them when `shuffle_mask_embedding` is set).  `mask_sampler`: a callable `y_lens -> mask_intervals` used when
+        `mask_intervals` is None (the reference's own `prepare_mask_intervals` fits).  No gradients: this engine does not train."""
         import ast
         import random
-        if mask_intervals is None:
+        if mask_intervals is None and mask_sampler is not None:
             # `model(batch)` of the reference draws the spans itself (prepare_mask_intervals, models/voicecraft.py:198-237: random
-            # training-time augmentation).  That sampler is deliberately not part of this engine; say so instead of failing later
-            raise TypeError("VoiceCraftEngine.forward(batch, mask_intervals): the masked spans are an argument here - pass one list of "
-                            "(start, end) frame pairs per utterance (the reference samples them inside prepare_mask_intervals, which "
-                            "this inference engine does not reproduce)")
+            # training-time augmentation).  The sampler is not part of this engine, but evaluation code that owns one can hand it in:
+            # mask_sampler(y_lens) -> one list of (start, end) frame pairs per utterance, e.g. the bound method
+            # `reference_model.prepare_mask_intervals` (same argument, same return value)
+            mask_intervals = [[(int(s0), int(e0)) for (s0, e0) in iv] for iv in mask_sampler(batch["y_lens"])]
+        if mask_intervals is None:
+            raise TypeError("VoiceCraftEngine.forward(batch, mask_intervals=... | mask_sampler=...): the masked spans are an argument here - "
+                            "pass one list of (start, end) frame pairs per utterance, or a callable that draws them from y_lens (the "
+                            "reference samples them inside prepare_mask_intervals, which this inference engine does not reproduce)")
         x, x_lens, y, y_lens = batch["x"], batch["x_lens"], batch["y"], batch["y_lens"]
         if len(x) == 0:
             return None
