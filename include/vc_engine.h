@@ -97,7 +97,6 @@ const char* vc_version(void);
  * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  name / value:
  *   "attn_pf"      "slices[,out-proj KB[,FFN-up KB]]"   prefetch role of the one-row attention launch, 0 = off; KB < 0 = half a tile
  *   "attn_pf_cut"  "p1,p2[,p0]"   that role fetches half its length from cached position p1, nothing from p2 or below p0 (0,0: never cut)
- *   "ln_pf"        "workgroups[,QKV KB[,FFN-up KB]]"    prefetch role of the LayerNorm launches of several-row steps, 0 = off
  *   "nt"           bit mask of the weight matrices streamed with the non-temporal hint (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down, 16 / 32
  *                  heads); "attn_nt" 0 / 1 / 2 = the decode attention's K/V loads never / always / from two rows per step
  *   "finished_rows" rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs (0 = off, max 16);
@@ -105,7 +104,8 @@ const char* vc_version(void);
  *                  fill the chip (d >= 2048), 2 = at every width, 0 = off;  "ln_trim" 1 = the LayerNorm prologue requests only the slabs
  *                  a pass has;  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
  *   "gemm_pf"      "workgroups[,FFN-down KB[,QKV KB]]"  prefetch roles hosted by the one-row out-projection / FFN-up launches, 0 = off
- *   "lnw_tiles"    weight tiles per workgroup of that form's consumers (0 = by row count, 1, 2)
+ *   "lnw_tiles"    weight tiles per workgroup of that form's consumers (0 = by row count, 1, 2);  "fr_pair" 1 = its FFN down-projection
+ *                  with two k-tiles per MFMA fragment at 2..8 rows;  "qkv_p8" 1 = the one-row QKV projection in the same paired form (2: 8 waves)
  *   "tile_attn"    "k[,min_rows]"  prefill attention kernel (1: 16 query rows per wave; 2: 64 per workgroup, P in registers - bf16,
  *                  head_dim 128, calls whose longest prompt has at least min_rows rows); "fr_split_rows" rows up to which that form's
  *                  attention stays split
@@ -113,7 +113,7 @@ const char* vc_version(void);
  * What an option may change: nothing in the exact fp32 mode's greedy tokens (tests/test_gpu_options.py, test_gpu_one_row.py); in bf16
  * mode the forms that re-order sums or round at another place ("finished_rows", "fr_split_rows", "attn_blocks*", "fr_one",
  * "attn_fast") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can differ between option
- * states; the prefetch / cache-policy options ("attn_pf*", "ln_pf", "gemm_pf", "nt", "attn_nt", "ln_trim", "graph_steps") change no value.
+ * states; the prefetch / cache-policy options ("attn_pf*", "gemm_pf", "nt", "attn_nt", "ln_trim", "graph_steps") change no value.
  * The non-temporal mask "nt" has no bit for the finished-row producers (rows_gemm_fr_k, rows_gemm_fr2_k, row_gemm_fr1_k): they always
  * stream with the hint.  Captured decode graphs are kept per option state, so an in-process A/B (bench.py --ab) pays for capture once
  * per state.  Unknown names / malformed values: VC_EINVAL. */

@@ -81,8 +81,6 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
             assert not has_role, name
         # the four words every address depends on come in ONE scalar batch
         assert len(re.findall(r"s_load_dword s\d+, s\[\d+:\d+\], 0x0\n\ts_load_dword s\d+, s\[\d+:\d+\], 0x0\n\ts_load_dword", body)) >= 1, name
-    for name, (body, _, _) in pick(kern, "ln_rows_k<").items():
-        assert ";;#ASMSTART" in body, name                                # the prefetch role of several-row decode steps
     decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false, 2>")      # FFN-up of a one-row step (h + the out-projection's two slabs)
     for name, (body, _, _) in decode.items():
         assert body.count("v_mfma_f32_16x16x32_bf16") >= 2 and " nt" in body, name     # non-temporal weight stream

@@ -117,13 +117,6 @@ struct vc_engine {
   // with the position and the window it leaves shrinks.  Cuts against uncut there: 400,700 -2.0 % (TTS) / -2.7 % (editing), 500,800
   // -0.7 / -1.8, 300,600 -0.9, 600,900 -0.2.
   int apf_cut1 = 400, apf_cut2 = 700, apf_cut0 = 128;
-  // the same for several-row decode steps, carried by the per-row LayerNorm launches (8 workgroups, 4.9 us each, HBM idle):
-  // VC_LN_PF=blocks[,qkv_kb[,w1_kb]] - LN1 prefetches the QKV matrix, LN2 the FFN-up matrix of the same layer; 0 = off
-  // Measured (profiles/r03i_ln_prefetch_sweep.log): whole matrices LOSE (8 rows 0.911 -> 0.924-0.950 ms: the 4.9 us launch grows by
-  // the 5 us the 25 MB take), the first 24 KB of every tile gain 1-2 % (0.857-0.863 -> 0.844).
-  int lpf_blocks = 248, lpf_qkv_kb = 24, lpf_w1_kb = 24;
-  // (the same on the sampler launch - next step's layer-0 QKV tiles - was built and measured in round 4: 248 x 24 KB +0.01 %, 248 x 40 KB
-  // +0.10 %, 504 x 24 KB -0.35 % +- 0.17 at giga830M, +0.25 % at giga330M in in-process A/Bs, profiles/r04b_bench_spf_*: not carried)
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
   // finished-row form of decode passes of 2..fr_rows rows (forward_rows_fr): 0 = off.  VC_FINISHED_ROWS / option "finished_rows"
   int fr_rows = VC_ROWS;
@@ -467,13 +460,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_LN, EPI_QKV, s));
       } else if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
-        if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_qkv.n_tiles % 8 == 0) {
-          const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * VC_TH_QKV;
-          g.pf = PfSeg{(const char*)ly.Wqkv, e->p_qkv.n_tiles, tile_b, std::min(tile_b, e->lpf_qkv_kb * 1024), 1};
-          g.pf_blocks = e->lpf_blocks;
-        }
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
-        g.pf_blocks = 0;
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
       } else {
@@ -544,13 +531,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       }
       if (split_ln) {
         g.x_out = e->xn;
-        if (e->lpf_blocks > 0 && rs.n_active != nullptr && e->p_f1.n_tiles % 8 == 0) {
-          const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * 16;
-          g.pf = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->lpf_w1_kb * 1024), 1};
-          g.pf_blocks = e->lpf_blocks;
-        }
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
-        g.pf_blocks = 0;
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
       } else {
@@ -969,10 +950,6 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->apf_cut1 = std::max(0, v0);
     e->apf_cut2 = n >= 2 ? std::max(e->apf_cut1, v1) : 0;
     e->apf_cut0 = n >= 3 ? std::max(0, v2) : (e->apf_cut2 > 0 ? 128 : 0);
-  } else if (name == "ln_pf") {       // workgroups[,QKV KB[,FFN-up KB]] of the LayerNorm launches' prefetch role (several-row steps); 0 = off
-    e->lpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
-    if (n >= 2) e->lpf_qkv_kb = std::max(0, v1);
-    if (n >= 3) e->lpf_w1_kb = std::max(0, v2);
   } else if (name == "graph_steps") { e->steps_per_graph = std::max(1, std::min(64, v0));
   } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
   } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
@@ -1007,8 +984,8 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|lpf=%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0, e->lpf_blocks,
-           e->lpf_qkv_kb, e->lpf_w1_kb, e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+           e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
            e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_qkv_kb, e->gpf_f1_kb);
   e->opt_state = buf;
@@ -1299,7 +1276,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipStreamCreate(&e->own_stream));
   // ---- options: the VC_* environment variables preset them, vc_set_option changes them at run time
   for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), std::make_pair("VC_LN_SPLIT_ROWS", "ln_split_rows"),
-                         std::make_pair("VC_LN_PF", "ln_pf"), std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
+                         std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),

@@ -152,7 +152,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
 
   VC_KTS_DECL();
   VC_KTS(0);
-  // Prefetch role (round 5, option "gemm_pf"; GemmArgs.pf / pf_blocks as in ln_rows_k): a launch that leaves HBM idle - the one-row
+  // Prefetch role (round 5, option "gemm_pf"; GemmArgs.pf / pf_blocks): a launch that leaves HBM idle - the one-row
   // out-projection waits for the attention partials and streams 8.4 MB in 4.3 us; every launch of a d = 1024 model - is launched
   // with a SECOND grid.z layer of workgroups that do none of its work: the first pf_blocks of them pull the head of a LATER launch's
   // weight tiles into the L2 of the XCD whose workgroups will read them (vc_common.h vc_prefetch_tiles), the rest exit at once.
@@ -1432,11 +1432,6 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_mt_k(const GemmArgs a) {
 template <typename WT>
 __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
   __shared__ float s_sum[4], s_sq[4];
-  if ((int)blockIdx.x >= a.n_rows) {     // piggyback prefetch (several-row decode steps: this launch leaves HBM idle)
-    const unsigned lin0 = ((unsigned)a.n_rows + 7u) & ~7u;
-    if (a.pf_blocks > 0 && blockIdx.x >= lin0) vc_prefetch_tiles(&a.pf, 1, blockIdx.x, lin0, (unsigned)a.pf_blocks);
-    return;
-  }
   const int active = *a.n_active;
   const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int d = a.d;
@@ -1493,9 +1488,10 @@ __global__ __launch_bounds__(256) void ln_rows_k(const GemmArgs a) {
 }
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s) {
   ++vc_launch_counts[VC_LC_LN_ROWS];
-  const int blocks = a.pf_blocks > 0 ? ((a.n_rows + 7) & ~7) + a.pf_blocks : a.n_rows;
-  if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(ln_rows_k<bf16_t>, dim3(blocks), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL(ln_rows_k<float>, dim3(blocks), dim3(256), 0, s, a);
+  // (round 3's prefetch role of this launch - option ln_pf - left the tree in round 5: it served the slab form of 3..16-row steps, which
+  // the finished-row form replaced as the default in round 4, and at 17..64 rows it measured a loss, profiles/r03j_lpf32_ab.log)
+  if (dtype == VC_DTYPE_BF16) hipLaunchKernelGGL(ln_rows_k<bf16_t>, dim3(a.n_rows), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL(ln_rows_k<float>, dim3(a.n_rows), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 
