@@ -103,7 +103,7 @@ const char* vc_version(void);
  *   "fr_one"       ONE-row steps: 1 (default) = the FFN down-projection finishes its row (no split-K slabs) where its d / 8 workgroups
  *                  fill the chip (d >= 2048), 2 = at every width, 0 = off;  "ln_trim" 1 = the LayerNorm prologue requests only the slabs
  *                  a pass has;  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
- *   "gemm_pf"      "workgroups[,FFN-down KB[,QKV KB]]"  prefetch roles hosted by the one-row out-projection / FFN-up launches, 0 = off
+ *   "gemm_pf"      "workgroups[,FFN-down KB[,FFN-up KB]]"  prefetch role hosted by the one-row out-projection launch, 0 = off; KB < 0 = by width
  *   "lnw_tiles"    weight tiles per workgroup of that form's consumers (0 = by row count, 1, 2);  "fr_pair" 1 = its FFN down-projection
  *                  with two k-tiles per MFMA fragment at 2..8 rows;  "qkv_p8" 1 = the one-row QKV projection in the same paired form (2: 8 waves)
  *   "tile_attn"    "k[,min_rows]"  prefill attention kernel (1: 16 query rows per wave; 2: 64 per workgroup, P in registers - bf16,

@@ -81,7 +81,7 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
             assert not has_role, name
         # the four words every address depends on come in ONE scalar batch
         assert len(re.findall(r"s_load_dword s\d+, s\[\d+:\d+\], 0x0\n\ts_load_dword s\d+, s\[\d+:\d+\], 0x0\n\ts_load_dword", body)) >= 1, name
-    decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false, 2>")      # FFN-up of a one-row step (h + the out-projection's two slabs)
+    decode = pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false, 2, false>")      # FFN-up of a one-row step (h + the out-projection's two slabs)
     for name, (body, _, _) in decode.items():
         assert body.count("v_mfma_f32_16x16x32_bf16") >= 2 and " nt" in body, name     # non-temporal weight stream
     # finished-row form (2..16-row decode steps): the FFN down-projection streams a wave's whole share (32 fragments) in ONE burst
@@ -104,13 +104,19 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
     for name, (body, _, vgpr) in pick(kern, "rows_gemm_frp_k<bf16_t, 16, 8>").items():
         assert len(re.findall(r"global_load_dwordx4[^\n]* nt", body)) == 16 and body.count("v_mfma_f32_16x16x32_bf16") == 16, name
         assert vgpr <= 256, (name, vgpr)
+    # the GEMM path reads `*a.n_active` with a SCALAR load wherever the kernel does not host the prefetch role (the role's inline asm
+    # turns it into a vector load: that is why the role has its own instantiation, `..., true>`)
+    for name, (body, _, _) in pick(kern, "rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false, 2, false>").items():
+        assert ";;#ASMSTART" not in body and re.search(r"s_load_dword s\d+, s\[\d+:\d+\], 0x0\n", body), name
+    for name, (body, _, _) in pick(kern, "rows_gemm_k<bf16_t, 8, 2, 1, 1, true, false, 4, true>").items():
+        assert ";;#ASMSTART" in body and "s_load" not in body.split("s_cbranch")[0], name        # the role, decided from blockIdx.z alone
     # the trimmed LayerNorm prologues: every slab the prologue does not request is two 16-byte loads per thread and row less
     n_plain = {}
     for np_ in ("0", "2", "4"):
-        for name, (body, _, _) in pick(kern, f"rows_gemm_k<bf16_t, 16, 0, 0, 1, true, false, {np_}>").items():
+        for name, (body, _, _) in pick(kern, f"rows_gemm_k<bf16_t, 16, 0, 0, 1, true, false, {np_}, false>").items():
             n_plain[np_] = len(re.findall(r"global_load_dwordx4 ", body)) - len(re.findall(r"global_load_dwordx4[^\n]* nt", body))
     assert n_plain["0"] + 4 <= n_plain["2"] and n_plain["2"] + 4 <= n_plain["4"], n_plain
-    for prefix in ("rows_gemm_k<bf16_t, 16, 3, 0, 2, true, false, 4>", "rows_gemm_k<bf16_t, 16, 3, 2, 2, true, false, 4>"):
+    for prefix in ("rows_gemm_k<bf16_t, 16, 3, 0, 2, true, false, 4, false>", "rows_gemm_k<bf16_t, 16, 3, 2, 2, true, false, 4, false>"):
         for name, (body, _, vgpr) in pick(kern, prefix).items():
             assert vgpr <= 128 and " nt" in body, (name, vgpr)             # 8 waves per workgroup, two workgroups per CU
 
@@ -123,7 +129,7 @@ def test_the_non_temporal_hint_survives_in_every_decode_gemm(kern):
     import re
     seen = 0
     for name, (body, _, _) in pick(kern, "rows_gemm_k<").items():
-        m = re.search(r"rows_gemm_k<(\w+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+)>", name)
+        m = re.search(r"rows_gemm_k<(\w+), (\d+), (\d+), (\d+), (\d+), (true|false), (true|false), (\d+), (true|false)>", name)
         assert m, name
         ktw, nt = int(m.group(2)), m.group(6) == "true"
         n = len(re.findall(r"global_load_dwordx4[^\n]* nt", body))

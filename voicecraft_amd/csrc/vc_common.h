@@ -228,11 +228,14 @@ __device__ __forceinline__ void vc_prefetch_tiles(const PfSeg* segs, int nseg, u
       for (unsigned q = 0; q < sub; ++q) {
         const char* src = sg.base + (size_t)((xcd + 8u * t) * sub + q) * (size_t)sg.tile_bytes;
         for (unsigned off = tid * 16u; off < (unsigned)sg.len; off += nthr * 16u)
-          asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src + off) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src + off));
       }
     }
   }
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink) :: "memory");
+  // (no "memory" clobber on these statements: the loads change nothing the program reads, volatile asms keep their order among
+  // themselves, and a clobber anywhere in a kernel makes hipcc turn every scalar load of the OTHER path - `*a.n_active`, the row's
+  // position - into a vector load: seen in the ISA of the rows-GEMM once it hosted this role, round 5)
+  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink));
 }
 #endif
 

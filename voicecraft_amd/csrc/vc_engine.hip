@@ -135,13 +135,15 @@ struct vc_engine {
   // whole K, two k-tiles per MFMA fragment, residual + bias added) instead of leaving 4 split-K slabs, so the next layer's QKV
   // projection (and heads-1) reads one 8 KB row instead of h + bias + 4 slabs = 40 KB in each of its 512 workgroups
   int fr_one = 1;
-  // option "gemm_pf" = "blocks,f2_kb,qkv_kb" (round 5): prefetch roles hosted by the one-row GEMM launches that leave HBM idle - the
-  // out-projection launch pulls the first f2_kb KB of every FFN down-projection tile, the FFN-up launch the first qkv_kb KB of the NEXT
-  // layer's QKV tiles (d <= 1024 models: every launch is latency); `blocks` extra workgroups per K slice.  0 = off.
-  // Measured with the attention launch's role off (profiles/r05c_ab_gemm_pf_attention_role_off_830M.log, r05c_*330M*): 128 workgroups x
-  // 16 KB of every FFN-down tile -0.57 % +- 0.06 at giga830M (32 KB: 0.0), giga330M 32 KB -0.84 % +- 0.06 / 16 KB -0.53 %; the QKV
-  // matrix under the FFN-up launch LOSES (+3.8 % at giga330M).  f2_kb < 0 = by width: 16 KB at d >= 2048, 32 KB below.
-  int gpf_blocks = 128, gpf_f2_kb = -1, gpf_qkv_kb = 0, gpf_f1_kb = 0;      // (f1_kb: the head of the FFN-up tiles - the NEXT launch - under the out-projection too)
+  // option "gemm_pf" = "blocks,f2_kb[,f1_kb]" (round 5): the prefetch role hosted by the one-row out-projection launch - it waits for the
+  // attention partials and streams 8.4 MB in ~4.5 us.  `blocks` extra workgroups pull the first f2_kb KB of every FFN down-projection
+  // tile (the launch after next) and, if f1_kb > 0, the first f1_kb KB of every FFN-up tile (the next launch).  0 = off.
+  // Measured with the attention launch's role off (profiles/r05c_ab_gemm_pf_attention_role_off_830M.log, r05d_*, r05e_*): 128 workgroups x
+  // 16 KB of every FFN-down tile -0.57 % +- 0.06 / -1.17 % +- 0.02 at giga830M on two boxes (32 KB: 0.0; 256 workgroups: 0.0), giga330M
+  // 32 KB -0.84 % +- 0.06 / 16 KB -0.53 %; + 16 KB of the FFN-up tiles +2.4 % (giga330M +0.5 %), INSTEAD of the FFN-down tiles +0.2 %.
+  // The NEXT layer's QKV tiles under the FFN-up launch (a first form of this option) lost 3.8 % at giga330M and left the tree.
+  // f2_kb < 0 = by width: 16 KB at d >= 2048, 32 KB below.
+  int gpf_blocks = 128, gpf_f2_kb = -1, gpf_f1_kb = 0;
   // option "fr_pair" (round 5): the FFN down-projection of 2..8-row steps with two k-tiles per MFMA fragment (rows_gemm_frp_k) instead
   // of half-filled 8-channel fragments (rows_gemm_fr_k)
   int fr_pair = 1;
@@ -524,11 +526,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.wg = ly.wg_1;
       g.out = e->act; g.out_ld = 4 * d;
-      if (!split_ln && e->gpf_blocks > 0 && e->gpf_qkv_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr && l + 1 < e->L) {
-        const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * VC_TH_QKV;
-        g.pf = PfSeg{(const char*)e->layers[l + 1].Wqkv, e->p_qkv.n_tiles, tile_b, std::min(tile_b, e->gpf_qkv_kb * 1024), 1};
-        g.pf_blocks = e->gpf_blocks;
-      }
       if (split_ln) {
         g.x_out = e->xn;
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
@@ -939,8 +936,8 @@ int check_err_flag(vc_engine* e, hipStream_t s) {
 
 // One option by name (vc_set_option, and the VC_* environment variables at creation).
 int apply_option(vc_engine* e, const std::string& name, const char* value) {
-  int v0 = 0, v1 = 0, v2 = 0, v3 = 0;
-  const int n = sscanf(value ? value : "", "%d,%d,%d,%d", &v0, &v1, &v2, &v3);
+  int v0 = 0, v1 = 0, v2 = 0;
+  const int n = sscanf(value ? value : "", "%d,%d,%d", &v0, &v1, &v2);
   if (n < 1) return fail(e, VC_EINVAL, "option '%s': '%s' is not a number list", name.c_str(), value ? value : "(null)");
   if (name == "attn_pf") {            // slices[,out-projection KB[,FFN-up KB]] of the one-row attention launch's prefetch role; 0 = off
     e->apf_z = std::max(0, std::min(v0, 16));
@@ -967,8 +964,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "gemm_pf") {
     e->gpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->gpf_f2_kb = v1;                      // < 0: by width
-    if (n >= 3) e->gpf_qkv_kb = std::max(0, v2);
-    e->gpf_f1_kb = n >= 4 ? std::max(0, v3) : 0;
+    e->gpf_f1_kb = n >= 3 ? std::max(0, v2) : 0;
   } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
   } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
@@ -984,10 +980,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_qkv_kb, e->gpf_f1_kb);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb);
   e->opt_state = buf;
 }
 

@@ -141,7 +141,10 @@ hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStr
 // that wrote whole rows).  Every workgroup of a consumer launch used to pull h + 4 slabs = 40 KB out of L2 whatever n_parts said
 // (unconditional loads, unused slabs discarded by a select): 512 workgroups x 40 KB = 20 MB through the CUs' vector memory
 // pipes per launch, queued IN FRONT of the 25-33 MB weight burst (round 5: in-kernel stamps, profiles/r04b_kernel_stamps_*).
-template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true, bool R2 = false, int NP = VC_MAX_KSPLIT>
+// PF: the launch carries the prefetch role below (a second grid.z layer of workgroups).  A template parameter because the role's
+// inline asm, merely by being in the kernel, makes hipcc load `*a.n_active` (and a gathered row index) with VECTOR loads in the
+// GEMM path as well (seen in the ISA, round 5): only the form that hosts the role - the one-row out-projection - pays that.
+template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true, bool R2 = false, int NP = VC_MAX_KSPLIT, bool PF = false>
 __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   static_assert(NTW == 1 || PRO == PRO_LNW, "two tiles per workgroup: finished-row consumers only");
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   // The role is decided from blockIdx.z alone - a test against a kernel argument would put a scalar load, its wait and a branch in
   // front of every other argument load of the GEMM path (seen in the ISA of the first build).  grid.x * grid.y is a multiple of
   // 8, so a workgroup's XCD is its index within the layer & 7.  (The heads' second linears use grid.z for their groups: no role.)
-  if constexpr (NTW == 1 && !R2 && EPI != EPI_LOGITS) {
+  static_assert(!PF || (NTW == 1 && !R2 && EPI != EPI_LOGITS), "prefetch role: one tile per workgroup, grid.z free");
+  if constexpr (PF) {
     if (blockIdx.z != 0) {
       const unsigned idx = blockIdx.x + gridDim.x * blockIdx.y;
       if (idx < (unsigned)a.pf_blocks) {
@@ -938,10 +942,8 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
   static_assert((PRO == PRO_PLAIN && EPI == EPI_RES) || (PRO == PRO_LN && EPI == EPI_QKV), "one-row paired forms");
   constexpr int NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;   // SPT = 16-byte units per (tile, k-tile) = 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  if (blockIdx.y != 0) {     // prefetch role, as in rows_gemm_k: a second layer of workgroups, decided from the workgroup id alone
-    if (blockIdx.x < (unsigned)a.pf_blocks) vc_prefetch_tiles(&a.pf, 1, blockIdx.x, 0u, (unsigned)a.pf_blocks);
-    return;
-  }
+  VC_KTS_DECL();
+  VC_KTS(0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x;
@@ -989,6 +991,7 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
   }
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
+  VC_KTS(1);
   if constexpr (PRO == PRO_PLAIN) {
 #define VC_FR1_XPARK(j, val) if constexpr (NXU > (j)) { if (tid + (j) * NTHR < units) *reinterpret_cast<uint4*>(xl + (size_t)(tid + (j) * NTHR) * 16) = val; }
     VC_FR1_XPARK(0, xu0) VC_FR1_XPARK(1, xu1) VC_FR1_XPARK(2, xu2) VC_FR1_XPARK(3, xu3)
@@ -1023,7 +1026,9 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
     s2 = wave_sum(s2);
     if (lane == 0) { stat[NW + 2 * wave] = s1; stat[NW + 2 * wave + 1] = s2; }
   }
+  VC_KTS(2);
   __syncthreads();
+  VC_KTS(3);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
   // B operand: column m = 0 reads x over k-tile 2 gp, column 1 over k-tile 2 gp + 1 (the other columns repeat these: cross terms)
   const char* xcol = xl + ((size_t)(m & 1) * T::KW + (size_t)kg * T::EPL) * sizeof(WT);
@@ -1038,8 +1043,10 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
   }
   // D[n = 4 kg + r][m]: channels 0..3 / 4..7 over the even k-tiles sit in lanes (m = 0, kg = 0 / 1), over the odd ones in lanes
   // (m = 1, kg = 2 / 3): four quads per wave
+  VC_KTS(4);
   if (m == (kg >> 1) && m < 2) red[wave * 4 + kg] = acc;
   __syncthreads();
+  VC_KTS(5);
   if (tid < 2) {             // thread t finishes channels 4 t .. 4 t + 3: quads t and t + 2 of every wave, in a fixed order
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -1060,16 +1067,15 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
       gemm_epilogue<WT, EPI_QKV>(a, sum, 0, nfin, 0, 0, 1, eb, epos, eseq);
     }
   }
+  VC_KTS(6);
+  VC_KTS_FLUSH();
 }
 template <typename WT, int NPW, int NW, int PRO, int EPI>
 static hipError_t launch_fr1_n(const GemmArgs& a, hipStream_t s) {
   auto kern = (a.KT == 2 * NW * NPW) ? row_gemm_fr1_k<WT, NPW, true, NW, PRO, EPI> : row_gemm_fr1_k<WT, NPW, false, NW, PRO, EPI>;
   const size_t lds = (size_t)a.K * sizeof(WT) + (size_t)NW * 4 * sizeof(f32x4) + (size_t)NW * 3 * sizeof(float);
   ++vc_launch_counts[VC_LC_ROW_GEMM_FR1];
-  GemmArgs b = a;
-  if (b.pf_blocks <= 0 || b.pf.len <= 0 || a.n_tiles % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
-  b.pf_blocks = std::min(b.pf_blocks, a.n_tiles);
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles, b.pf_blocks > 0 ? 2 : 1), dim3(64 * NW), lds, s, b);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(64 * NW), lds, s, a);
   return hipGetLastError();
 }
 // 1 when the one-row paired kernel can take an [N x K] matrix in this dtype with `nw` waves per workgroup (the engine's planning and
@@ -1502,9 +1508,9 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4) + VC_ROWS * 4 * 3 * sizeof(float);   // X rows, K-reduce area, LN statistics + row means
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int NTW, bool NT, bool R2 = false, int NP = VC_MAX_KSPLIT>
+template <typename WT, int KTW, int PRO, int EPI, int NTW, bool NT, bool R2 = false, int NP = VC_MAX_KSPLIT, bool PF = false>
 static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW, NT, R2, NP>;
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW, NT, R2, NP, PF>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit) + (size_t)(NTW - 1) * 4 * 64 * sizeof(f32x4);
   if (lds > 64 * 1024) {
     static size_t granted[16] = {0};   // per instantiation and device
@@ -1531,7 +1537,7 @@ static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int gr
   }
   ++vc_launch_counts[VC_LC_ROWS_GEMM];
   // (prefetch role: extra workgroups behind the tiles; only where the tile -> XCD rule holds)
-  if (NTW != 1 || R2 || EPI == EPI_LOGITS || groups != 1 || b.pf_blocks <= 0 || (b.pf.len <= 0 && b.pf2.len <= 0) || (a.n_tiles * ksplit) % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
+  if (!PF || groups != 1 || b.pf_blocks <= 0 || (b.pf.len <= 0 && b.pf2.len <= 0) || (a.n_tiles * ksplit) % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
   b.pf_blocks = std::min(b.pf_blocks, a.n_tiles * ksplit);
   hipLaunchKernelGGL(kern, dim3(a.n_tiles / NTW, ksplit, b.pf_blocks > 0 ? 2 : groups), dim3(256 * NTW), lds, s, b);
   return hipGetLastError();
@@ -1546,6 +1552,10 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
       if (a.n_parts == 0 && !a.has_prev_bias) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, 0>(a, dtype, ksplit, groups, s);
       if (a.n_parts <= 2) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, 2>(a, dtype, ksplit, groups, s);
     }
+  }
+  if constexpr (PRO == PRO_ATT && EPI == EPI_PART && NTW == 1) {
+    // the one-row out-projection may host the prefetch role (option gemm_pf): its own instantiation
+    if (a.pf_blocks > 0 && a.nt && groups == 1) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, VC_MAX_KSPLIT, true>(a, dtype, ksplit, groups, s);
   }
   if (a.nt) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true>(a, dtype, ksplit, groups, s);
   return launch_dec_nt<WT, KTW, PRO, EPI, NTW, false>(a, dtype, ksplit, groups, s);
