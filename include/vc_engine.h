@@ -100,8 +100,7 @@ const char* vc_version(void);
  *   "nt"           bit mask of the weight matrices streamed with the non-temporal hint (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down, 16 / 32
  *                  heads); "attn_nt" 0 / 1 / 2 = the decode attention's K/V loads never / always / from two rows per step
  *   "finished_rows" rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs (0 = off, max 16);
- *   "fr_one"       ONE-row steps: 1 (default) = the FFN down-projection finishes its row (no split-K slabs) where its d / 8 workgroups
- *                  fill the chip (d >= 2048), 2 = at every width, 0 = off;  "ln_trim" 1 = the LayerNorm prologue requests only the slabs
+ *   "fr_one"       ONE-row steps: 1 (default) = the FFN down-projection finishes its row (no split-K slabs), 0 = off;  "ln_trim" 1 = the LayerNorm prologue requests only the slabs
  *                  a pass has;  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
  *   "gemm_pf"      "workgroups[,FFN-down KB[,FFN-up KB]]"  prefetch role hosted by the one-row out-projection launch, 0 = off; KB < 0 = by width
  *   "lnw_tiles"    weight tiles per workgroup of that form's consumers (0 = by row count, 1, 2);  "fr_pair" 1 = its FFN down-projection

@@ -44,7 +44,7 @@ def test_one_row_forms_fp32_tokens_equal_the_oracle(preset, use_graph):
     want, tr = _oracle_run(a, sd, x, xl, y)
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=1, max_positions=256, use_graph=use_graph)
     L, n = a.num_decoder_layers, len(tr)
-    for fr_one, ln_trim, attn_fast, qkv_p8 in list(itertools.product((2, 0), (1, 0), (1, 0), (1,))) + [(2, 1, 1, 0)]:      # (fr_one 2: also below d = 2048, where the default keeps the slab form)
+    for fr_one, ln_trim, attn_fast, qkv_p8 in list(itertools.product((2, 0), (1, 0), (1, 0), (1,))) + [(2, 1, 1, 0)]:
         eng.set_option("fr_one", fr_one)
         eng.set_option("ln_trim", ln_trim)
         eng.set_option("attn_fast", attn_fast)

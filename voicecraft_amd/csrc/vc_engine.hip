@@ -131,9 +131,9 @@ struct vc_engine {
   // 512 / 800 / 2048 causal rows: 14.3 / 24.6 / 86.7 us (first kernel) against 15.5 / 21.0 / 52.5 us (second).
   int tile_attn = 2, tile_attn_min_rows = 768;
   int fr_split_rows = VC_FR_MAX_ROWS;   // option "fr_split_rows": passes of more rows run the attention unsplit (it normalises itself, plain out-projection prologue)
-  // option "fr_one" (round 5): ONE-row steps - bit 0: the FFN down-projection finishes its row (row_gemm_fr1_k: 8-channel tiles over the
-  // whole K, two k-tiles per MFMA fragment, residual + bias added) instead of leaving 4 split-K slabs, so the next layer's QKV
-  // projection (and heads-1) reads one 8 KB row instead of h + bias + 4 slabs = 40 KB in each of its 512 workgroups
+  // option "fr_one" (round 5): ONE-row steps - the FFN down-projection finishes its row (row_gemm_fr1_k: 8-channel tiles over the whole K,
+  // two k-tiles per MFMA fragment, residual + bias added) instead of leaving 4 split-K slabs, so the next layer's QKV projection (and
+  // heads-1) reads one 8 KB row instead of h + bias + 4 slabs = 40 KB in each of its 512 workgroups; 0 = off
   int fr_one = 1;
   // option "gemm_pf" = "blocks,f2_kb[,f1_kb]" (round 5): the prefetch role hosted by the one-row out-projection launch - it waits for the
   // attention partials and streams 8.4 MB in ~4.5 us.  `blocks` extra workgroups pull the first f2_kb KB of every FFN down-projection
@@ -320,10 +320,11 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
 }
 
 // ONE-row steps whose FFN down-projection finishes the row (option "fr_one" bit 0): the launcher's own statement of what it takes
-// fr_one = 1 (default): only where the producer's d/8 workgroups fill the chip (d >= 2048: in-process A/Bs of round 5, profiles/r05a_*:
-// giga830M -2.13 % +- 0.01 per step; giga330M, 128 workgroups on 256 CUs, +1.5 % +- 0.09); 2: wherever the kernel can run
+// fr_one != 0: wherever the kernel can run.  (The first build - FFN-down alone - gained 2.1 % at giga830M and LOST 1.5 % at giga330M,
+// whose d / 8 = 128 workgroups fill half the chip; together with the paired QKV projection it takes along the form gains there
+// too: -0.5 % +- 0.1 / -0.9 % +- 0.09 on two boxes, profiles/r05e_ab_330M.log, r05f_ab_330M.log.)
 inline bool fd_one(const vc_engine* e, int rows) {
-  if (rows != 1 || e->fr_one == 0 || (e->fr_one == 1 && e->d / VC_TH_RES < 256)) return false;
+  if (rows != 1 || e->fr_one == 0) return false;
   return !e->layers.empty() && e->layers[0].W28 != nullptr && vc_gemm_fr1_ok(e->d, 4 * e->d, e->dtype, VC_FR_WAVES) != 0;
 }
 
