@@ -117,14 +117,15 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 #pragma unroll
       for (int j = 0; j < EPL / 4; ++j) qv[j] = qp[j];
     }
-    const long hbase = (long)h * a.S_max * hd + li * EPL;
-    const long base = (long)seq * a.cache_seq_stride + hbase;
-    const WT* kb = reinterpret_cast<const WT*>(a.kcache) + base;
-    const WT* vb = reinterpret_cast<const WT*>(a.vcache) + base;
-    const long own = (long)seq * a.cache_seq_stride;      // positions below `share` live in sequence 0's cache
     uint4 ku[4], vu[4];
     int pp[4];
+    // (the general form - refills of long chunks, calls with a shared text prefix - computes its per-lane 64-bit bases where it is
+    // used: hoisted in front of the first batch they would sit in front of the lean path too)
 #define VC_KV_LOADS(pb_)                                                     \
+    const long own = (long)seq * a.cache_seq_stride;      /* positions below `share` live in sequence 0's cache */ \
+    const long base = own + (long)h * a.S_max * hd + li * EPL;               \
+    const WT* kb = reinterpret_cast<const WT*>(a.kcache) + base;             \
+    const WT* vb = reinterpret_cast<const WT*>(a.vcache) + base;             \
     _Pragma("unroll") for (int it = 0; it < 4; ++it) {                       \
       pp[it] = (pb_) + (it * NW + wave) * PPW + sub;                         \
       const long pc = max(min(pp[it], p1 - 1), 0);                           \
@@ -137,7 +138,30 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
         vu[it] = *reinterpret_cast<const uint4*>(vb + po);                   \
       }                                                                      \
     }
-    VC_KV_LOADS(p0);
+    // The FIRST batch - the one every launch waits for - from a wave-uniform base and one 32-bit offset per lane when no prefix is
+    // shared (every call but the sentence-chained ones): scalar-base addressing, no 64-bit vector arithmetic, no select per visit.
+    // (In-kernel stamps of the first round-5 build: 2 956 clk from "position known" to "loads issued" - the address code in front of
+    // the requests is paid in instruction fetch at the cold start of the launch, profiles/r05f_kernel_stamps_giga830M.log.)
+    if (__builtin_expect(share == 0 && a.fast != 3, 1)) {       // (a.fast == 3: the comparison arm of option attn_fast = 3, the general form)
+      const char* kbu = reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.kcache) + (long)seq * a.cache_seq_stride + (long)h * a.S_max * hd);
+      const char* vbu = reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.vcache) + (long)seq * a.cache_seq_stride + (long)h * a.S_max * hd);
+      const unsigned lo = (unsigned)(li * EPL) * (unsigned)sizeof(WT);
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        pp[it] = p0 + (it * NW + wave) * PPW + sub;
+        const unsigned pc = (unsigned)max(min(pp[it], p1 - 1), 0);
+        const unsigned off = ((pc << a.hd_shift) * (unsigned)sizeof(WT)) + lo;
+        if constexpr (NT) {
+          ku[it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kbu + off)));
+          vu[it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vbu + off)));
+        } else {
+          ku[it] = *reinterpret_cast<const uint4*>(kbu + off);
+          vu[it] = *reinterpret_cast<const uint4*>(vbu + off);
+        }
+      }
+    } else {
+      VC_KV_LOADS(p0)
+    }
     __builtin_amdgcn_sched_barrier(0);
     VC_KTS(2);
     float q[EPL];
@@ -203,7 +227,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
       }
       pb += step;
       if (pb >= p1) break;
-      VC_KV_LOADS(pb);
+      { VC_KV_LOADS(pb) }
     }
 #undef VC_KV_LOADS
     VC_KTS(4);
