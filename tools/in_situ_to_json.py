@@ -11,8 +11,8 @@ d = {"giga830M": 2048, "giga330M": 1024}.get(cfg["preset"], 2048)
 alg = {"ffn1": 4 * d * d * 2 + d * 4 + 4 * d * 2, "ffn2": 4 * d * d * 2 + 4 * d * 2 + d * 4, "qkv": 3 * d * d * 2 + d * 4 + 3 * d * 2,
        "oproj": d * d * 2 + d * 4 * 2}
 # one-row step: the form each matrix runs in (first pattern that matches a line wins; most calls wins among equal names)
-pat = {"ffn2": [r"row_gemm_fr1_k<bf16_t, \d+, \w+, 8, 1, 5", r"rows_gemm_k<bf16_t, \d+, 1, 1,"], "qkv": [r"row_gemm_fr1_k<bf16_t, \d+, \w+, 4, 0, 0", r"rows_gemm_k<bf16_t, \d+, 0, 0,"],
-       "ffn1": [r"row_gemm_fr1_k<bf16_t, \d+, \w+, 4, 0, 2", r"rows_gemm_k<bf16_t, \d+, 0, 2,"], "oproj": [r"rows_gemm_k<bf16_t, \d+, 2, 1,"], "attn": [r"rows_attn_k<bf16_t"],
+pat = {"ffn2": [r"row_gemm_fr1_k<bf16_t, \d+, \w+, 8, 1, 5>", r"rows_gemm_k<bf16_t, \d+, 1, 1,"], "qkv": [r"row_gemm_fr1_k<bf16_t, \d+, \w+, 4, 0, 0>", r"rows_gemm_k<bf16_t, \d+, 0, 0,"],
+       "ffn1": [r"rows_gemm_k<bf16_t, \d+, 0, 2,"], "oproj": [r"rows_gemm_k<bf16_t, \d+, 2, 1,"], "attn": [r"rows_attn_k<bf16_t"],
        "heads1": [r"rows_gemm_k<bf16_t, \d+, 0, 3,"], "heads2": [r"rows_gemm_k<bf16_t, \d+, 1, 4,"], "sampler": [r"sample_fused_k"]}
 rows = []
 for line in open(src):

@@ -11,8 +11,8 @@ d = 2048
 alg = {"ffn1": 4 * d * d * 2 + d * 4 + 4 * d * 2, "ffn2": 4 * d * d * 2 + 4 * d * 2 + d * 4, "qkv": 3 * d * d * 2 + d * 4 + 3 * d * 2,
        "oproj": d * d * 2 + d * 4 * 2}
 # first pattern that matches wins (the forms a one-row step launches since round 5, then the round-4 forms)
-pat = {"ffn1": [r"row_gemm_fr1_k<bf16_t, 16, true, 4, 0, 2", r"rows_gemm_k<bf16_t, 16, 0, 2,"], "ffn2": [r"row_gemm_fr1_k<bf16_t, 16, true, 8, 1, 5", r"rows_gemm_k<bf16_t, 16, 1, 1,"],
-       "qkv": [r"row_gemm_fr1_k<bf16_t, 8, true, 4, 0, 0", r"rows_gemm_k<bf16_t, 16, 0, 0,"], "oproj": [r"rows_gemm_k<bf16_t, 8, 2, 1,"]}
+pat = {"ffn1": [r"rows_gemm_k<bf16_t, 16, 0, 2,"], "ffn2": [r"row_gemm_fr1_k<bf16_t, 16, true, 8, 1, 5>", r"rows_gemm_k<bf16_t, 16, 1, 1,"],
+       "qkv": [r"row_gemm_fr1_k<bf16_t, 8, true, 4, 0, 0>", r"rows_gemm_k<bf16_t, 16, 0, 0,"], "oproj": [r"rows_gemm_k<bf16_t, 8, 2, 1,"]}
 out = {"source": f"{src} (rocprofv3 --pmc FETCH_SIZE --kernel-trace, own pass of `python bench.py --steps 1 --warmup 0`; FETCH_SIZE[KB] * 1024 * 2)",
        "config": cfg, "kernels": {}}
 lines = [l for l in open(src) if "FETCH_SIZE" in l]

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     // shared (every call but the sentence-chained ones): scalar-base addressing, no 64-bit vector arithmetic, no select per visit.
     // (In-kernel stamps of the first round-5 build: 2 956 clk from "position known" to "loads issued" - the address code in front of
     // the requests is paid in instruction fetch at the cold start of the launch, profiles/r05f_kernel_stamps_giga830M.log.)
-    if (__builtin_expect(share == 0 && a.fast != 3, 1)) {       // (a.fast == 3: the comparison arm of option attn_fast = 3, the general form)
+    if (__builtin_expect(share == 0, 1)) {       // (against the general form, in-process: -0.19 % +- 0.06 per step at giga830M, -0.38 % at giga330M, -0.40 % at 8 rows; profiles/r05g_ab_*.log)
       const char* kbu = reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.kcache) + (long)seq * a.cache_seq_stride + (long)h * a.S_max * hd);
       const char* vbu = reinterpret_cast<const char*>(reinterpret_cast<const WT*>(a.vcache) + (long)seq * a.cache_seq_stride + (long)h * a.S_max * hd);
       const unsigned lo = (unsigned)(li * EPL) * (unsigned)sizeof(WT);

@@ -423,7 +423,7 @@ hipError_t vc_launch_gemm_fr(const GemmArgs& a, int dtype, int pro, hipStream_t 
 size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype);
 int vc_gemm_fr_form(int rows, int N, int K, int dtype, int pro, int nsplit);   // 0 none, 1 one piece, 2 K in two halves
 hipError_t vc_launch_gemm_fr1(const GemmArgs& a, int dtype, int pro, int epi, hipStream_t s);   // one-row paired kernel (vc_gemm.hip row_gemm_fr1_k)
-int vc_gemm_fr1_ok(int N, int K, int dtype, int nw, int pair);
+int vc_gemm_fr1_ok(int N, int K, int dtype, int nw);
 hipError_t vc_launch_gemm_frp(const GemmArgs& a, int dtype, hipStream_t s);           // paired finished-row producer of 2..8-row passes (rows_gemm_frp_k)
 int vc_gemm_frp_ok(int rows, int N, int K, int dtype);
 extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production

@@ -144,9 +144,6 @@ struct vc_engine {
   // The NEXT layer's QKV tiles under the FFN-up launch (a first form of this option) lost 3.8 % at giga330M and left the tree.
   // f2_kb < 0 = by width: 16 KB at d >= 2048, 32 KB below.
   int gpf_blocks = 128, gpf_f2_kb = -1, gpf_f1_kb = 0;
-  // option "ffn1_lean" (round 5): the one-row FFN up-projection in row_gemm_fr1_k<PRO_LN, EPI_RELU> (the same 16-channel tiles and math as
-  // rows_gemm_k's one-row path, none of its other code in front of the weight burst)
-  int ffn1_lean = 1;
   // option "fr_pair" (round 5): the FFN down-projection of 2..8-row steps with two k-tiles per MFMA fragment (rows_gemm_frp_k) instead
   // of half-filled 8-channel fragments (rows_gemm_fr_k)
   int fr_pair = 1;
@@ -328,12 +325,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
 // too: -0.5 % +- 0.1 / -0.9 % +- 0.09 on two boxes, profiles/r05e_ab_330M.log, r05f_ab_330M.log.)
 inline bool fd_one(const vc_engine* e, int rows) {
   if (rows != 1 || e->fr_one == 0) return false;
-  return !e->layers.empty() && e->layers[0].W28 != nullptr && vc_gemm_fr1_ok(e->d, 4 * e->d, e->dtype, VC_FR_WAVES, 1) != 0;
-}
-
-// ONE-row steps: the FFN up-projection in the lean kernel (option "ffn1_lean"); it sums at most two slabs
-inline bool ffn1_lean_ok(const vc_engine* e, int rows) {
-  return rows == 1 && e->ffn1_lean && e->p_o.ksplit <= 2 && vc_gemm_fr1_ok(4 * e->d, e->d, e->dtype, 4, 0) != 0;
+  return !e->layers.empty() && e->layers[0].W28 != nullptr && vc_gemm_fr1_ok(e->d, 4 * e->d, e->dtype, VC_FR_WAVES) != 0;
 }
 
 inline int attn_nt_for(const vc_engine* e, int rows) { return e->attn_nt == 1 || (e->attn_nt == 2 && rows >= 2); }
@@ -535,9 +527,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.wg = ly.wg_1;
       g.out = e->act; g.out_ld = 4 * d;
-      if (ffn1_lean_ok(e, rs.n_rows) && !split_ln) {      // one row: the same LayerNorm fold in the lean kernel (vc_gemm.hip row_gemm_fr1_k)
-        HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_LN, EPI_RELU, s));
-      } else if (split_ln) {
+      if (split_ln) {
         g.x_out = e->xn;
         HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
         g.x_in = e->xn; g.x_ld = d;
@@ -976,11 +966,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->gpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->gpf_f2_kb = v1;                      // < 0: by width
     e->gpf_f1_kb = n >= 3 ? std::max(0, v2) : 0;
-  } else if (name == "ffn1_lean") { e->ffn1_lean = v0 ? 1 : 0;
   } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
   } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
-  } else if (name == "attn_fast") { e->attn_fast = (v0 == 3) ? 3 : (v0 ? 1 : 0);      // 3 = fast form with the general (64-bit, shared-prefix) addressing of the first K/V batch
+  } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
@@ -992,10 +981,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->ffn1_lean, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb);
   e->opt_state = buf;
 }
 
@@ -1168,7 +1157,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
       if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo8, VC_TH_RES))) return rc;
       if ((rc = pack_matrix(e, pre + "linear2.weight", d, 4 * d, &ly.W28, VC_TH_RES))) return rc;
       // (the one-row paired QKV kernel reads the folded matrix in 8-channel tiles: only where its form can run, i.e. behind fr_one)
-      if (vc_gemm_fr1_ok(3 * d, d, e->dtype, 4, 1)) {
+      if (vc_gemm_fr1_ok(3 * d, d, e->dtype, 4)) {
         const RawTensor* tg1;
         if ((rc = need(e, pre + "norm1.weight", {d}, &tg1))) return rc;
         if ((rc = pack_matrix(e, pre + "self_attn.in_proj_weight", 3 * d, d, &ly.Wqkv8, VC_TH_RES, tg1->dev))) return rc;
@@ -1288,7 +1277,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_FFN1_LEAN", "ffn1_lean"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1906,8 +1895,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
       g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit;
       g.prev_bias = ly.bo; g.has_prev_bias = 1; g.wg = ly.wg_1; g.out = e->act; g.out_ld = 4 * d;
-      if (ffn1_lean_ok(e, n_rows) && !split_ln) HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_LN, EPI_RELU, s));
-      else if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s)); }
+      if (split_ln) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s)); }
       else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_RELU, 1, 1, s));
     } else if (w == "ffn2" && fd_one(e, n_rows)) {     // one row, finished by the producer (forward_rows, option fr_one)
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);

@@ -929,29 +929,23 @@ hipError_t vc_launch_gemm_fr(const GemmArgs& a0, int dtype, int pro, hipStream_t
 // 8 channels over the whole K (d/8 workgroups), its 8 waves stream K/8 each in one burst, the row of X is staged once in LDS,
 // and the epilogue adds residual + bias and writes the finished channels: the consumer's LayerNorm prologue reads ONE 8 KB row.
 // NPW = fragment pairs per wave (K / KW / 16, rounded up; pairs beyond the matrix are zeroed).
-// EXACT: the matrix has exactly NW * NPW fragments (pairs) per tile (every real model width): no clamped addresses, no zeroed fragments.
-// NW waves per workgroup, each streaming NPW consecutive fragments (KB) in one burst.
-// PAIR: 8-channel tiles, a fragment = two k-tiles (above).  !PAIR: the ordinary 16-channel tiles of rows_gemm_k, a fragment = one k-tile -
-//   the same math as that kernel's one-row path, but nothing else in the code: no row loop, no gather, no chunk loop, one scalar-based
-//   address per load.  In-kernel stamps (profiles/r05f_kernel_stamps_giga830M.log): the first workgroup of the paired QKV launch has
-//   its loads and burst out 776 clk after entry, the FFN-up launch of rows_gemm_k 2 756 clk - straight-line code in front of the
-//   burst is paid in instruction-cache misses at the cold start of every launch.
+// EXACT: the matrix has exactly NW * NPW fragment pairs per tile (every real model width): no clamped addresses, no zeroed fragments.
+// NW waves per workgroup, each streaming NPW consecutive fragment pairs (KB) in one burst.
 // PRO_PLAIN / EPI_RES (the FFN down-projection): X = a.x_in (WT [K]), h_out = h_in + bias + W x.
 // PRO_LN / EPI_QKV (the QKV projection behind a FINISHED row, option "qkv_p8"): X = the row of h_in, centred and rounded (LayerNorm
 //   fold, rows_gemm_k above), epilogue = rstd / mean correction + folded bias, q to a buffer, K / V into the cache.  The 12-channel
 //   tiles of rows_gemm_k leave a quarter of every fragment's lanes idle: the QKV launch pays the vector-memory instructions of a
 //   33.6 MB stream for 25.2 MB; here every lane's 16 bytes are weights (3d / 8 workgroups: three per CU at d = 2048).
-// PRO_LN / EPI_RELU, NP = 2, !PAIR (the FFN up-projection, option "ffn1_lean"): X = LayerNorm fold of h + bias + the out-projection's
-//   (up to) two slabs; workgroup 0 also writes that sum (h') for the down-projection's epilogue.
-template <typename WT, int NPW, bool EXACT, int NW, int PRO, int EPI, int NP = 0, bool PAIR = true>
+// (A third form - the FFN up-projection on its ordinary 16-channel tiles with this kernel's lean code, LayerNorm fold of h + bias + two
+// slabs - was built at the end of round 5 on the reading that straight-line code in front of the burst is paid in instruction fetch
+// at every cold launch start: its first workgroup had the burst out after 2 000 clk instead of 2 756, and the step came out
+// +0.84 % +- 0.44 at giga830M, +0.21 % +- 0.06 at giga330M in in-process A/Bs, profiles/r05g_ab_*.log.  Not carried: the FFN-up
+// launch is bound by its stream, not by its prologue.)
+template <typename WT, int NPW, bool EXACT, int NW, int PRO, int EPI>
 __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
   using T = WTr<WT>;
-  static_assert((PRO == PRO_PLAIN && EPI == EPI_RES && PAIR) || (PRO == PRO_LN && EPI == EPI_QKV && PAIR && NP == 0) ||
-                (PRO == PRO_LN && EPI == EPI_RELU && !PAIR), "one-row lean forms");
-  static_assert(NP == 0 || NP == 2, "slabs the LayerNorm prologue requests");
-  constexpr int NTHR = 64 * NW, TH = PAIR ? VC_TH_RES : 16, SPT = 4 * TH;   // SPT = 16-byte units per (tile, k-tile)
-  constexpr int FK = PAIR ? 2 : 1;                  // k-tiles per fragment
-  constexpr int NFIN = TH / 4;                      // finishing threads (4 channels each)
+  static_assert((PRO == PRO_PLAIN && EPI == EPI_RES) || (PRO == PRO_LN && EPI == EPI_QKV), "one-row paired forms");
+  constexpr int NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;   // SPT = 16-byte units per (tile, k-tile) = 32
   extern __shared__ __attribute__((aligned(16))) char smem[];
   VC_KTS_DECL();
   VC_KTS(0);
@@ -959,30 +953,28 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nt = blockIdx.x;
   const int K = a.K;
-  const int nfr = a.KT / FK;                       // fragments per tile (KT even when PAIR: host contract)
+  const int npairs = a.KT >> 1;                    // KT even (host contract)
   char* xl = smem;                                 // the row: K elements of WT
   f32x4* red = reinterpret_cast<f32x4*>(smem + (size_t)K * sizeof(WT));     // [NW][4] partial quads
   float* stat = reinterpret_cast<float*>(red + NW * 4);                     // PRO_LN: [NW] row sums, then [NW][2] statistics of the rounded row
   const int active = *a.n_active;
   const int m = lane & 15, kg = lane >> 4;
-  // epilogue operands first (a wave's loads return in order): for the finishing threads, channels 4 t .. 4 t + 3 of the tile
-  const int nfin = nt * TH + 4 * (tid & (NFIN - 1));
+  // epilogue operands first (a wave's loads return in order): for the two finishing threads, channels 4 t .. 4 t + 3 of the tile
+  const int nfin = nt * TH + 4 * (tid & 1);
   float4 eres = make_float4(0.f, 0.f, 0.f, 0.f), ewg = eres;
   const float4 eb = *reinterpret_cast<const float4*>(a.bias + nfin);
   int epos = -1, eseq = 0;
   if constexpr (EPI == EPI_RES) eres = *reinterpret_cast<const float4*>(a.h_in + nfin);
-  else ewg = *reinterpret_cast<const float4*>(a.wg + nfin);
-  if constexpr (EPI == EPI_QKV) { epos = a.row_pos[0]; eseq = a.row_seq[0]; }
-  // the operand row: PLAIN - 16-byte units of X; LN - float4 columns of the residual row (+ bias + NP slabs)
-  // (a fragment = FK k-tiles = 64 FK bytes of WT = 4 FK units; K = NW * NPW fragments when EXACT)
-  constexpr int NXU = (NPW * 4 * FK + 63) / 64;                               // 16-byte units of the WT row per thread
-  constexpr int NXQ = ((sizeof(WT) == 2 ? 8 : 4) * FK * NPW + 63) / 64;       // float4 columns of the fp32 row per thread
-  static_assert(NXU <= 4 && (PRO != PRO_LN || NXQ <= (NP ? 2 : 4)), "the operand row fits its staging registers");
+  else { ewg = *reinterpret_cast<const float4*>(a.wg + nfin); epos = a.row_pos[0]; eseq = a.row_seq[0]; }
+  // the operand row: PLAIN - 16-byte units of X (a fragment pair covers 64 of them); LN - float4 columns of the residual row
+  // (a fragment pair = two k-tiles = 128 bytes of WT = 8 units; K = NW * NPW pairs when EXACT)
+  constexpr int NXU = (NPW * 8 + 63) / 64;                               // 16-byte units of the WT row per thread
+  constexpr int NXQ = ((sizeof(WT) == 2 ? 16 : 8) * NPW + 63) / 64;      // float4 columns of the fp32 row per thread
+  static_assert(NXU <= 4 && (PRO != PRO_LN || NXQ <= 4), "the operand row fits four staging registers per thread");
   const int units = K * (int)sizeof(WT) / 16, nq = K >> 2;
   // (explicit scalars: an indexed array is demoted to scratch memory by the compiler)
   uint4 xu0 = make_uint4(0u, 0u, 0u, 0u), xu1 = xu0, xu2 = xu0, xu3 = xu0;
   float4 xq0 = make_float4(0.f, 0.f, 0.f, 0.f), xq1 = xq0, xq2 = xq0, xq3 = xq0;
-  float4 pq0 = xq0, pq1 = xq0, sa0 = xq0, sa1 = xq0, sb0 = xq0, sb1 = xq0;     // NP = 2: previous bias, slab 0, slab 1 of columns 0 / 1
   if constexpr (PRO == PRO_PLAIN) {
     const char* src = reinterpret_cast<const char*>(a.x_in);
 #define VC_FR1_XLOAD(j, dst) if constexpr (NXU > (j)) dst = *reinterpret_cast<const uint4*>(src + (size_t)min(tid + (j) * NTHR, units - 1) * 16);
@@ -992,27 +984,15 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
 #define VC_FR1_QLOAD(j, dst) if constexpr (NXQ > (j)) dst = *reinterpret_cast<const float4*>(a.h_in + (size_t)min(tid + (j) * NTHR, nq - 1) * 4);
     VC_FR1_QLOAD(0, xq0) VC_FR1_QLOAD(1, xq1) VC_FR1_QLOAD(2, xq2) VC_FR1_QLOAD(3, xq3)
 #undef VC_FR1_QLOAD
-    if constexpr (NP == 2) {       // unconditional, clamped: the slabs a pass does not have are read and dropped by a select
-      const size_t c0 = (size_t)min(tid, nq - 1) * 4, c1 = (size_t)min(tid + NTHR, nq - 1) * 4;
-      const float* s1p = a.parts + (size_t)a.rows_cap * a.d;
-      pq0 = *reinterpret_cast<const float4*>(a.prev_bias + c0);
-      sa0 = *reinterpret_cast<const float4*>(a.parts + c0);
-      sb0 = *reinterpret_cast<const float4*>(s1p + c0);
-      if constexpr (NXQ > 1) {
-        pq1 = *reinterpret_cast<const float4*>(a.prev_bias + c1);
-        sa1 = *reinterpret_cast<const float4*>(a.parts + c1);
-        sb1 = *reinterpret_cast<const float4*>(s1p + c1);
-      }
-    }
   }
-  // the wave's whole share of the weights in one burst: fragment p of wave w = fragment (NPW w + p)
-  const int wunit = PAIR ? ((m >> 3) * SPT + kg * TH + (m & 7)) : (kg * TH + m);
-  const uint4* wbase = a.Wp + ((long)nt * a.KT + FK * NPW * wave) * SPT;    // wave-uniform: a wave streams NPW consecutive KB
+  // the wave's whole share of the weights in one burst: pair p of wave w = fragment pair (NPW w + p)
+  const int wunit = (m >> 3) * SPT + kg * TH + (m & 7);
+  const uint4* wbase = a.Wp + ((long)nt * a.KT + 2 * NPW * wave) * SPT;    // wave-uniform: a wave streams NPW consecutive KB
   uint4 wf[NPW];
 #pragma unroll
   for (int p = 0; p < NPW; ++p) {
-    const int gp = EXACT ? p : min(NPW * wave + p, nfr - 1) - NPW * wave;
-    wf[p] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + (long)gp * (FK * SPT) + wunit)));
+    const int gp = EXACT ? p : min(NPW * wave + p, npairs - 1) - NPW * wave;
+    wf[p] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wbase + (long)gp * (2 * SPT) + wunit)));
   }
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
@@ -1022,20 +1002,7 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
     VC_FR1_XPARK(0, xu0) VC_FR1_XPARK(1, xu1) VC_FR1_XPARK(2, xu2) VC_FR1_XPARK(3, xu3)
 #undef VC_FR1_XPARK
   } else {
-    if constexpr (NP == 2) {       // hn = h + prev_bias + slabs; workgroup 0 leaves it in h_out
-      const bool pb = a.has_prev_bias != 0, u0 = a.n_parts > 0, u1 = a.n_parts > 1;
-#define VC_FR1_ADD(X_, u_, v_) X_.x += u_ ? v_.x : 0.f; X_.y += u_ ? v_.y : 0.f; X_.z += u_ ? v_.z : 0.f; X_.w += u_ ? v_.w : 0.f;
-#define VC_FR1_SUM(X_, p_, s0_, s1_) VC_FR1_ADD(X_, pb, p_) VC_FR1_ADD(X_, u0, s0_) VC_FR1_ADD(X_, u1, s1_)      /* the order rows_gemm_k sums in */
-      VC_FR1_SUM(xq0, pq0, sa0, sb0)
-      if constexpr (NXQ > 1) { VC_FR1_SUM(xq1, pq1, sa1, sb1) }
-#undef VC_FR1_SUM
-#undef VC_FR1_ADD
-      if (a.h_out && blockIdx.x == 0) {
-        if (tid < nq) *reinterpret_cast<float4*>(a.h_out + (size_t)tid * 4) = xq0;
-        if constexpr (NXQ > 1) { if (tid + NTHR < nq) *reinterpret_cast<float4*>(a.h_out + (size_t)(tid + NTHR) * 4) = xq1; }
-      }
-    }
-    // LayerNorm fold of the row (see the top of this file): centred BEFORE it is rounded, statistics of the rounded values
+    // LayerNorm fold of the finished row (see the top of this file): centred BEFORE it is rounded, statistics of the rounded values
     float t = 0.f;
 #define VC_FR1_QSUM(j, v) if constexpr (NXQ > (j)) { if (tid + (j) * NTHR < nq) t += (v.x + v.y) + (v.z + v.w); }
     VC_FR1_QSUM(0, xq0) VC_FR1_QSUM(1, xq1) VC_FR1_QSUM(2, xq2) VC_FR1_QSUM(3, xq3)
@@ -1068,32 +1035,27 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
   __syncthreads();
   VC_KTS(3);
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  // B operand.  PAIR: column m = 0 reads x over k-tile 2 gp, column 1 over k-tile 2 gp + 1 (the other columns repeat these: cross
-  // terms); !PAIR: every column reads x over k-tile gp
-  const char* xcol = xl + ((size_t)(PAIR ? (m & 1) : 0) * T::KW + (size_t)kg * T::EPL) * sizeof(WT);
+  // B operand: column m = 0 reads x over k-tile 2 gp, column 1 over k-tile 2 gp + 1 (the other columns repeat these: cross terms)
+  const char* xcol = xl + ((size_t)(m & 1) * T::KW + (size_t)kg * T::EPL) * sizeof(WT);
 #pragma unroll
   for (int p = 0; p < NPW; ++p) {
     const int gpr = NPW * wave + p;
-    const int gp = EXACT ? gpr : min(gpr, nfr - 1);
-    const uint4 xf = *reinterpret_cast<const uint4*>(xcol + (size_t)gp * (FK * T::KW * sizeof(WT)));
+    const int gp = EXACT ? gpr : min(gpr, npairs - 1);
+    const uint4 xf = *reinterpret_cast<const uint4*>(xcol + (size_t)gp * (2 * T::KW * sizeof(WT)));
     uint4 w = wf[p];
-    if constexpr (!EXACT) { if (gpr >= nfr) w = make_uint4(0u, 0u, 0u, 0u); }
+    if constexpr (!EXACT) { if (gpr >= npairs) w = make_uint4(0u, 0u, 0u, 0u); }
     acc = mfma_frag(w, xf, acc, (WT*)nullptr);
   }
+  // D[n = 4 kg + r][m]: channels 0..3 / 4..7 over the even k-tiles sit in lanes (m = 0, kg = 0 / 1), over the odd ones in lanes
+  // (m = 1, kg = 2 / 3): four quads per wave
   VC_KTS(4);
-  // D[n = 4 kg + r][m].  PAIR: channels 0..3 / 4..7 over the even k-tiles sit in lanes (m = 0, kg = 0 / 1), over the odd ones in lanes
-  // (m = 1, kg = 2 / 3): four quads per wave, thread t finishes quads t and t + 2.  !PAIR: column 0 holds channels 4 kg .. 4 kg + 3
-  if constexpr (PAIR) { if (m == (kg >> 1) && m < 2) red[wave * 4 + kg] = acc; }
-  else { if (m == 0) red[wave * 4 + kg] = acc; }
+  if (m == (kg >> 1) && m < 2) red[wave * 4 + kg] = acc;
   __syncthreads();
   VC_KTS(5);
-  if (tid < NFIN) {          // thread t finishes channels 4 t .. 4 t + 3 of the tile, the waves' quads in a fixed order
+  if (tid < 2) {             // thread t finishes channels 4 t .. 4 t + 3: quads t and t + 2 of every wave, in a fixed order
     f32x4 sum = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int w = 0; w < NW; ++w) {
-      if constexpr (PAIR) sum += red[w * 4 + tid] + red[w * 4 + tid + 2];
-      else sum += red[w * 4 + tid];
-    }
+    for (int w = 0; w < NW; ++w) sum += red[w * 4 + tid] + red[w * 4 + tid + 2];
     if constexpr (EPI == EPI_RES) {
       const f32x4 o = {eres.x + eb.x + sum[0], eres.y + eb.y + sum[1], eres.z + eb.z + sum[2], eres.w + eb.w + sum[3]};
       store4(a.h_out + nfin, o);
@@ -1107,57 +1069,53 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
       const float rstd = 1.0f / sqrtf(var + 1e-5f);      // eps 1e-5 (transformer.py:30)
       sum[0] = rstd * (sum[0] - mean * ewg.x); sum[1] = rstd * (sum[1] - mean * ewg.y);
       sum[2] = rstd * (sum[2] - mean * ewg.z); sum[3] = rstd * (sum[3] - mean * ewg.w);
-      gemm_epilogue<WT, EPI>(a, sum, 0, nfin, 0, 0, 1, eb, epos, eseq);
+      gemm_epilogue<WT, EPI_QKV>(a, sum, 0, nfin, 0, 0, 1, eb, epos, eseq);
     }
   }
   VC_KTS(6);
   VC_KTS_FLUSH();
 }
-template <typename WT, int NPW, int NW, int PRO, int EPI, int NP = 0, bool PAIR = true>
+template <typename WT, int NPW, int NW, int PRO, int EPI>
 static hipError_t launch_fr1_n(const GemmArgs& a, hipStream_t s) {
-  auto kern = (a.KT == (PAIR ? 2 : 1) * NW * NPW) ? row_gemm_fr1_k<WT, NPW, true, NW, PRO, EPI, NP, PAIR> : row_gemm_fr1_k<WT, NPW, false, NW, PRO, EPI, NP, PAIR>;
+  auto kern = (a.KT == 2 * NW * NPW) ? row_gemm_fr1_k<WT, NPW, true, NW, PRO, EPI> : row_gemm_fr1_k<WT, NPW, false, NW, PRO, EPI>;
   const size_t lds = (size_t)a.K * sizeof(WT) + (size_t)NW * 4 * sizeof(f32x4) + (size_t)NW * 3 * sizeof(float);
   ++vc_launch_counts[VC_LC_ROW_GEMM_FR1];
   hipLaunchKernelGGL(kern, dim3(a.n_tiles), dim3(64 * NW), lds, s, a);
   return hipGetLastError();
 }
-// 1 when the one-row lean kernel can take an [N x K] matrix in this dtype with `nw` waves per workgroup (the engine's planning and
-// the launcher agree on it).  pair = 1: 8-channel tiles, two k-tiles per fragment; 0: 16-channel tiles, one
-int vc_gemm_fr1_ok(int N, int K, int dtype, int nw, int pair) {
+// 1 when the one-row paired kernel can take an [N x K] matrix in this dtype with `nw` waves per workgroup (the engine's planning and
+// the launcher agree on it)
+int vc_gemm_fr1_ok(int N, int K, int dtype, int nw) {
   const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16, esz = dtype == VC_DTYPE_BF16 ? 2 : 4;
-  const int th = pair ? VC_TH_RES : 16, fk = pair ? 2 : 1;
-  if (N % th != 0 || K % (fk * KW) != 0 || (nw != 4 && nw != 8)) return 0;
-  const int nfr = K / KW / fk, npw = (nfr + nw - 1) / nw;
+  if (N % VC_TH_RES != 0 || K % (2 * KW) != 0 || (nw != 4 && nw != 8)) return 0;
+  const int npairs = K / KW / 2, npw = (npairs + nw - 1) / nw;
   int cap = 1;
   while (cap < npw) cap <<= 1;
-  if (cap > (nw == 4 ? 16 : 32) || (long)K * esz > 64L * 1024) return 0;      // a wave's fragments fit its registers; the row fits its staging registers
-  if (!pair && (long)K > 2L * 64 * nw * 4) return 0;                            // the slab form stages at most two float4 columns per thread
+  if (cap > (nw == 4 ? 16 : 32) || (long)K * esz > 64L * 1024) return 0;      // a wave's fragments fit its registers; the row <= 4 staging registers per thread
   return 1;
 }
-// ONE row.  pro / epi = PRO_PLAIN / EPI_RES: h_out[n] = h_in[n] + bias[n] + sum_k W[n][k] x[k] (a.x_in = the row, WT [K]; 8 waves, a.Wp =
-// the 8-channel-tile image); PRO_LN / EPI_QKV: the QKV projection of the finished row a.h_in (LayerNorm fold; 4 waves, or 8 with a.mt == 8;
-// 8-channel-tile image); PRO_LN / EPI_RELU: the FFN up-projection of h_in + prev_bias + up to two slabs (4 waves, the 16-channel image).
+// ONE row.  pro / epi = PRO_PLAIN / EPI_RES: h_out[n] = h_in[n] + bias[n] + sum_k W[n][k] x[k] (a.x_in = the row, WT [K]; 8 waves);
+// PRO_LN / EPI_QKV: the QKV projection of the finished row a.h_in (LayerNorm fold; 4 waves).  a.Wp = the 8-channel-tile image.
 hipError_t vc_launch_gemm_fr1(const GemmArgs& a0, int dtype, int pro, int epi, hipStream_t s) {
-  const bool qkv = pro == PRO_LN && epi == EPI_QKV, up = pro == PRO_LN && epi == EPI_RELU;
-  if (!qkv && !up && !(pro == PRO_PLAIN && epi == EPI_RES)) return hipErrorInvalidValue;
-  const int nw = up ? 4 : (qkv && a0.mt != 8) ? 4 : VC_FR_WAVES;        // (GemmArgs.mt == 8: the QKV form with eight waves - the comparison arm of option qkv_p8 = 2)
-  if (!vc_gemm_fr1_ok(a0.N, a0.K, dtype, nw, up ? 0 : 1) || a0.n_rows != 1 || (up && a0.n_parts > 2)) return hipErrorInvalidValue;
+  const bool qkv = pro == PRO_LN && epi == EPI_QKV;
+  if (!qkv && !(pro == PRO_PLAIN && epi == EPI_RES)) return hipErrorInvalidValue;
+  const int nw = (qkv && a0.mt != 8) ? 4 : VC_FR_WAVES;        // (GemmArgs.mt == 8: the QKV form with eight waves - the comparison arm of option qkv_p8 = 2)
+  if (!vc_gemm_fr1_ok(a0.N, a0.K, dtype, nw) || a0.n_rows != 1) return hipErrorInvalidValue;
   GemmArgs a = a0;
   const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16;
-  a.n_tiles = a.N / (up ? 16 : VC_TH_RES);
+  a.n_tiles = a.N / VC_TH_RES;
   a.KT = a.K / KW;
-  const int nfr = a.KT / (up ? 1 : 2), npw = (nfr + nw - 1) / nw;
+  const int npairs = a.KT / 2, npw = (npairs + nw - 1) / nw;
   int cap = 1;
   while (cap < npw) cap <<= 1;
 #define VC_FR1_CASE(P_) case P_:                                                                                        \
-    if (up) return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, 4, PRO_LN, EPI_RELU, 2, false>(a, s) : launch_fr1_n<float, P_, 4, PRO_LN, EPI_RELU, 2, false>(a, s);   \
     if (qkv && nw == 8) return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, 8, PRO_LN, EPI_QKV>(a, s) : launch_fr1_n<float, P_, 8, PRO_LN, EPI_QKV>(a, s);   \
     if (qkv) return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, 4, PRO_LN, EPI_QKV>(a, s) : launch_fr1_n<float, P_, 4, PRO_LN, EPI_QKV>(a, s);   \
     return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s) : launch_fr1_n<float, P_, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s);
   switch (cap) {
     VC_FR1_CASE(1) VC_FR1_CASE(2) VC_FR1_CASE(4) VC_FR1_CASE(8) VC_FR1_CASE(16)
     case 32:
-      if (qkv || up) return hipErrorInvalidValue;      // (K <= 2048 there: at most 16 fragments per wave of four)
+      if (qkv) return hipErrorInvalidValue;      // (K <= 2048 there: at most 16 pairs per wave of four)
       return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, 32, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s) : launch_fr1_n<float, 32, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s);
     default: return hipErrorInvalidValue;
   }
