@@ -1,4 +1,5 @@
-"""Prefill attention (tile_attn*_k) at several pass sizes; VC_TILE_ATTN picks the form (1 = round 2, 2 = pipelined, 8 = 8 waves).
+"""Prefill attention at several pass sizes; VC_TILE_ATTN=k[,min_rows] picks the kernel (1 = tile_attn_k: 16 query rows per wave; 2 = tile_attn64_k:
+64 query rows per workgroup, from min_rows prompt rows - the option `tile_attn` of include/vc_engine.h).
 usage: python tools/pf_attn_probe.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

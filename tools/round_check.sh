@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 5, GPU call 6: the whole GPU suite on the current library, the default bench line, rocprofv3 kernel trace + FETCH_SIZE pass of
+# The whole-state check of a round (called by tools/next_round.sh): GPU suite, default bench line, rocprofv3 kernel trace + FETCH_SIZE pass of
 # the same command, in-kernel stamps (twin library), leftover A/Bs (giga330M finished rows, attention split counts), 8-row kernel trace
 set -u
 export TMPDIR=/tmp
