@@ -4,11 +4,13 @@
 set -u
 export TMPDIR=/tmp
 O=gpurun_out
-echo "== probe"; timeout 200 python tools/box_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/r05f_box_probe.log
-echo "== whole GPU suite"; timeout 700 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $O/r05f_pytest_gpu.log
-echo "== default bench line"; timeout 900 python bench.py 2>/dev/null | tail -1 > $O/r05f_bench.json.log; python - <<'PY'
+TAG=${TAG:-chk}      # file-name prefix of everything written under gpurun_out/
+export TAG
+echo "== probe"; timeout 200 python tools/box_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_box_probe.log
+echo "== whole GPU suite"; timeout 700 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $O/${TAG}_pytest_gpu.log
+echo "== default bench line"; timeout 900 python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench.json.log; python - <<'PY'
 import json
-d=json.loads(open("gpurun_out/r05f_bench.json.log").read())
+d=json.loads(open("gpurun_out/" + __import__("os").environ.get("TAG", "chk") + "_bench.json.log").read())
 print({k:d[k] for k in ("value","ms_per_step","decode_ms_per_token_step","prefill_ms")}, d["roofline"]["frac"], d["roofline"]["kernel"][:60], d["roofline"]["in_situ"], d["decode_step"])
 print("ab", {k:d["ab"].get(k) for k in ("knob","A_ms_median","B_ms_median","median_delta_pct","spread_pct")})
 for r in d.get("ab_more", []): print("  ", {k:r.get(k) for k in ("knob","A","B","median_delta_pct","spread_pct","error")})
@@ -16,12 +18,11 @@ print("box", d.get("box"), "sampler", d.get("sampler"))
 print({k:(v.get("value"), v.get("decode_ms_per_step"), v.get("hbm_frac_in_loop"), v.get("error")) for k,v in d.get("configs",{}).items()})
 print(d["kernels"])
 PY
-echo "== rocprof kernel trace"; bash tools/prof_decode.sh r05f --no-codec --ab none --no-configs; head -14 $O/r05f_rocprof_kernel_stats.txt
-python tools/in_situ_to_json.py $O/r05f_rocprof_kernel_stats.txt $O/in_situ.json > /dev/null
-echo "== FETCH_SIZE pass"; bash tools/prof_pmc.sh r05f_fetch FETCH_SIZE --ab none --no-configs; head -12 $O/r05f_fetch_pmc.txt
-python tools/pmc_to_json.py $O/r05f_fetch_pmc.txt $O/pmc_traffic.json > /dev/null
-echo "== in-kernel stamps"; timeout 200 python tools/kernel_ts.py giga830M 1 2>&1 | grep -v amdgpu.ids | tee $O/r05f_kernel_stamps_giga830M.log
-echo "== giga330M"; timeout 300 python tools/ab_sweep.py --preset giga330M fr_one=1:2 attn_blocks1=256:64 2>&1 | grep -v amdgpu.ids | tee $O/r05f_ab_330M.log
-echo "== giga830M"; timeout 300 python tools/ab_sweep.py attn_blocks1=256:64 2>&1 | grep -v amdgpu.ids | tee $O/r05f_ab_830M.log
-echo "== 8 rows"; timeout 300 python tools/ab_sweep.py --batch 8 attn_blocks=512:256 attn_blocks=512:1024 2>&1 | grep -v amdgpu.ids | tee $O/r05f_ab_b8.log
-bash tools/prof_decode.sh r05f_b8 --batch 8 --no-codec --ab none; head -12 $O/r05f_b8_rocprof_kernel_stats.txt
+echo "== rocprof kernel trace"; bash tools/prof_decode.sh ${TAG} --no-codec --ab none --no-configs; head -14 $O/${TAG}_rocprof_kernel_stats.txt
+python tools/in_situ_to_json.py $O/${TAG}_rocprof_kernel_stats.txt $O/in_situ.json > /dev/null
+echo "== FETCH_SIZE pass"; bash tools/prof_pmc.sh ${TAG}_fetch FETCH_SIZE --ab none --no-configs; head -12 $O/${TAG}_fetch_pmc.txt
+python tools/pmc_to_json.py $O/${TAG}_fetch_pmc.txt $O/pmc_traffic.json > /dev/null
+echo "== in-kernel stamps"; timeout 200 python tools/kernel_ts.py giga830M 1 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_kernel_stamps_giga830M.log
+echo "== giga330M"; timeout 300 python tools/ab_sweep.py --preset giga330M fr_one=0:1 gemm_pf=0:128,-1,0 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_330M.log
+echo "== 8 rows"; timeout 300 python tools/ab_sweep.py --batch 8 fr_pair=0:1 finished_rows=0:16 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_b8.log
+bash tools/prof_decode.sh ${TAG}_b8 --batch 8 --no-codec --ab none; head -12 $O/${TAG}_b8_rocprof_kernel_stats.txt
