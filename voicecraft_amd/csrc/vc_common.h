@@ -296,7 +296,6 @@ struct GemmArgs {
   PfSeg pf;                 // ln_rows_k, rows_gemm_k (one tile per workgroup), row_gemm_fr1_k: pf_blocks extra workgroups
   int pf_blocks;            // prefetch the head of this matrix's tiles (vc_prefetch_tiles); 0 = none
   PfSeg pf2;                // rows_gemm_k: a second matrix for the same role (len 0 = unused)
-  int* zero_word;           // row_gemm_fr1_k: workgroup 0 stores 0 here (the arrival counter of the fused attention + out-projection launch behind it); null = none
 };
 
 struct AttnArgs {
@@ -425,8 +424,6 @@ size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype);
 int vc_gemm_fr_form(int rows, int N, int K, int dtype, int pro, int nsplit);   // 0 none, 1 one piece, 2 K in two halves
 hipError_t vc_launch_gemm_fr1(const GemmArgs& a, int dtype, int pro, int epi, hipStream_t s);   // one-row paired kernel (vc_gemm.hip row_gemm_fr1_k)
 int vc_gemm_fr1_ok(int N, int K, int dtype, int nw);
-hipError_t vc_launch_fused_ao(const AttnArgs& at, const GemmArgs& og, int ksplit, int* sync, int* err, int dtype, hipStream_t s);   // vc_fused.hip
-int vc_fused_ao_ok(int d, int H, int nsplit, int ksplit, int dtype);
 hipError_t vc_launch_gemm_frp(const GemmArgs& a, int dtype, hipStream_t s);           // paired finished-row producer of 2..8-row passes (rows_gemm_frp_k)
 int vc_gemm_frp_ok(int rows, int N, int K, int dtype);
 extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production
@@ -434,7 +431,7 @@ extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill blo
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one
 // they compared with the oracle.
 enum { VC_LC_ROWS_GEMM = 0, VC_LC_MT2 = 1, VC_LC_MT4 = 2, VC_LC_BLK64 = 3, VC_LC_BLK128_SBS = 4, VC_LC_BLK128_2X2 = 5,
-       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_ROWS_GEMM_FRP = 15, VC_LC_FUSED_AO = 16, VC_LC_N = 24 };
+       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_ROWS_GEMM_FRP = 15, VC_LC_N = 16 };
 extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);

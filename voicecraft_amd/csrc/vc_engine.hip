@@ -144,10 +144,6 @@ struct vc_engine {
   // The NEXT layer's QKV tiles under the FFN-up launch (a first form of this option) lost 3.8 % at giga330M and left the tree.
   // f2_kb < 0 = by width: 16 KB at d >= 2048, 32 KB below.
   int gpf_blocks = 128, gpf_f2_kb = -1, gpf_f1_kb = 0;
-  // option "fuse_ao" (round 5): one-row steps run the decode attention and the out-projection as ONE launch (vc_fused.hip: the
-  // out-projection's workgroups request their weights at once and wait on a device-scope arrival counter for the attention partials)
-  int fuse_ao = 0;
-  int* fuse_sync = nullptr;             // that launch's arrival counter (zeroed by the QKV launch in front of it)
   // option "fr_pair" (round 5): the FFN down-projection of 2..8-row steps with two k-tiles per MFMA fragment (rows_gemm_frp_k) instead
   // of half-filled 8-channel fragments (rows_gemm_fr_k)
   int fr_pair = 1;
@@ -446,9 +442,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   // it and leaves h' in hA for the down-projection's epilogue
   const bool fd = fd_one(e, rs.n_rows);
   e->finished_rows_h = fd;
-  // ... and attention + out-projection as one launch (option fuse_ao): behind the paired QKV launch only - it zeroes the arrival counter
-  const bool fz = fd && e->fuse_ao && rs.n_active != nullptr && e->qkv_p8 && !e->layers.empty() && e->layers[0].Wqkv8 && !split_ln &&
-                  vc_fused_ao_ok(d, e->H, rs.nsplit, e->p_o.ksplit, e->dtype) != 0;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
     const float* h_res = (l == 0) ? rs.h_in : e->hB;
@@ -467,7 +460,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         // the row entering the layer is finished (layer 0: the sampler's dec_h row): 8-channel tiles, two k-tiles per fragment
         g.Wp = ly.Wqkv8;
         g.mt = e->qkv_p8 == 2 ? 8 : 0;
-        g.zero_word = fz ? e->fuse_sync : nullptr;
         HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_LN, EPI_QKV, s));
       } else if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
@@ -478,19 +470,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LN, EPI_QKV, 1, 1, s));
       }
     }
-    if (fz) {  // attention and out-projection as ONE launch (vc_fused.hip)
-      AttnArgs a;
-      memset(&a, 0, sizeof a);
-      a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc;
-      a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
-      a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7; a.d = d; a.nsplit = rs.nsplit;
-      a.scale = 1.0f / sqrtf((float)e->hd);
-      a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = 1;
-      a.n_active = rs.n_active; a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
-      GemmArgs g = base_args(e, rs, e->p_o, d, d);
-      g.Wp = ly.Wo; g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit; g.part_out = e->parts;
-      HIPCHK(e, vc_launch_fused_ao(a, g, e->p_o.ksplit, e->fuse_sync, e->err_flag, e->dtype, s));
-    } else {
     {  //                                                                 
       AttnArgs a;
       memset(&a, 0, sizeof a);
@@ -540,7 +519,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         g.pf_blocks = e->gpf_blocks;
       }
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
-    }
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
@@ -952,8 +930,6 @@ int check_err_flag(vc_engine* e, hipStream_t s) {
     (void)hipMemsetAsync(e->err_flag, 0, sizeof(int), s);   // already on the error path
     if (bits & 2)
       return fail(e, VC_EINVAL, "shared_text_prefix: a sequence's text differs from sequence 0's inside the shared prefix");
-    if (bits & 4)
-      return fail(e, VC_EHIP, "fused attention + out-projection launch: a consumer gave up waiting for the attention partials (option fuse_ao)");
     return fail(e, VC_EINVAL, "token id out of range in x or y (text rows %d, audio vocab %d)", e->cfg.text_rows, e->V);
   }
   return VC_OK;
@@ -990,7 +966,6 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->gpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
     if (n >= 2) e->gpf_f2_kb = v1;                      // < 0: by width
     e->gpf_f1_kb = n >= 3 ? std::max(0, v2) : 0;
-  } else if (name == "fuse_ao") { e->fuse_ao = v0 ? 1 : 0;
   } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
   } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
@@ -1006,10 +981,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->fuse_ao, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb);
   e->opt_state = buf;
 }
 
@@ -1276,8 +1251,6 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->share_len, (size_t)4))) return rc;
-  if ((rc = dalloc(e, &e->fuse_sync, (size_t)4))) return rc;
-  HIPCHK(e, hipMemset(e->fuse_sync, 0, 16));
   HIPCHK(e, hipMemset(e->share_len, 0, 16));
   if ((rc = dalloc(e, &e->samp, (size_t)e->NS * (VC_MAX_CODEBOOKS + 2)))) return rc;
   if ((rc = dalloc(e, &e->cond, (size_t)e->NS))) return rc;
@@ -1304,7 +1277,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_FUSE_AO", "fuse_ao"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1409,7 +1382,6 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
-  if (e->fuse_ao && (rc = check_err_flag(e, s))) return rc;   // (the fused launch's consumers report a wait they gave up here)
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];
@@ -1580,7 +1552,6 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState), hipMemcpyDeviceToHost, s));
   HIPCHK(e, hipStreamSynchronize(s));
-  if (e->fuse_ao && (rc = check_err_flag(e, s))) return rc;   // (the fused launch's consumers report a wait they gave up here)
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];

@@ -997,9 +997,6 @@ __global__ __launch_bounds__(64 * NW) void row_gemm_fr1_k(const GemmArgs a) {
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
   VC_KTS(1);
-  if constexpr (EPI == EPI_QKV) {      // (the fused attention + out-projection launch behind this one counts arrivals from zero)
-    if (a.zero_word && blockIdx.x == 0 && tid == 0) *a.zero_word = 0;
-  }
   if constexpr (PRO == PRO_PLAIN) {
 #define VC_FR1_XPARK(j, val) if constexpr (NXU > (j)) { if (tid + (j) * NTHR < units) *reinterpret_cast<uint4*>(xl + (size_t)(tid + (j) * NTHR) * 16) = val; }
     VC_FR1_XPARK(0, xu0) VC_FR1_XPARK(1, xu1) VC_FR1_XPARK(2, xu2) VC_FR1_XPARK(3, xu3)
