@@ -107,43 +107,3 @@ def test_one_row_finished_row_producer_writes_residual_plus_bias():
     # (the microbenchmark's launch i runs on layer i % L: its single timed launch is layer 0's)
     b2 = sd["decoder.layers.0.linear2.bias"]
     assert torch.allclose(hB, b2, atol=0, rtol=0), float((hB - b2).abs().max())
-
-
-@pytest.mark.parametrize("preset", ["tiny", "tiny128", "tiny_h16"])
-@pytest.mark.parametrize("dtype", ["fp32", "bf16"])
-def test_one_row_fused_qkv_attention(preset, dtype):
-    """Option `fuse_qa`: the QKV projection and the attention of a one-row step as ONE launch (`qa_row_k`, vc_qa.hip): every
-    (head, split) workgroup computes its own head's q, K / V of the new position come from a second role of the same grid and enter
-    the out-projection's merge as a ninth partial.  The same sums in a different order: fp32 tokens equal the oracle's (captured
-    graph and eager), bf16 teacher-forced logits within the bf16 tolerance of the oracle's and next to the two-launch path's; the
-    census tells which form ran, and the K/V cache the fused launch appended serves a later two-launch call unchanged."""
-    from voicecraft_amd import synth
-    from voicecraft_amd.engine import VoiceCraftEngine
-    a = synth.make_args(preset)
-    sd = synth.make_state_dict(a, seed=8)
-    x, xl, y = synth.random_prompt(a, 6, 21, seed=41)
-    want, tr = _oracle_run(a, sd, x, xl, y)
-    forced = torch.stack([t["tokens"] for t in tr]).numpy()
-    L = a.num_decoder_layers
-    for use_graph in (True, False):
-        eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype=dtype, max_seqs=1, max_positions=256, use_graph=use_graph)
-        out = {}
-        for fq in (0, 1, 0, 1):
-            eng.set_option("fuse_qa", fq)
-            assert eng.options().split("|r1=")[1].split("|")[0].split(",")[4] == str(fq)
-            c0 = eng.launch_counts()
-            if dtype == "fp32":
-                got = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
-                assert np.array_equal(got, want), (fq, use_graph)
-            else:
-                _, _, lg = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3, _forced=forced, _logit_steps=len(tr))
-                lg = lg.cpu().numpy()
-                if fq in out:
-                    assert np.array_equal(out[fq], lg)          # (deterministic, run to run)
-                out[fq] = lg
-            c = _delta(eng.launch_counts(), c0)
-            assert (c["qa_row"] >= L) == bool(fq), (fq, c)
-        if dtype == "bf16":
-            want_lg = torch.stack([t["logits"][0] for t in tr]).numpy()
-            assert rel_l2(out[1], want_lg).max() <= 2e-2
-            assert np.abs(out[0] - out[1])[np.abs(out[0]) < 1e3].max() < 0.25

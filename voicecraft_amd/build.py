@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libvcengine.so"
-SOURCES = ["vc_gemm.hip", "vc_gemm_pf.hip", "vc_qa.hip", "vc_attn.hip", "vc_tokens.hip", "vc_engine.hip", "vc_codec.hip"]
+SOURCES = ["vc_gemm.hip", "vc_gemm_pf.hip", "vc_attn.hip", "vc_tokens.hip", "vc_engine.hip", "vc_codec.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 
 

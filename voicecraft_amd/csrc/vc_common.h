@@ -285,10 +285,7 @@ struct GemmArgs {
   void* out;                // RELU/GELU: WT [r][out_ld]; LOGITS: float [r][group][N]
   int out_ld;
   int out_group_stride;
-  float* q_out;             // QKV: [r][d]  (PRO_ATT with kv_new: read - q of the one row)
-  const void* kv_new;       // PRO_ATT, one row behind the fused QKV + attention launch (vc_qa.hip): WT [2][d], K and V of the position being
-                            // written - the merge takes it as a ninth partial (score q . k * att_scale, weight 1); null = the cache holds it already
-  float att_scale;          // 1 / sqrt(head_dim), with kv_new
+  float* q_out;             // QKV: [r][d]
   void* kcache;             // QKV: WT [seq][H][S_max][hd]
   void* vcache;
   long cache_seq_stride;    // H*S_max*hd
@@ -327,31 +324,6 @@ struct AttnArgs {
   int nt;                   // rows_attn_k: K/V rows requested with the non-temporal hint
   int fast;                 // rows_attn_k: 1 = the round-5 form (wave maximum before any exponential; bf16 mode: hardware exp2)
 };
-
-// QKV projection + decode attention of a one-row step as one launch (vc_qa.hip, option "fuse_qa")
-struct QaArgs {
-  const uint4* Wp;          // the LayerNorm-folded QKV matrix in 8-channel tiles (Layer.Wqkv8)
-  const float* bias;        // [3 d] folded bias
-  const float* wg;          // [3 d] row sums of the folded weights
-  const float* h_in;        // the finished residual row [d]
-  int d, KT;                // K = d; KT = d / KW (set by the launcher)
-  void* kcache;             // WT [seq][H][S_max][hd]
-  void* vcache;
-  long cache_seq_stride;
-  int S_max, H, hd, hd_shift, nsplit;     // (hd, hd_shift set by the launcher)
-  float inv_nsplit, scale;
-  const int* row_seq;
-  const int* row_pos;
-  const int* n_active;      // never null
-  const int* share_len;     // never null (AttnArgs)
-  float* att_o;             // [H][nsplit][hd] partials over the CACHED positions [0, pos)
-  float* att_ml;
-  float* q_out;             // [d] fp32: the out-projection scores the new position with it
-  void* kv_new;             // WT [2][d]: K and V of the new position as the cache holds them
-  int n_attn;               // H * nsplit (set by the launcher)
-};
-int vc_qa_row_ok(int d, int H, int nsplit, int dtype);
-hipError_t vc_launch_qa_row(const QaArgs& a, int dtype, hipStream_t s);
 
 struct Segment {            // one run of columns of the rearranged audio sequence
   int col0, ncols;          // first column and number of columns it contributes
@@ -459,7 +431,7 @@ extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill blo
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one
 // they compared with the oracle.
 enum { VC_LC_ROWS_GEMM = 0, VC_LC_MT2 = 1, VC_LC_MT4 = 2, VC_LC_BLK64 = 3, VC_LC_BLK128_SBS = 4, VC_LC_BLK128_2X2 = 5,
-       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_ROWS_GEMM_FRP = 15, VC_LC_QA_ROW = 16, VC_LC_N = 24 };
+       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_ROWS_GEMM_FRP = 15, VC_LC_N = 16 };
 extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);

@@ -150,11 +150,6 @@ struct vc_engine {
   // option "qkv_p8" (round 5): one-row steps behind a finished row (fr_one) run the QKV projection on 8-channel tiles with two k-tiles
   // per MFMA fragment (row_gemm_fr1_k<PRO_LN, EPI_QKV>: every lane's 16 bytes are weights) instead of 12-channel tiles
   int qkv_p8 = 1;
-  // option "fuse_qa" (round 5): one-row steps behind a finished row run the QKV projection and the attention as ONE launch (vc_qa.hip:
-  // every (head, split) workgroup computes its own head's q while its K/V requests are in flight; K / V of the new position come from a
-  // second role of the same grid and enter the out-projection's merge as a ninth partial)
-  int fuse_qa = 0;
-  char* kv_new = nullptr;               // WT [2][d]: K and V of the position being written (that launch -> the out-projection)
   // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
   // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
   int ln_trim = 1;
@@ -447,22 +442,9 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   // it and leaves h' in hA for the down-projection's epilogue
   const bool fd = fd_one(e, rs.n_rows);
   e->finished_rows_h = fd;
-  // ... and QKV projection + attention as one launch (option fuse_qa; vc_qa.hip)
-  const bool fq = fd && e->fuse_qa && rs.n_active != nullptr && e->attn_fast && !e->layers.empty() && e->layers[0].Wqkv8 && !split_ln &&
-                  vc_qa_row_ok(d, e->H, rs.nsplit, e->dtype) != 0 && (e->nt_decode & NT_O) != 0;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
     const float* h_res = (l == 0) ? rs.h_in : e->hB;
-    if (fq) {
-      QaArgs qa;
-      memset(&qa, 0, sizeof qa);
-      qa.Wp = ly.Wqkv8; qa.bias = ly.bqkv; qa.wg = ly.wg_qkv; qa.h_in = h_res; qa.d = d;
-      qa.kcache = ly.kc; qa.vcache = ly.vc; qa.cache_seq_stride = (long)e->H * e->S_max * e->hd;
-      qa.S_max = e->S_max; qa.H = e->H; qa.nsplit = rs.nsplit; qa.scale = 1.0f / sqrtf((float)e->hd);
-      qa.row_seq = rs.row_seq; qa.row_pos = rs.row_pos; qa.n_active = rs.n_active; qa.share_len = e->share_len;
-      qa.att_o = e->att_o; qa.att_ml = e->att_ml; qa.q_out = e->q; qa.kv_new = e->kv_new;
-      HIPCHK(e, vc_launch_qa_row(qa, e->dtype, s));
-    } else {
     {  // x = LN1(h); q,k,v = Wqkv x + b ; K/V go straight into the cache
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv;
@@ -513,13 +495,11 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       }
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
-    }
     {  // out-projection of the merged attention output -> split-K partial slabs
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo; nt_bit(e, g, NT_O);
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
-      if (fq) { g.q_out = e->q; g.kv_new = e->kv_new; g.att_scale = 1.0f / sqrtf((float)e->hd); }     // the new position: the merge's ninth partial
       const int f2_kb = e->gpf_f2_kb < 0 ? (d >= 2048 ? 16 : 32) : e->gpf_f2_kb;
       if (e->gpf_blocks > 0 && f2_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr) {
         // prefetch role: the head of every FFN down-projection tile of this layer, as the launch after next will read them
@@ -989,7 +969,6 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
   } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
-  } else if (name == "fuse_qa") { e->fuse_qa = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
@@ -1002,10 +981,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->fuse_qa, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb);
   e->opt_state = buf;
 }
 
@@ -1255,7 +1234,6 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->parts, (size_t)VC_MAX_KSPLIT * VC_SLAB_ROWS * d))) return rc;
   if ((rc = dalloc(e, &e->att_o, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * e->hd))) return rc;     // split partials: decode-size passes only
   if ((rc = dalloc(e, &e->att_ml, (size_t)VC_ROWS * e->H * VC_MAX_NSPLIT * 2))) return rc;
-  if ((rc = dalloc(e, &e->kv_new, (size_t)2 * d * e->esz))) return rc;
   char* tmp;
   if ((rc = dalloc(e, &tmp, (size_t)VC_MAX_ROWS * 4 * d * e->esz))) return rc;
   e->act = tmp;
@@ -1299,7 +1277,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_FUSE_QA", "fuse_qa"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";

@@ -148,11 +148,8 @@ template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true, b
 __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   static_assert(NTW == 1 || PRO == PRO_LNW, "two tiles per workgroup: finished-row consumers only");
-  // (PRO_ATT re-uses the parameter: NP = 1 is the one-row out-projection behind the fused QKV + attention launch, whose merge takes the
-  // position being written as a ninth partial - vc_qa.hip)
-  constexpr bool QN = PRO == PRO_ATT && NP == 1;
-  static_assert(NP == VC_MAX_KSPLIT || PRO == PRO_LN || QN, "slab count: LayerNorm prologue of slab-form passes only");
-  static_assert(NP == 0 || NP == 2 || NP == VC_MAX_KSPLIT || QN, "slabs requested per row");
+  static_assert(NP == VC_MAX_KSPLIT || PRO == PRO_LN, "slab count: LayerNorm prologue of slab-form passes only");
+  static_assert(NP == 0 || NP == 2 || NP == VC_MAX_KSPLIT, "slabs requested per row");
   static_assert(!R2 || NTW == 2, "two rows per wave: the two-tile form");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -450,11 +447,6 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
         ml##S[ib_][s_] = ml_[se_];                                                               \
         os##S[ib_][s_] = *reinterpret_cast<const float4*>(op_ + (long)se_ * a.hd);               \
       }                                                                                          \
-      if constexpr (QN) {   /* one row: q and the new position's K / V as the cache holds them */ \
-        qn##S[ib_] = *reinterpret_cast<const float4*>(a.q_out + c##S[ib_]);                      \
-        kn##S[ib_] = load4f(reinterpret_cast<const WT*>(a.kv_new) + c##S[ib_]);                  \
-        vn##S[ib_] = load4f(reinterpret_cast<const WT*>(a.kv_new) + a.d + c##S[ib_]);            \
-      }                                                                                          \
     }
 #define VC_ATT_FINISH(S, NS, IB)                                                                 \
     _Pragma("unroll") for (int ib_ = 0; ib_ < IB; ++ib_) {                                       \
@@ -462,13 +454,6 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
       _Pragma("unroll") for (int s_ = 0; s_ < NS; ++s_) {                                        \
         ml##S[ib_][s_].x = (s_ < a.nsplit) ? ml##S[ib_][s_].x : -INFINITY;                       \
         M_ = fmaxf(M_, ml##S[ib_][s_].x);                                                        \
-      }                                                                                          \
-      float tn_ = 0.f;                                                                           \
-      if constexpr (QN) {   /* score of the new position: q . k over the head's hd / 4 lanes */  \
-        tn_ = (qn##S[ib_].x * kn##S[ib_][0] + qn##S[ib_].y * kn##S[ib_][1]) + (qn##S[ib_].z * kn##S[ib_][2] + qn##S[ib_].w * kn##S[ib_][3]); \
-        for (int off_ = a.hd >> 3; off_ >= 1; off_ >>= 1) tn_ += __shfl_xor(tn_, off_, 64);      \
-        tn_ *= a.att_scale;                                                                      \
-        M_ = fmaxf(M_, tn_);                                                                     \
       }                                                                                          \
       float L_ = 0.f;                                                                            \
       f32x4 o_ = {0.f, 0.f, 0.f, 0.f};                                                           \
@@ -478,11 +463,6 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
         o_[0] += w_ * os##S[ib_][s_].x; o_[1] += w_ * os##S[ib_][s_].y;                          \
         o_[2] += w_ * os##S[ib_][s_].z; o_[3] += w_ * os##S[ib_][s_].w;                          \
       }                                                                                          \
-      if constexpr (QN) {                                                                        \
-        const float w_ = expf(tn_ - M_);                                                         \
-        L_ += w_;                                                                                \
-        o_ += w_ * vn##S[ib_];                                                                   \
-      }                                                                                          \
       const float inv_ = (L_ > 0.f) ? 1.0f / L_ : 0.f;                                           \
       o_[0] *= inv_; o_[1] *= inv_; o_[2] *= inv_; o_[3] *= inv_;                                \
       if (on##S[ib_]) store4(reinterpret_cast<WT*>(xl + (size_t)r##S[ib_] * xs) + (c##S[ib_] - k0), o_); \
@@ -491,8 +471,6 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
     {                                                                                            \
       float2 mlA[IB][NS], mlB[IB][NS];                                                           \
       float4 osA[IB][NS], osB[IB][NS];                                                           \
-      float4 qnA[IB], qnB[IB];                                                                   \
-      f32x4 knA[IB], knB[IB], vnA[IB], vnB[IB];                                                  \
       int rA[IB], cA[IB], rB[IB], cB[IB];                                                        \
       bool onA[IB], onB[IB];                                                                     \
       VC_ATT_LOAD(A, NS, IB, 0);                                                                 \
@@ -1582,11 +1560,6 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
   }
   if constexpr (PRO == PRO_ATT && EPI == EPI_PART && NTW == 1) {
     // the one-row out-projection may host the prefetch role (option gemm_pf): its own instantiation
-    if (a.kv_new) {      // behind the fused QKV + attention launch (one row, 8 splits): the new position is the merge's ninth partial
-      if (a.n_rows != 1 || a.nsplit != VC_MAX_NSPLIT || !a.nt || groups != 1) return hipErrorInvalidValue;
-      if (a.pf_blocks > 0) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, 1, true>(a, dtype, ksplit, groups, s);
-      return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, 1, false>(a, dtype, ksplit, groups, s);
-    }
     if (a.pf_blocks > 0 && a.nt && groups == 1) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, VC_MAX_KSPLIT, true>(a, dtype, ksplit, groups, s);
   }
   if (a.nt) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true>(a, dtype, ksplit, groups, s);

@@ -12,18 +12,6 @@ __device__ __forceinline__ void store4(bf16_t* p, const f32x4& v) {
   *reinterpret_cast<uint2*>(p) = u;
 }
 
-// four consecutive WT elements as floats
-__device__ __forceinline__ f32x4 load4f(const float* p) {
-  const float4 v = *reinterpret_cast<const float4*>(p);
-  const f32x4 r = {v.x, v.y, v.z, v.w};
-  return r;
-}
-__device__ __forceinline__ f32x4 load4f(const bf16_t* p) {
-  const uint2 u = *reinterpret_cast<const uint2*>(p);
-  const f32x4 r = {__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u)};
-  return r;
-}
-
 // store and return the values as the MFMA will read them back (identity in fp32 mode)
 __device__ __forceinline__ f32x4 store4r(float* p, const f32x4& v) { store4(p, v); return v; }
 __device__ __forceinline__ f32x4 store4r(bf16_t* p, const f32x4& v) {
