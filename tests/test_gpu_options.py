@@ -115,3 +115,41 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
         eng.set_option("no_such_option", "1")
     with pytest.raises(AssertionError):
         eng.set_option("attn_pf", "many")
+
+
+@pytest.mark.parametrize("preset,B", [("tiny", 1), ("tiny_h16", 1), ("tiny128", 20)])
+def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
+    """Option `qkv16` (default on): prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
+    the LayerNorm-folded matrix instead of the 12-channel tiles of the one-row kernels.  The same dot products on other MFMA lanes:
+    fp32 tokens equal the oracle's in both states (one sequence: the prompt pass; 20 sequences: every decode step as well), bf16
+    tokens agree between the states wherever the arg-max margin is not a rounding."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args(preset)
+    sd = synth.make_state_dict(a, seed=4, head_gain=4.0)
+    prompts = [synth.random_prompt(a, 4 + (u % 5), 17 + 3 * (u % 7), seed=500 + u) for u in range(B)]
+    _, want_res = _oracle_traces(a, sd, prompts)
+    for dtype in ("fp32", "bf16"):
+        eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype=dtype, max_seqs=B, max_positions=256)
+        res = {}
+        for q16 in (1, 0, 1):
+            eng.set_option("qkv16", q16)
+            assert eng.options().endswith(f"|q16={q16}")
+            c0 = eng.launch_counts()
+            if B == 1:
+                x, xl, y = prompts[0]
+                got = [eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()]
+            else:
+                outs = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3)
+                got = [res.cpu().numpy() for (res, gen) in outs]
+            c = _delta(eng.launch_counts(), c0)
+            assert c["blk64"] + c["blk64_occ2"] + c["blk128_sbs"] + c["blk128_2x2"] > 0, c          # the prompt went through the block GEMM
+            if B > 16:
+                assert c["mt2"] + c["mt4"] > 0, c                                               # ... and the steps through the wide-decode kernel
+            if dtype == "fp32":
+                for g, w in zip(got, want_res):
+                    assert np.array_equal(g, w), q16
+            res[q16] = got
+        if dtype == "bf16":
+            same = sum(int(np.array_equal(g1, g0)) for g1, g0 in zip(res[1], res[0]))
+            assert same >= (B * 3) // 4, (same, B)

@@ -188,7 +188,10 @@ struct SeqState {
 
 // ---------------------------------------------------------------- kernel argument blocks
 enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2, PRO_LNW = 3 };      // PRO_LNW: LayerNorm fold of 2..8 FINISHED rows, one wave per row
-enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4, EPI_RES = 5 };   // EPI_RES: h_out = h_in + bias + W x (whole rows)
+enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4, EPI_RES = 5, EPI_QKV16 = 6 };   // EPI_RES: h_out = h_in + bias + W x (whole rows)
+// EPI_QKV16: the QKV epilogue over the 16-channel image of the matrix (prefill and wide-decode passes, round 5): the 12-channel tiles of
+// EPI_QKV leave a quarter of every MFMA's A lanes idle, which costs a many-row pass a quarter of its QKV launch
+constexpr bool vc_is_qkv(int epi) { return epi == EPI_QKV || epi == EPI_QKV16; }
 #define VC_TH_RES 8         // output channels per weight tile of the finished-row producers (rows_gemm_fr_k): d/8 workgroups
 #define VC_FR_WAVES 8       // waves of a finished-row producer workgroup (each streams K/8 of its 8 channels in ONE burst)
 #define VC_FR_MAX_ROWS 8    // finished-row passes of up to this many rows: one row per consumer wave, split attention merged by the

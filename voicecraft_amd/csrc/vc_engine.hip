@@ -32,6 +32,7 @@ struct RawTensor {
 struct Layer {
   uint4 *Wqkv = nullptr, *Wo = nullptr, *W1 = nullptr, *W2 = nullptr;
   uint4 *Wo8 = nullptr, *W28 = nullptr;                                 // Wo / W2 once more in 8-channel tiles (finished-row producers, vc_gemm.hip)
+  uint4 *Wqkv16 = nullptr;                                              // Wqkv . gamma in 16-channel tiles (prefill and wide-decode passes, option "qkv16")
   uint4 *Wqkv8 = nullptr;                                               // Wqkv . gamma in 8-channel tiles (one-row paired QKV kernel, option "qkv_p8")
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;   // bqkv / b1 hold the FOLDED biases (W beta + b)
   float *wg_qkv = nullptr, *wg_1 = nullptr;                             // row sums of the folded weights W . gamma
@@ -61,6 +62,7 @@ struct vc_engine {
   float *text_emb = nullptr, *audio_emb = nullptr, *mask_emb = nullptr, *pe = nullptr;
   float alpha_text = 1.f, alpha_audio = 1.f;
   Plan p_qkv{}, p_o{}, p_f1{}, p_f2{}, p_h1{}, p_h2{};
+  Plan p_qkv16;                         // the same matrix on 16-channel tiles (Layer.Wqkv16)
 
   // activations / scratch
   float *emb = nullptr;                 // prefill rows [emb_cap][d] (one or several prompts back to back)
@@ -150,6 +152,10 @@ struct vc_engine {
   // option "qkv_p8" (round 5): one-row steps behind a finished row (fr_one) run the QKV projection on 8-channel tiles with two k-tiles
   // per MFMA fragment (row_gemm_fr1_k<PRO_LN, EPI_QKV>: every lane's 16 bytes are weights) instead of 12-channel tiles
   int qkv_p8 = 1;
+  // option "qkv16" (round 5): prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of the
+  // folded matrix (every A lane of every MFMA a weight) instead of the 12-channel tiles one-row steps were tuned on; + 6 d^2 bytes per
+  // layer in bf16 (0.4 GB at giga830M).  VC_QKV16=0 at creation: not packed, the option stays off.
+  int qkv16 = 1;
   // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
   // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
   int ln_trim = 1;
@@ -617,7 +623,12 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = mtv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
+      if (e->qkv16 && ly.Wqkv16) {     // every A lane a weight: the 16-channel image
+        g.Wp = ly.Wqkv16; g.n_tiles = e->p_qkv16.n_tiles; g.KT = e->p_qkv16.KT; g.nchunk = e->p_qkv16.nchunk;
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV16, 1, 1, s));
+      } else {
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
+      }
     }
     {
       AttnArgs a;
@@ -969,6 +980,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
   } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
+  } else if (name == "qkv16") {
+    if (v0 && !e->layers.empty() && !e->layers[0].Wqkv16)
+      return fail(e, VC_ESTATE, "option 'qkv16': this engine was created with VC_QKV16=0 and holds no 16-channel image of the QKV matrix");
+    e->qkv16 = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
@@ -981,10 +996,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d|q16=%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb, e->qkv16);
   e->opt_state = buf;
 }
 
@@ -1139,12 +1154,19 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   const char* env_fr = getenv("VC_FINISHED_ROWS");
   const char* env_f1 = getenv("VC_FR_ONE");
   const bool want_fr8 = !(env_fr && atoi(env_fr) == 0 && env_f1 && atoi(env_f1) == 0);
+  const char* env_q16 = getenv("VC_QKV16");
+  const bool want_qkv16 = !(env_q16 && atoi(env_q16) == 0);
   e->layers.resize(L);
   for (int l = 0; l < L; ++l) {
     const std::string pre = "decoder.layers." + std::to_string(l) + ".";
     Layer& ly = e->layers[l];
     if ((rc = pack_folded(e, pre + "self_attn.in_proj_weight", pre + "self_attn.in_proj_bias", pre + "norm1.", 3 * d, d,
                           &ly.Wqkv, &ly.wg_qkv, &ly.bqkv, VC_TH_QKV))) return rc;
+    if (want_qkv16) {
+      const RawTensor* tg1;
+      if ((rc = need(e, pre + "norm1.weight", {d}, &tg1))) return rc;
+      if ((rc = pack_matrix(e, pre + "self_attn.in_proj_weight", 3 * d, d, &ly.Wqkv16, 16, tg1->dev))) return rc;
+    }
     if ((rc = pack_matrix(e, pre + "self_attn.out_proj.weight", d, d, &ly.Wo))) return rc;
     if ((rc = keep_vec(e, pre + "self_attn.out_proj.bias", d, &ly.bo))) return rc;
     if ((rc = pack_folded(e, pre + "linear1.weight", pre + "linear1.bias", pre + "norm2.", 4 * d, d,
@@ -1218,6 +1240,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   e->raw.clear();
   // ---- launch plans
   e->p_qkv = make_plan(3 * d, d, e->dtype, false, nullptr, VC_TH_QKV);
+  e->p_qkv16 = make_plan(3 * d, d, e->dtype, false, nullptr, 16);
   e->p_o = make_plan(d, d, e->dtype, true, "VC_KSPLIT_O");
   e->p_f1 = make_plan(4 * d, d, e->dtype, false, nullptr);
   e->p_f2 = make_plan(d, 4 * d, e->dtype, true, "VC_KSPLIT_F");
@@ -1277,7 +1300,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1827,7 +1850,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   if (!which || n_rows < 1 || iters < 1 || !avg_ms) return fail(e, VC_EINVAL, "bad argument to vc_bench_kernel");
   const bool pf = std::string(which).rfind("pf_", 0) == 0;      // prefill block GEMM: up to VC_MAX_ROWS rows
   if (n_rows > (pf ? VC_MAX_ROWS : VC_ROWS)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed %d", n_rows, pf ? VC_MAX_ROWS : VC_ROWS);
-  if (pf && (n_rows > e->emb_cap || (std::string(which) == "pf_attn" && n_rows > e->S_max)))
+  if (pf && (n_rows > e->emb_cap || ((std::string(which) == "pf_attn" || std::string(which) == "pf_qkv") && n_rows > e->S_max)))
     return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed the prefill arena / cache", n_rows);
   hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
   const std::string w = which;
@@ -1938,6 +1961,17 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       hipError_t le = vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s);
       vc_blk_dbg_mask = 0;
       HIPCHK(e, le);
+    } else if (w == "pf_qkv") {       // the prefill pass's QKV projection (X = xn; the image option "qkv16" selects)
+      GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
+      g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = 1;
+      g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+      g.row_seq = e->pre_row_seq; g.row_pos = e->pre_row_pos;        // sequence 0, positions 0 .. n_rows - 1
+      if (e->qkv16 && ly.Wqkv16) {
+        g.Wp = ly.Wqkv16; g.n_tiles = e->p_qkv16.n_tiles; g.KT = e->p_qkv16.KT; g.nchunk = e->p_qkv16.nchunk;
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV16, 1, 1, s));
+      } else {
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
+      }
     } else if (w == "pf_attn") {      // the prefill's MFMA tile attention: n_rows consecutive positions of sequence 0 (16-row tiles)
       AttnArgs a;
       memset(&a, 0, sizeof a);
@@ -1974,6 +2008,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     else if (w == "qkv") b = 3.0 * d * d * es + n_rows * (d * 4.0 + 3.0 * d * es);
     else if (w == "oproj") b = 1.0 * d * d * es + n_rows * (d * 4.0 * 2);
     else if (w == "attn") b = n_rows * 2.0 * d * es * (std::min(e->S_max - 1, 883) + 1);   // K and V of every cached position
+    else if (w == "pf_qkv") b = 2.0 * n_rows * (double)d * 3.0 * d;                        // FLOPs
     else if (w == "pf_ffn1") b = 2.0 * n_rows * (double)d * 4.0 * d;                       // FLOPs, not bytes (MFMA roofline)
     else if (w == "pf_attn") b = 4.0 * d * ((double)n_rows * (n_rows + 1) / 2.0);          // FLOPs of Q K^T and P V under the causal mask
     else b = (double)e->L * (12.0 * d * d + 13.0 * d) * es + 2.0 * d * es +

@@ -1635,6 +1635,10 @@ static hipError_t launch_ktw(const GemmArgs& a, int dtype, int pro, int epi, int
   if (pro == PRO_PLAIN && epi == EPI_PART) return launch_one<WT, KTW, PRO_PLAIN, EPI_PART>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_LOGITS) return launch_one<WT, KTW, PRO_PLAIN, EPI_LOGITS>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_QKV) return launch_one<WT, KTW, PRO_PLAIN, EPI_QKV>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_PLAIN && epi == EPI_QKV16) {      // the 16-channel image: wide decode passes only here (prefill: vc_gemm_pf.hip)
+    if (a.mt == 2) return launch_mt<WT, KTW, PRO_PLAIN, EPI_QKV16>(a, dtype, ksplit, groups, s);
+    return hipErrorInvalidValue;
+  }
   if (pro == PRO_PLAIN && epi == EPI_RELU) return launch_one<WT, KTW, PRO_PLAIN, EPI_RELU>(a, dtype, ksplit, groups, s);
   if (pro == PRO_PLAIN && epi == EPI_GELU) return launch_one<WT, KTW, PRO_PLAIN, EPI_GELU>(a, dtype, ksplit, groups, s);
   return hipErrorInvalidValue;

@@ -33,7 +33,7 @@ __device__ __forceinline__ void epi_preload(const GemmArgs& a, int mg, int n, in
 template <typename WT, int EPI>
 __device__ __forceinline__ float4 wg_preload(const GemmArgs& a, int n, int grp) {
   const int nc = (n < a.N) ? n : 0;
-  if constexpr (EPI == EPI_QKV) return *reinterpret_cast<const float4*>(a.wg + nc);
+  if constexpr (vc_is_qkv(EPI)) return *reinterpret_cast<const float4*>(a.wg + nc);
   else return *reinterpret_cast<const float4*>(a.wg + (long)grp * a.bias_group_stride + nc);
 }
 template <typename WT, int EPI>
@@ -42,7 +42,7 @@ __device__ __forceinline__ void epi_preload(const GemmArgs& a, int mg, int n, in
   pos = -1;
   seq = 0;
   const int nc = (n < a.N) ? n : 0;
-  if constexpr (EPI == EPI_QKV) {
+  if constexpr (vc_is_qkv(EPI)) {
     b = *reinterpret_cast<const float4*>(a.bias + nc);
     pos = a.row_pos[mg];
     seq = a.row_seq[mg];
@@ -61,7 +61,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int 
                                               const float4& b, int pos, int seq) {
   if constexpr (EPI == EPI_PART) {
     if (n < a.N) store4(a.part_out + ((long)(ks * a.rows_cap + mg)) * a.N + n, acc);
-  } else if constexpr (EPI == EPI_QKV) {
+  } else if constexpr (vc_is_qkv(EPI)) {
     if (n < a.N) {
       acc[0] += b.x; acc[1] += b.y; acc[2] += b.z; acc[3] += b.w;
       const int d = a.d;
@@ -108,7 +108,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& a, f32x4 acc, int 
 template <typename WT, int EPI, int MT, int NTW>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT][NTW], const float4 (&ebias)[NTW],
                                               int row0, int nt0, int TH, int kg, int ks, int n_rows) {
-  static_assert(EPI == EPI_QKV || EPI == EPI_PART || EPI == EPI_RELU, "block GEMM epilogues");
+  static_assert(vc_is_qkv(EPI) || EPI == EPI_PART || EPI == EPI_RELU, "block GEMM epilogues");
   constexpr bool PACK = sizeof(WT) == 2;
   int n[NTW];
   bool ok[NTW];
@@ -119,7 +119,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT
   }
   long rowoff[MT], choff[NTW];
   bool isq[NTW], isv[NTW];
-  if constexpr (EPI == EPI_QKV) {
+  if constexpr (vc_is_qkv(EPI)) {
     int pos[MT], seq[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) {
@@ -150,7 +150,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT
       if constexpr (EPI == EPI_RELU) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
       if constexpr (PACK && EPI != EPI_PART) {    // bf16 outputs ride in the first two registers (q of the QKV form stays fp32)
         const float p0 = __uint_as_float(pack_bf16x2(v[0], v[1])), p1 = __uint_as_float(pack_bf16x2(v[2], v[3]));
-        const bool keep = EPI == EPI_QKV && isq[j];
+        const bool keep = vc_is_qkv(EPI) && isq[j];
         v[0] = keep ? v[0] : p0;
         v[1] = keep ? v[1] : p1;
       }
@@ -168,7 +168,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, f32x4 (&acc)[MT
       const f32x4 v = acc[i][j];
       if constexpr (EPI == EPI_PART) {
         *reinterpret_cast<f32x4*>(a.part_out + ((long)(ks * a.rows_cap + mg)) * a.N + n[j]) = v;
-      } else if constexpr (EPI == EPI_QKV) {
+      } else if constexpr (vc_is_qkv(EPI)) {
         if (isq[j]) {
           *reinterpret_cast<f32x4*>(a.q_out + (long)mg * a.d + n[j]) = v;
         } else if (rowoff[i] >= 0) {

@@ -402,6 +402,7 @@ static hipError_t launch_blk(const GemmArgs& a, int pro, int epi, int ksplit, hi
     if (!big_off && a.n_rows > 512 && a.n_tiles % 16 == 0) {
       if (wgs >= 160) {                    // 256 x 256 tiles
         if (epi == EPI_QKV) return launch_big<EPI_QKV, 2>(a, ksplit, s);
+        if (epi == EPI_QKV16) return launch_big<EPI_QKV16, 2>(a, ksplit, s);
         if (epi == EPI_PART) return launch_big<EPI_PART, 2>(a, ksplit, s);
         if (epi == EPI_RELU) return launch_big<EPI_RELU, 2>(a, ksplit, s);
       }
@@ -411,6 +412,7 @@ static hipError_t launch_blk(const GemmArgs& a, int pro, int epi, int ksplit, hi
     }
   }
   if (epi == EPI_QKV) return launch_blk_e<WT, EPI_QKV>(a, ksplit, s);
+  if (epi == EPI_QKV16) return launch_blk_e<WT, EPI_QKV16>(a, ksplit, s);
   if (epi == EPI_PART) return launch_blk_e<WT, EPI_PART>(a, ksplit, s);
   if (epi == EPI_RELU) return launch_blk_e<WT, EPI_RELU>(a, ksplit, s);
   return hipErrorInvalidValue;
