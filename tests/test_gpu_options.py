@@ -121,7 +121,8 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
 def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
     """Option `qkv16` (default on): prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
     the LayerNorm-folded matrix instead of the 12-channel tiles of the one-row kernels.  The same dot products on other MFMA lanes:
-    fp32 tokens equal the oracle's in both states (one sequence: the prompt pass; 20 sequences: every decode step as well), bf16
+    fp32 tokens equal the oracle's in both states (one sequence: the prompt pass; 20 sequences: 20-row decode steps as well; the wide-decode
+    kernel itself at d = 2048: tests/test_gpu_scale.py, 32 rows), bf16
     tokens agree between the states wherever the arg-max margin is not a rounding."""
     from voicecraft_amd import synth
     from voicecraft_amd.engine import VoiceCraftEngine
@@ -144,8 +145,6 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
                 got = [res.cpu().numpy() for (res, gen) in outs]
             c = _delta(eng.launch_counts(), c0)
             assert c["blk64"] + c["blk64_occ2"] + c["blk128_sbs"] + c["blk128_2x2"] > 0, c          # the prompt went through the block GEMM
-            if B > 16:
-                assert c["mt2"] + c["mt4"] > 0, c                                               # ... and the steps through the wide-decode kernel
             if dtype == "fp32":
                 for g, w in zip(got, want_res):
                     assert np.array_equal(g, w), q16

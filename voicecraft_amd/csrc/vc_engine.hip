@@ -604,6 +604,20 @@ int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n
 
 // Prefill pass over up to VC_MAX_ROWS prompt rows: LayerNorm once per row (ln_rows_k), then the
 // multi-tile rows-GEMM (weights streamed once per pass).  Same buffers and slabs as the decode pass.
+// Which image of the QKV matrix a many-row pass reads (option "qkv16").  The 16-channel image has 3/4 of the 12-channel image's tiles,
+// and the block GEMM picks its workgroup tile from the tile count (vc_gemm_pf.hip launch_blk_e: 128-channel tiles from 240 workgroups):
+// where the smaller count would push a pass back to the 64-channel form the 12-channel image stays (giga830M, 385..512 rows: 24.0 us
+// against 34.0, profiles/r05j_qkv16_probe.log); everywhere else the full fragments win or tie (240 rows -6.7 %, 800 rows -1.7 %,
+// 1 280 rows -26.7 % - there the pass also leaves the 256 x 256 kernel, whose 160 workgroups fill 5/8 of the chip -, 32-row decode
+// steps -1.8 % per step).
+bool use_qkv16(const vc_engine* e, int rows, int mtv) {
+  if (!e->qkv16 || e->layers.empty() || !e->layers[0].Wqkv16) return false;
+  if (mtv == 2) return true;                          // wide decode passes: a weight stream, fewer instructions per byte
+  const long blk = (rows + 127) / 128;
+  const long w12 = (long)(e->p_qkv.n_tiles / 8) * blk, w16 = (long)(e->p_qkv16.n_tiles / 8) * blk;
+  return !(w12 >= 240 && w16 < 240);
+}
+
 int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
   e->finished_rows_h = false;           // this pass leaves h + split-K slabs
@@ -623,7 +637,7 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = mtv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
-      if (e->qkv16 && ly.Wqkv16) {     // every A lane a weight: the 16-channel image
+      if (use_qkv16(e, rs.n_rows, mtv)) {     // every A lane a weight: the 16-channel image
         g.Wp = ly.Wqkv16; g.n_tiles = e->p_qkv16.n_tiles; g.KT = e->p_qkv16.KT; g.nchunk = e->p_qkv16.nchunk;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV16, 1, 1, s));
       } else {
@@ -1966,7 +1980,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = 1;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       g.row_seq = e->pre_row_seq; g.row_pos = e->pre_row_pos;        // sequence 0, positions 0 .. n_rows - 1
-      if (e->qkv16 && ly.Wqkv16) {
+      if (use_qkv16(e, n_rows, 1)) {
         g.Wp = ly.Wqkv16; g.n_tiles = e->p_qkv16.n_tiles; g.KT = e->p_qkv16.KT; g.nchunk = e->p_qkv16.nchunk;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV16, 1, 1, s));
       } else {
