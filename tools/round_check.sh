@@ -1,13 +1,15 @@
 #!/bin/bash
 # The whole-state check of a round (called by tools/next_round.sh): GPU suite, default bench line, rocprofv3 kernel trace + FETCH_SIZE pass of
 # the same command, in-kernel stamps (twin library), leftover A/Bs (giga330M finished rows, attention split counts), 8-row kernel trace
+# (SHORT=1 stops after the FETCH_SIZE pass)
 set -u
 export TMPDIR=/tmp
 O=gpurun_out
 TAG=${TAG:-chk}      # file-name prefix of everything written under gpurun_out/
 export TAG
 echo "== probe"; timeout 200 python tools/box_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_box_probe.log
-echo "== whole GPU suite"; timeout 700 python -m pytest tests -m gpu -q 2>&1 | tail -8 | tee $O/${TAG}_pytest_gpu.log
+echo "== whole GPU suite"; timeout 700 python -m pytest tests -m gpu -q 2>&1 | tail -25 | tee $O/${TAG}_pytest_gpu.log
+echo "== smoke"; timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | grep -v amdgpu.ids | tail -3 | tee $O/${TAG}_smoke.log
 echo "== default bench line"; timeout 900 python bench.py 2>/dev/null | tail -1 > $O/${TAG}_bench.json.log; python - <<'PY'
 import json
 d=json.loads(open("gpurun_out/" + __import__("os").environ.get("TAG", "chk") + "_bench.json.log").read())
@@ -22,6 +24,7 @@ echo "== rocprof kernel trace"; bash tools/prof_decode.sh ${TAG} --no-codec --ab
 python tools/in_situ_to_json.py $O/${TAG}_rocprof_kernel_stats.txt $O/in_situ.json > /dev/null
 echo "== FETCH_SIZE pass"; bash tools/prof_pmc.sh ${TAG}_fetch FETCH_SIZE --ab none --no-configs; head -12 $O/${TAG}_fetch_pmc.txt
 python tools/pmc_to_json.py $O/${TAG}_fetch_pmc.txt $O/pmc_traffic.json > /dev/null
+if [ "${SHORT:-0}" = "1" ]; then exit 0; fi      # SHORT=1: suite + smoke + bench + the two profiles only
 echo "== in-kernel stamps"; timeout 200 python tools/kernel_ts.py giga830M 1 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_kernel_stamps_giga830M.log
 echo "== giga330M"; timeout 300 python tools/ab_sweep.py --preset giga330M fr_one=0:1 gemm_pf=0:128,-1,0 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_330M.log
 echo "== 8 rows"; timeout 300 python tools/ab_sweep.py --batch 8 fr_pair=0:1 finished_rows=0:16 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_b8.log
