@@ -632,13 +632,22 @@ def main():
         step_ms, _ = eng.bench_kernel("step", n_rows=mb_rows, iters=8)
         kernels, kraw = {}, {}
         for kn in ("qkv", "attn", "oproj", "ffn1", "ffn2", "qkv_hot", "oproj_hot", "ffn1_hot", "ffn2_hot"):
-            ms_, by_ = eng.bench_kernel(kn, n_rows=mb_rows, iters=64)
+            # (a short untimed run first, then the better of two: the first microbenchmark after the step used to catch the chip in
+            # transition - the same kernel read 6.3 / 6.7 / 7.8 us on three boxes while its in-situ average stayed at 6.4-6.5)
+            eng.bench_kernel(kn, n_rows=mb_rows, iters=8)
+            ms_, by_ = min(eng.bench_kernel(kn, n_rows=mb_rows, iters=64), eng.bench_kernel(kn, n_rows=mb_rows, iters=64))
             kernels[kn] = {"avg_us": round(ms_ * 1e3, 2), "GB/s": round(by_ / (ms_ * 1e-3) / 1e9, 1)}
             kraw[kn] = (ms_, by_)
         c1 = eng.launch_counts()
         fr1_form = c1["row_gemm_fr1"] > c0["row_gemm_fr1"]      # which forms the microbenchmarks (= the step) really launched
         fr_form = c1["rows_gemm_fr"] > c0["rows_gemm_fr"]
-        dom = max(("ffn1", "ffn2", "qkv"), key=lambda k: kraw[k][0])
+        # ... decided by the committed in-situ trace of this very configuration where there is one (what a reader of profiles/ computes),
+        # by the isolated times otherwise
+        ins = {k: in_situ(k, args) for k in ("ffn1", "ffn2", "qkv")}
+        if all(v and v.get("avg_us") for v in ins.values()):
+            dom = max(ins, key=lambda k: ins[k]["avg_us"])
+        else:
+            dom = max(("ffn1", "ffn2", "qkv"), key=lambda k: kraw[k][0])
         k_ms, k_bytes = kraw[dom]
         what = {"ffn1": "FFN up-projection", "ffn2": "FFN down-projection", "qkv": "QKV projection"}[dom]
         if fr_form:
