@@ -156,6 +156,9 @@ struct vc_engine {
   // folded matrix (every A lane of every MFMA a weight) instead of the 12-channel tiles one-row steps were tuned on; + 6 d^2 bytes per
   // layer in bf16 (0.4 GB at giga830M).  VC_QKV16=0 at creation: not packed, the option stays off.
   int qkv16 = 1;
+  // option "wide_heads" (round 5): decode steps of 17..64 rows run the prediction heads once on the weight-stationary kernel of those
+  // steps (one LayerNorm launch + two rows_gemm_mt_k launches) instead of once per 16 rows on the rows-GEMM
+  int wide_heads = 1;
   // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
   // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
   int ln_trim = 1;
@@ -594,7 +597,37 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
   }
   return VC_OK;
 }
+// 17..64 rows (wide decode steps): the final LayerNorm once per row (ln_rows_k), then both head matrices on the weight-stationary
+// kernel of those steps (rows_gemm_mt_k: every weight read ONCE per step) instead of once per 16 rows - at 64 rows the 16-row passes
+// streamed the 33.6 MB of head weights four times (option "wide_heads").
+int run_heads_wide(vc_engine* e, int n, const int* n_active, hipStream_t s) {
+  RowSrc rs{};
+  rs.n_rows = n; rs.n_active = n_active;
+  {
+    GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
+    g.Wp = e->Wh1; nt_bit(e, g, NT_H1); g.bias = e->bh1;
+    g.h_in = e->hB; g.h_out = nullptr;
+    g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
+    g.wg = e->wg_h1;
+    g.out = e->hh; g.out_ld = e->K * e->P;
+    g.x_out = e->xn;
+    HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
+    g.x_in = e->xn; g.x_ld = e->d; g.mt = 2;
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_GELU, 1, 1, s));
+  }
+  {
+    GemmArgs g = base_args(e, rs, e->p_h2, e->V, e->P);
+    g.Wp = e->Wh2; nt_bit(e, g, NT_H2); g.bias = e->bh2;
+    g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
+    g.x_in = e->hh; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
+    g.out = e->logits; g.mt = 2;
+    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
+  }
+  return VC_OK;
+}
 int run_heads(vc_engine* e, const int* gather, int n, int out_row0, const int* n_active, hipStream_t s) {
+  if (e->wide_heads && !gather && out_row0 == 0 && n > VC_ROWS && n <= VC_MAX_SEQS && n_active != nullptr && !e->finished_rows_h)
+    return run_heads_wide(e, n, n_active, s);
   for (int r0 = 0; r0 < n; r0 += VC_ROWS) {       // wide batches: the heads run 16 rows at a time
     int rc = run_heads16(e, gather, std::min(VC_ROWS, n - r0), r0, out_row0 + r0, n_active, s);
     if (rc) return rc;
@@ -994,6 +1027,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
   } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
+  } else if (name == "wide_heads") { e->wide_heads = v0 ? 1 : 0;
   } else if (name == "qkv16") {
     if (v0 && !e->layers.empty() && !e->layers[0].Wqkv16)
       return fail(e, VC_ESTATE, "option 'qkv16': this engine was created with VC_QKV16=0 and holds no 16-channel image of the QKV matrix");
@@ -1010,10 +1044,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d|q16=%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d|q16=%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb, e->qkv16);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb, e->qkv16, e->wide_heads);
   e->opt_state = buf;
 }
 
@@ -1314,7 +1348,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
