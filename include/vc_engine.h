@@ -110,10 +110,11 @@ const char* vc_version(void);
  *                  attention stays split
  *   "qkv16"        1 (default) = prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
  *                  the folded matrix instead of the one-row kernels' 12-channel tiles (VC_QKV16=0 at creation: not packed, stays off)
+ *   "wide_heads"   1 (default) = decode steps of 17..64 rows run the prediction heads once on the wide-decode kernel instead of once per 16 rows
  *   "graph_steps"  decode steps captured per hipGraph;  "ln_split_rows", "attn_blocks", "attn_blocks1", "prefill_rows"
  * What an option may change: nothing in the exact fp32 mode's greedy tokens (tests/test_gpu_options.py, test_gpu_one_row.py); in bf16
  * mode the forms that re-order sums or round at another place ("finished_rows", "fr_split_rows", "attn_blocks*", "fr_one",
- * "attn_fast", "qkv16") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can differ between option
+ * "attn_fast", "qkv16", "wide_heads") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can differ between option
  * states; the prefetch / cache-policy options ("attn_pf*", "gemm_pf", "nt", "attn_nt", "ln_trim", "graph_steps") change no value.
  * The non-temporal mask "nt" has no bit for the finished-row producers (rows_gemm_fr_k, rows_gemm_fr2_k, row_gemm_fr1_k): they always
  * stream with the hint.  Captured decode graphs are kept per option state, so an in-process A/B (bench.py --ab) pays for capture once
