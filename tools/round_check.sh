@@ -1,5 +1,5 @@
 #!/bin/bash
-# The whole-state check of a round (called by tools/next_round.sh): GPU suite, default bench line, rocprofv3 kernel trace + FETCH_SIZE pass of
+# The whole-state check of a round: GPU suite, default bench line, rocprofv3 kernel trace + FETCH_SIZE pass of
 # the same command, in-kernel stamps (twin library), leftover A/Bs (giga330M finished rows, attention split counts), 8-row kernel trace
 # (SHORT=1 stops after the FETCH_SIZE pass)
 set -u
