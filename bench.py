@@ -107,7 +107,7 @@ def in_situ(kernel, args):
 OPTION_STATE = {"attn_pf": ("apf", (0, 1, 2)), "attn_pf_cut": ("apf", (4, 5, 6)), "graph_steps": ("g", (0,)),
                 "ln_split_rows": ("ls", (0,)), "attn_blocks": ("ab", (0,)), "attn_blocks1": ("ab", (1,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)),
                 "finished_rows": ("fr", (0,)), "lnw_tiles": ("fr", (1,)), "fr_split_rows": ("fr", (2,)), "fr_pair": ("fr", (3,)), "tile_attn": ("ta", (0, 1)),
-                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "gemm_pf": ("gpf", (0, 1, 2)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,))}
+                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "gemm_pf": ("gpf", (0, 1, 2)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,)), "mt_tiles": ("q16", (2,))}
 
 
 def option_value(text, knob):
@@ -160,7 +160,7 @@ def options_object(text):
     names = {"apf": ("attn_pf", ["slices", "wo_kb", "w1_kb", "scale_quarters", "cut1", "cut2", "cut0"]), 
              "g": ("graph_steps", None), "ls": ("ln_split_rows", None), "ab": ("attn_blocks", ["several_rows", "one_row"]),
              "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "lnw_tiles", "split_rows", "paired"]),
-             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "gpf": ("gemm_pf", ["workgroups", "ffn_down_kb", "ffn_up_kb"]), "q16": ("many_rows", ["qkv16", "wide_heads"])}
+             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "gpf": ("gemm_pf", ["workgroups", "ffn_down_kb", "ffn_up_kb"]), "q16": ("many_rows", ["qkv16", "wide_heads", "mt_tiles"])}
     out = {"text": text}
     try:
         for part in text.split("|"):

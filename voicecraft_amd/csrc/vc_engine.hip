@@ -159,6 +159,8 @@ struct vc_engine {
   // option "wide_heads" (round 5): decode steps of 17..64 rows run the prediction heads once on the weight-stationary kernel of those
   // steps (one LayerNorm launch + two rows_gemm_mt_k launches) instead of once per 16 rows on the rows-GEMM
   int wide_heads = 1;
+  // option "mt_tiles": weight tiles per workgroup of the wide-decode kernel, 0 = by tile count (rows_gemm_mt_k launcher), 2 / 4 forced
+  int mt_tiles = 0;
   // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
   // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
   int ln_trim = 1;
@@ -325,6 +327,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
   g.ln_trim = e->ln_trim;
+  g.mt_ntw = (e->mt_tiles == 1 && rs.n_rows > 32) ? 2 : (e->mt_tiles == 2 || e->mt_tiles == 4) ? e->mt_tiles : 0;    // 1 = two tiles from 33 rows on
   return g;
 }
 
@@ -1028,6 +1031,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
   } else if (name == "wide_heads") { e->wide_heads = v0 ? 1 : 0;
+  } else if (name == "mt_tiles") {
+    if (v0 != 0 && v0 != 1 && v0 != 2 && v0 != 4) return fail(e, VC_EINVAL, "option 'mt_tiles': 0 (by tile count), 1 (two tiles from 33 rows on), 2 or 4");
+    e->mt_tiles = v0;
   } else if (name == "qkv16") {
     if (v0 && !e->layers.empty() && !e->layers[0].Wqkv16)
       return fail(e, VC_ESTATE, "option 'qkv16': this engine was created with VC_QKV16=0 and holds no 16-channel image of the QKV matrix");
@@ -1044,10 +1050,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d|q16=%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d|q16=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb, e->qkv16, e->wide_heads);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb, e->qkv16, e->wide_heads, e->mt_tiles);
   e->opt_state = buf;
 }
 

@@ -1600,7 +1600,7 @@ static hipError_t launch_mt(const GemmArgs& a, int dtype, int ksplit, int groups
     return hipErrorInvalidValue;       // multi-tile passes take their LayerNorm from ln_rows_k
   } else {
     // 4 weight tiles per workgroup when that still leaves >= 128 workgroups, else 2
-    if ((long)a.n_tiles * ksplit * groups >= 512) return launch_mt_n<WT, KTW, PRO, EPI, 4>(a, dtype, ksplit, groups, s);
+    if (a.mt_ntw == 4 || (a.mt_ntw == 0 && (long)a.n_tiles * ksplit * groups >= 512)) return launch_mt_n<WT, KTW, PRO, EPI, 4>(a, dtype, ksplit, groups, s);
     return launch_mt_n<WT, KTW, PRO, EPI, 2>(a, dtype, ksplit, groups, s);
   }
 }
