@@ -48,7 +48,7 @@ def test_option_state_text_round_trips_through_the_bench_helpers():
     takes it (what an in-process A/B restores afterwards)."""
     sys.path.insert(0, ROOT)
     import bench
-    t = "apf=8,0,-1,4,400,700,128|g=8|ls=3|ab=512,256|nt=63,2|fr=16,0,8|ta=2,768|r1=1,1,1,1|gpf=0,0,0|q16=1,1,0"
+    t = "apf=8,0,-1,4,400,700,128|g=8|ls=3|ab=512,256|nt=63,2|fr=16,0,8|ta=2,768|r1=1,1,1,1|gpf=0,0,0|q16=1,1,2"
     o = bench.options_object(t)
     assert o["text"] == t and o["attn_pf"]["cut1"] == 400 and o["graph_steps"] == 8 and o["ln_split_rows"] == 3
     assert o["one_row"] == {"fr_one": 1, "ln_trim": 1, "attn_fast": 1, "qkv_p8": 1} and o["nt"] == {"weights_mask": 63, "attn_kv": 2}

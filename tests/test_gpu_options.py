@@ -119,7 +119,7 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
 
 @pytest.mark.parametrize("preset,B", [("tiny", 1), ("tiny_h16", 1), ("tiny128", 20)])
 def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
-    """Options `qkv16` and `wide_heads` (both default on).  `qkv16`: prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
+    """Options `qkv16`, `wide_heads` (both default on) and `mt_tiles`.  `qkv16`: prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
     the LayerNorm-folded matrix instead of the 12-channel tiles of the one-row kernels.  The same dot products on other MFMA lanes:
     fp32 tokens equal the oracle's in both states (one sequence: the prompt pass; 20 sequences: 20-row decode steps as well; the wide-decode
     kernel itself at d = 2048: tests/test_gpu_scale.py, 32 rows), bf16
@@ -133,10 +133,13 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
     for dtype in ("fp32", "bf16"):
         eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype=dtype, max_seqs=B, max_positions=256)
         res = {}
-        for q16, wh in ((1, 1), (0, 0), (1, 0)):       # (wide_heads: 17..64-row steps run the heads once on the wide-decode kernel, not per 16 rows)
+        # (wide_heads: 17..64-row steps run the heads once on the wide-decode kernel, not per 16 rows; mt_tiles: that kernel's weight tiles
+        # per workgroup - 2, the default, or by tile count as through round 4)
+        for q16, wh, mt in ((1, 1, 2), (0, 0, 0), (1, 0, 2), (1, 1, 0)):
             eng.set_option("qkv16", q16)
             eng.set_option("wide_heads", wh)
-            assert f"|q16={q16},{wh}," in eng.options()
+            eng.set_option("mt_tiles", mt)
+            assert eng.options().endswith(f"|q16={q16},{wh},{mt}")
             c0 = eng.launch_counts()
             if B == 1:
                 x, xl, y = prompts[0]
@@ -151,7 +154,7 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
                     assert np.array_equal(g, w), q16
             if B > 16:       # heads of a wide step: once on the weight-stationary kernel, or 16 rows at a time on the rows-GEMM
                 assert (c["mt2"] + c["mt4"] > 0) if wh else (c["rows_gemm"] > 0), (wh, c)
-            res[(q16, wh)] = got
+            res[(q16, wh, mt)] = got
         if dtype == "bf16":
-            same = sum(int(np.array_equal(g1, g0)) for g1, g0 in zip(res[(1, 1)], res[(0, 0)]))
+            same = sum(int(np.array_equal(g1, g0)) for g1, g0 in zip(res[(1, 1, 2)], res[(0, 0, 0)]))
             assert same >= (B * 3) // 4, (same, B)

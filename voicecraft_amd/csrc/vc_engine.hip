@@ -159,8 +159,10 @@ struct vc_engine {
   // option "wide_heads" (round 5): decode steps of 17..64 rows run the prediction heads once on the weight-stationary kernel of those
   // steps (one LayerNorm launch + two rows_gemm_mt_k launches) instead of once per 16 rows on the rows-GEMM
   int wide_heads = 1;
-  // option "mt_tiles": weight tiles per workgroup of the wide-decode kernel, 0 = by tile count (rows_gemm_mt_k launcher), 2 / 4 forced
-  int mt_tiles = 0;
+  // option "mt_tiles": weight tiles per workgroup of the wide-decode kernel (17..64-row steps): 2 (default since the end of round 5: twice the
+  // workgroups of 512 threads - every CU busy - measured -2.6 % per step at 32 rows and -3.0 % at 64, profiles/r05t_mt_tiles_ab.log; 4 tiles
+  // everywhere +4.2 %), 0 = by tile count (4 from 512 tiles on: the rule of rounds 2-4), 1 = two tiles from 33 rows on, 4 forced
+  int mt_tiles = 2;
   // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
   // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
   int ln_trim = 1;
