@@ -111,6 +111,7 @@ const char* vc_version(void);
  *   "qkv16"        1 (default) = prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
  *                  the folded matrix instead of the one-row kernels' 12-channel tiles (VC_QKV16=0 at creation: not packed, stays off)
  *   "wide_heads"   1 (default) = decode steps of 17..64 rows run the prediction heads once on the wide-decode kernel instead of once per 16 rows
+ *   "mt_tiles"     weight tiles per workgroup of the wide-decode kernel: 2 (default), 4, 0 = by tile count (rounds 2-4), 1 = two from 33 rows on
  *   "graph_steps"  decode steps captured per hipGraph;  "ln_split_rows", "attn_blocks", "attn_blocks1", "prefill_rows"
  * What an option may change: nothing in the exact fp32 mode's greedy tokens (tests/test_gpu_options.py, test_gpu_one_row.py); in bf16
  * mode the forms that re-order sums or round at another place ("finished_rows", "fr_split_rows", "attn_blocks*", "fr_one",
