@@ -262,3 +262,69 @@ def test_twelve_row_decode_in_the_two_half_finished_row_form(giga):
         worst = max(worst, float(rel_l2(lg[steps, u], want).max()))
         assert outs[u][1].shape[2] == n - a.n_codebooks
     assert worst <= 2e-2, worst
+
+
+def test_sixty_four_row_decode_at_giga830M(giga):
+    """64 sequences per step at d = 2048 (the widest step the engine takes; README's 64-utterance line): every layer GEMM and both
+    head matrices on the wide-decode kernel, the decode attention on a 64-row grid, one LayerNorm launch per consumer - per-sequence
+    bf16 logits at three steps against the oracle's one-pass evaluation of each sequence's own forced trajectory, and the launch
+    census of the eager loop (every launch counted)."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga
+    B, n, L = 64, 10, a.num_decoder_layers
+    prompts = [synth.random_prompt(a, 5 + (u % 6), 7 + (u % 9), seed=900 + u) for u in range(B)]
+    forced = np.stack([forced_trajectory(a, n, seed=290 + u, term=a.eos) for u in range(B)], axis=1)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=128, use_graph=False)
+    c0 = eng.launch_counts()
+    outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
+                                       _forced=forced, _logit_steps=n)
+    c = delta(eng.launch_counts(), c0)
+    wide = c["mt2"] + c["mt4"] + c.get("wd", 0)
+    assert wide >= (4 * L + 2) * (n - 1), c                 # QKV, out-projection, FFN-up, FFN-down of every layer + the two head matrices, per step
+    assert c["rows_attn"] >= L * (n - 1) and c["ln_rows"] >= (2 * L + 1) * (n - 1), c
+    assert c["rows_gemm_fr"] + c["rows_gemm_frp"] + c["row_gemm_fr1"] == 0, c
+    lg = lg.cpu().numpy()
+    steps = [0, 4, n - 1]
+    worst = {}
+    for u in range(B):
+        want = orc.tts_logits_for_trajectory(prompts[u][0], prompts[u][2], forced[:, u], steps=steps).numpy()
+        worst[u] = float(rel_l2(lg[steps, u], want).max())
+        assert outs[u][1].shape[2] == n - a.n_codebooks
+    assert max(worst.values()) <= 2e-2, {u: w for u, w in worst.items() if w > 1e-2}
+
+
+@pytest.mark.parametrize("batch_size", [3, 4])
+def test_best_of_n_at_giga830M_replays_the_oracles_draws(giga, batch_size):
+    """`inference_tts_batch(batch_size = 3 | 4)` at giga830M (the mode the reference's front-ends run: gradio_app.py:506
+    sample_batch_size = 3; models/voicecraft.py:1156-1171, :1296-1302): the same raw draws go through the oracle's and the
+    engine's state machine - two samples emit the terminator at the same step, the LAST of them is kept, the others are dropped,
+    the kept one finishes its K - 1 tail - and the kept tokens must be identical; the bf16 head logits of EVERY sample before
+    that step, and of the kept one after it, stay within 2e-2 of the oracle's."""
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a, sd, orc = giga
+    K, V = a.n_codebooks, a.audio_vocab_size + a.n_special
+    x, xl, y = synth.random_prompt(a, 24, 50, seed=21)
+    n, t_end = 26, 15
+    draws = np.random.RandomState(60 + batch_size).randint(0, 2048, size=(n, batch_size, K)).astype(np.int64)
+    draws[t_end, 0, 0] = draws[t_end, batch_size - 2, 0] = int(a.eos)          # two samples terminate together: the later index is kept
+    kn = dict(top_k=40, top_p=1.0, temperature=1.0, stop_repetition=3, kvcache=1, batch_size=batch_size)
+    trace = []
+    want_res, want_gen = orc.inference_tts_batch(x, xl, y, forced_draws=draws, trace=trace, **kn)
+    assert want_gen.shape == (1, K, t_end)
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=batch_size, max_positions=512)
+    res, gen, lg = eng.inference_tts_batch(x.cuda(), xl.cuda(), y.cuda(), **kn, _forced=draws, _forced_mode="draws", _seed=1,
+                                           _logit_steps=len(trace))
+    assert np.array_equal(res.cpu().numpy(), want_res.numpy())
+    assert np.array_equal(gen.cpu().numpy()[0, 0], draws[:t_end, batch_size - 2, 0])          # the kept sample's trajectory
+    assert eng.last_steps == t_end + K
+    lg = lg.cpu().numpy()
+    keep = batch_size - 2
+    worst = 0.0
+    for s in (0, 7, t_end, len(trace) - 1):
+        want = trace[s]["logits"].numpy()                                        # [B,K,V]
+        rows = range(batch_size) if s <= t_end else [keep]
+        for b in rows:
+            worst = max(worst, float(rel_l2(lg[s, b][None], want[b][None]).max()))
+    assert worst <= 2e-2, worst
