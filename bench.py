@@ -7,6 +7,7 @@ top_k=40, Lx=80 phonemes, 150 prompt frames -> 650 generated frames (the referen
 cap ends generation).  codec tokens = K * generated frames.
 
   python bench.py --gpus 1 --steps 3 --warmup 1
+  python bench.py --gpus N ...            (no launcher: starts its own N ranks through torch.distributed.run)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
@@ -387,7 +388,7 @@ class Workload:
     `inference_tts` / `inference_tts_multi` / `inference` call (prompt build + prefill + every decode step + un-shift) and returns
     the generated frames of every utterance."""
 
-    def __init__(self, preset, mode, batch, lx, prompt_frames, top_k, dtype, dev, use_graph=True, rank=0, world=1, sd=None):
+    def __init__(self, preset, mode, batch, lx, prompt_frames, top_k, dtype, dev, use_graph=True, rank=0, world=1, sd=None, best_of=1):
         from voicecraft_amd import synth
         from voicecraft_amd.engine import VoiceCraftEngine
         self.preset, self.mode, self.B, self.lx, self.top_k, self.dtype, self.dev = preset, mode, batch, lx, top_k, dtype, dev
@@ -395,6 +396,8 @@ class Workload:
         self.K = K = a.n_codebooks
         self.sd = sd if sd is not None else synth.make_state_dict(a, seed=0, perturb=False, mute_eos=True, fast=True)
         self.edit = mode == "edit"
+        self.best_of = int(best_of)      # > 1: inference_tts_batch(batch_size = best_of) of ONE utterance (models/voicecraft.py:1156)
+        assert self.best_of == 1 or (batch == 1 and mode == "tts")
         self.span = None
         if self.edit:      # 16 s utterance (10 frames per phoneme), the middle eighth masked: generation runs to the
             assert batch == 1, "editing is single-utterance (models/voicecraft.py:607)"      # reference's length cap y_len > 10*Lx
@@ -405,7 +408,7 @@ class Workload:
         # generated frames: TTS 10 Lx - T (the length cap); editing: the cap minus the rearranged prompt's columns
         # (two shifted pieces of K extra columns each, two mask placeholders, the end token and the start column)
         self.Tg = 10 * lx - prompt_frames if not self.edit else 10 * lx - (prompt_frames - (span[1] - span[0]) + 2 * K + 4) + 1
-        self.eng = VoiceCraftEngine(a, self.sd, device=dev, dtype=dtype, max_seqs=max(1, batch),
+        self.eng = VoiceCraftEngine(a, self.sd, device=dev, dtype=dtype, max_seqs=max(1, batch, self.best_of),
                                     max_positions=max(1024, lx + prompt_frames + self.Tg + 64), use_graph=use_graph)
         # utterance u of this rank = global utterance (u * world + rank); seed = 1 + global index
         self.prompts = [synth.random_prompt(a, lx, prompt_frames, seed=1 + (u * world + rank)) for u in range(batch)]
@@ -420,7 +423,11 @@ class Workload:
             mi = torch.tensor([[list(self.span)]], dtype=torch.int64)
             res = eng.inference(self.xs[0], self.xls[0], self.ys[0], mi, silence_tokens=[1388, 1898, 131], _seed=seed, **self.knobs)
             return [None], (int(res.shape[2]) - (self.prompt_frames - (self.span[1] - self.span[0]))) * K
-        if self.B == 1:
+        if self.best_of > 1:      # the reference's front-ends run this mode (gradio_app.py:506 sample_batch_size = 3): the kept sample's frames count
+            res, gen = eng.inference_tts_batch(self.xs[0], self.xls[0], self.ys[0], kvcache=1, batch_size=self.best_of,
+                                               silence_tokens=[1388, 1898, 131], _seed=seed, **self.knobs)
+            gens = [gen]
+        elif self.B == 1:
             res, gen = eng.inference_tts(self.xs[0], self.xls[0], self.ys[0], kvcache=1, silence_tokens=[1388, 1898, 131], _seed=seed, **self.knobs)
             gens = [gen]
         else:
@@ -432,6 +439,9 @@ class Workload:
         if self.edit:
             return (f"{self.preset} speech editing, Lx={self.lx}, {self.prompt_frames}-frame utterance, span "
                     f"{self.span} re-generated (~{self.Tg} frames, reference length cap), top_k={self.top_k}")
+        if self.best_of > 1:
+            return (f"{self.preset} TTS best-of-{self.best_of} (inference_tts_batch: {self.best_of} samples of one utterance decoded together, one kept), Lx={self.lx}, "
+                    f"{self.prompt_frames} prompt frames -> {self.Tg} generated frames, top_k={self.top_k}, hipGraph={'on' if use_graph else 'off'}")
         return (f"{self.preset} TTS, batch {self.B}/GPU, Lx={self.lx}, {self.prompt_frames} prompt frames -> "
                 f"{self.Tg} generated frames ({(self.prompt_frames + self.Tg) // 50} s total), top_k={self.top_k}, hipGraph={'on' if use_graph else 'off'}")
 
@@ -450,6 +460,9 @@ def configs_block(args, dev, sd830):
         ("C4", "BASELINE config 4", dict(preset="giga830M", mode="edit", batch=1, lx=80, prompt_frames=150, top_k=40)),
         ("C5_per_gpu_share", "BASELINE config 5: 64 utterances over 8 GPUs = 8 per GPU, this GPU's share",
          dict(preset="giga830M", mode="tts", batch=8, lx=80, prompt_frames=150, top_k=40)),
+        ("C3_best_of_3", "BASELINE config 3's utterance through inference_tts_batch(batch_size=3), the mode the reference's front-ends run "
+         "(gradio_app.py:506, inference_tts.ipynb): three samples decoded together, the kept one's frames counted",
+         dict(preset="giga830M", mode="tts", batch=1, lx=80, prompt_frames=150, top_k=40, best_of=3)),
     ]
     out = {}
     sd_cache = {"giga830M": sd830} if sd830 is not None else {}
@@ -471,7 +484,7 @@ def configs_block(args, dev, sd830):
                 tm = wl.eng.last_timing_ms()
                 dec += tm["decode_ms"]; pre += tm["prefill_ms"]; steps += wl.eng.last_steps
             dstep = dec / max(1, steps)
-            sb = step_alg_bytes(wl.a, args.dtype, wl.B, wl.s_mean())
+            sb = step_alg_bytes(wl.a, args.dtype, max(wl.B, wl.best_of), wl.s_mean())
             out[key] = {"config": what, "workload": wl.label(not args.no_graph), "value": round(tok / wall, 1), "unit": "codec-tokens/s",
                         "calls": n_calls, "ms_per_call": round(wall / n_calls * 1e3, 2), "prefill_ms": round(pre / n_calls, 2),
                         "decode_ms_per_step": round(dstep, 4), "rtf": round(wall / (tok / wl.K / 50.0), 4),
@@ -543,10 +556,39 @@ def cpu_only(args):
             json.dump(j, f, indent=1, sort_keys=True)
 
 
+def spawn_command(gpus, argv, port):
+    """`python bench.py --gpus N` outside a launcher: the command that starts the N ranks (one process per GPU, rendezvous on
+    127.0.0.1) with this very argument list - the form the driver itself uses for N > 1."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.join(ROOT, "bench.py"), *argv]
+
+
+def spawn_ranks(args):
+    """--gpus N > 1 with no WORLD_SIZE in the environment: start the N ranks here (a plain `python bench.py --gpus 8`
+    used to measure ONE GPU and print n_gpus 1).  Fails loudly when the box shows fewer than N devices - unless
+    VC_RANKS_SHARE_DEVICE=1 (every rank drives cuda:0: the single-GPU test of the N > 1 path, which needs --dist-backend gloo)."""
+    import socket
+    import subprocess
+    share = os.environ.get("VC_RANKS_SHARE_DEVICE", "0") == "1"
+    have = torch.cuda.device_count()
+    if not share and have < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible (set VC_RANKS_SHARE_DEVICE=1 and "
+                 "--dist-backend gloo to run every rank on cuda:0)")
+    if share and args.dist_backend == "nccl":
+        sys.exit("bench.py: VC_RANKS_SHARE_DEVICE=1 needs --dist-backend gloo (RCCL refuses two ranks on one device)")
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    return subprocess.call(spawn_command(args.gpus, sys.argv[1:], port), env=env, cwd=ROOT)
+
+
 def main():
     args = parse()
     if args.cpu_baseline_only:
         return cpu_only(args)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -567,7 +609,7 @@ def main():
         dist = None
     cdev = dev if (dist is None or args.dist_backend == "nccl") else torch.device("cpu")      # where the reductions' tensors live
     n_gpus = world
-    assert args.gpus == n_gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert args.gpus == n_gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from voicecraft_amd import dist as vdist
     box = box_block(dev) if (rank == 0 and world == 1) else None

@@ -71,3 +71,22 @@ def test_in_situ_figure_is_quoted_only_for_the_configuration_it_was_traced_on(tm
     assert got["avg_us"] == 7.0 and abs(got["frac"] - 33579008 / 7e-6 / 8e12) < 1e-3
     a.batch = 8
     assert bench.in_situ("ffn2", a) is None
+
+
+def test_plain_multi_gpu_entry_builds_the_launcher_command_and_refuses_a_box_without_the_gpus():
+    """`python bench.py --gpus N` with no WORLD_SIZE starts its own N ranks (torch.distributed.run, rendezvous on 127.0.0.1, the
+    caller's own arguments); here, with no GPU at all, it must exit non-zero with a clear message and print no JSON line."""
+    sys.path.insert(0, ROOT)
+    import bench
+    cmd = bench.spawn_command(4, ["--gpus", "4", "--steps", "2"], 29517)
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"] and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29517"
+    assert cmd[-5:] == [os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "2"]
+    env = dict(os.environ, VC_RANKS_SHARE_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    import torch
+    n = torch.cuda.device_count() + 2
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n)], cwd=ROOT, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0 and f"--gpus {n} but only" in r.stdout, r.stdout[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

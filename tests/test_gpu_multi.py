@@ -22,14 +22,17 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _two_rank_bench(tmp_path, backend, share):
+def _two_rank_bench(tmp_path, backend, share, plain_entry=False):
     import json
     common = ["--steps", "2", "--warmup", "1", "--preset", "tiny128", "--lx", "8", "--prompt-frames", "20", "--batch", "2",
               "--no-cpu-baseline", "--no-codec", "--dist-backend", backend]
     dump2 = str(tmp_path / "two.npz")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", VC_RANKS_SHARE_DEVICE="1" if share else "0")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dump", dump2, *common],
+    env.pop("WORLD_SIZE", None)
+    launcher = [] if plain_entry else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                       "--master-port", str(_free_port())]
+    # plain_entry: `python bench.py --gpus 2` with no launcher around it - bench.py starts its own two ranks
+    r = subprocess.run([sys.executable, *launcher, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dump", dump2, *common],
                        cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -62,7 +65,19 @@ def _check_against_one_engine(dump2):
 
 
 def test_two_ranks_on_one_gpu_run_the_whole_n_gpu_code_path(tmp_path):
-    _check_against_one_engine(_two_rank_bench(tmp_path, "gloo", share=True))
+    """... through the PLAIN entry `python bench.py --gpus 2`: bench.py launches its two ranks itself."""
+    _check_against_one_engine(_two_rank_bench(tmp_path, "gloo", share=True, plain_entry=True))
+
+
+def test_plain_entry_refuses_more_gpus_than_the_box_has():
+    """`python bench.py --gpus N` on a box with fewer than N devices must fail loudly, not measure one GPU and print n_gpus 1."""
+    env = dict(os.environ, VC_RANKS_SHARE_DEVICE="0")
+    env.pop("WORLD_SIZE", None)
+    n = torch.cuda.device_count() + 1
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0", "--preset", "tiny128"],
+                       cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0 and f"--gpus {n} but only" in r.stdout, r.stdout[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs")
