@@ -67,18 +67,30 @@ def parse():
     return p.parse_args()
 
 
+def lib_stamp():
+    """First 16 hex digits of the digest of the library's sources (voicecraft_amd/build.py writes it next to the .so): the committed
+    in-situ trace and PMC pass are quoted only when they were taken on THIS build."""
+    try:
+        with open(os.path.join(ROOT, "voicecraft_amd", ".build_stamp")) as f:
+            return f.read()[:16]
+    except Exception:
+        return None
+
+
 def pmc_traffic(kernel, args):
     """HBM bytes per launch of `kernel` from the committed PMC pass (rocprofv3 --pmc FETCH_SIZE in its own run of THIS
     command, x2-corrected for gfx950 as the microarchitecture guide prescribes).  None unless the pass on file was taken
-    on the same preset / dtype / batch / Lx / prompt length as this run (profiles/pmc_traffic.json "config")."""
+    on the same preset / dtype / batch / Lx / prompt length as this run (profiles/pmc_traffic.json "config") AND on this build of the
+    library ("lib_stamp").  Returned with its source file and box: it is a committed measurement, not one of this run."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             j = json.load(f)
         want = {"preset": args.preset, "dtype": args.dtype, "batch": args.batch, "lx": args.lx,
                 "prompt_frames": args.prompt_frames, "mode": args.mode}
-        if j.get("config") != want:
+        if j.get("config") != want or j.get("lib_stamp") != lib_stamp():
             return None
-        return int(j["kernels"][kernel]["fetch_bytes_per_launch"])
+        return {"bytes": int(j["kernels"][kernel]["fetch_bytes_per_launch"]), "source": j.get("source"), "box": j.get("box"),
+                "lib_stamp": j.get("lib_stamp")}
     except Exception:
         return None
 
@@ -87,16 +99,18 @@ def in_situ(kernel, args):
     """The same kernel's IN-SITU average from the committed rocprofv3 kernel trace of THIS command (profiles/in_situ.json, written by
     tools/in_situ_to_json.py from a tools/prof_decode.sh summary): every launch of the decode loop, rotating layers, caches as the
     step leaves them - the microbenchmark of `roofline.achieved` runs the kernel back to back on a quiet chip and comes out ~5 %
-    higher.  None unless the trace on file was taken on this run's preset / dtype / batch / Lx / prompt length / mode."""
+    higher.  None unless the trace on file was taken on this run's preset / dtype / batch / Lx / prompt length / mode and on this
+    build of the library ("lib_stamp" = digest of its sources)."""
     try:
         with open(os.path.join(ROOT, "profiles", "in_situ.json")) as f:
             j = json.load(f)
         want = {"preset": args.preset, "dtype": args.dtype, "batch": args.batch, "lx": args.lx,
                 "prompt_frames": args.prompt_frames, "mode": args.mode}
-        if j.get("config") != want:
+        if j.get("config") != want or j.get("lib_stamp") != lib_stamp():
             return None
         k = j["kernels"][kernel]
-        out = {"kernel": k["name"], "avg_us": k["avg_us"], "calls": k["calls"], "source": j.get("source")}
+        out = {"kernel": k["name"], "avg_us": k["avg_us"], "calls": k["calls"], "source": j.get("source"), "box": j.get("box"),
+               "lib_stamp": j.get("lib_stamp")}
         if k.get("algorithmic_bytes"):
             out["frac"] = round(k["algorithmic_bytes"] / (k["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
         return out
@@ -108,7 +122,7 @@ def in_situ(kernel, args):
 OPTION_STATE = {"attn_pf": ("apf", (0, 1, 2)), "attn_pf_cut": ("apf", (4, 5, 6)), "graph_steps": ("g", (0,)),
                 "ln_split_rows": ("ls", (0,)), "attn_blocks": ("ab", (0,)), "attn_blocks1": ("ab", (1,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)),
                 "finished_rows": ("fr", (0,)), "lnw_tiles": ("fr", (1,)), "fr_split_rows": ("fr", (2,)), "fr_pair": ("fr", (3,)), "tile_attn": ("ta", (0, 1)),
-                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "gemm_pf": ("gpf", (0, 1, 2)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,)), "mt_tiles": ("q16", (2,))}
+                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "gemm_pf": ("gpf", (0, 1, 2)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,)), "mt_tiles": ("q16", (2,)), "wide_gemm": ("q16", (3,)), "shrink": ("sh", (0,))}
 
 
 def option_value(text, knob):
@@ -161,7 +175,7 @@ def options_object(text):
     names = {"apf": ("attn_pf", ["slices", "wo_kb", "w1_kb", "scale_quarters", "cut1", "cut2", "cut0"]), 
              "g": ("graph_steps", None), "ls": ("ln_split_rows", None), "ab": ("attn_blocks", ["several_rows", "one_row"]),
              "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "lnw_tiles", "split_rows", "paired"]),
-             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "gpf": ("gemm_pf", ["workgroups", "ffn_down_kb", "ffn_up_kb"]), "q16": ("many_rows", ["qkv16", "wide_heads", "mt_tiles"])}
+             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "gpf": ("gemm_pf", ["workgroups", "ffn_down_kb", "ffn_up_kb"]), "q16": ("many_rows", ["qkv16", "wide_heads", "mt_tiles", "wide_gemm"]), "sh": ("shrink", None)}
     out = {"text": text}
     try:
         for part in text.split("|"):
@@ -388,7 +402,7 @@ class Workload:
     `inference_tts` / `inference_tts_multi` / `inference` call (prompt build + prefill + every decode step + un-shift) and returns
     the generated frames of every utterance."""
 
-    def __init__(self, preset, mode, batch, lx, prompt_frames, top_k, dtype, dev, use_graph=True, rank=0, world=1, sd=None, best_of=1):
+    def __init__(self, preset, mode, batch, lx, prompt_frames, top_k, dtype, dev, use_graph=True, rank=0, world=1, sd=None, best_of=1, lx_min=None):
         from voicecraft_amd import synth
         from voicecraft_amd.engine import VoiceCraftEngine
         self.preset, self.mode, self.B, self.lx, self.top_k, self.dtype, self.dev = preset, mode, batch, lx, top_k, dtype, dev
@@ -411,7 +425,11 @@ class Workload:
         self.eng = VoiceCraftEngine(a, self.sd, device=dev, dtype=dtype, max_seqs=max(1, batch, self.best_of),
                                     max_positions=max(1024, lx + prompt_frames + self.Tg + 64), use_graph=use_graph)
         # utterance u of this rank = global utterance (u * world + rank); seed = 1 + global index
-        self.prompts = [synth.random_prompt(a, lx, prompt_frames, seed=1 + (u * world + rank)) for u in range(batch)]
+        # lx_min: a RAGGED batch - utterance u has lx_min .. lx phonemes (evenly spread), so the reference's length cap (10 frames per
+        # phoneme) ends the sequences at different steps: generated lengths spread 10 lx_min - T .. 10 lx - T
+        self.lxs = [lx if (lx_min is None or batch == 1) else lx_min + (lx - lx_min) * u // (batch - 1) for u in range(batch)]
+        self.ragged = lx_min is not None and batch > 1
+        self.prompts = [synth.random_prompt(a, self.lxs[u], prompt_frames, seed=1 + (u * world + rank)) for u in range(batch)]
         self.xs = [p[0].to(dev) for p in self.prompts]
         self.xls = [p[1].to(dev) for p in self.prompts]
         self.ys = [p[2].to(dev) for p in self.prompts]
@@ -442,6 +460,10 @@ class Workload:
         if self.best_of > 1:
             return (f"{self.preset} TTS best-of-{self.best_of} (inference_tts_batch: {self.best_of} samples of one utterance decoded together, one kept), Lx={self.lx}, "
                     f"{self.prompt_frames} prompt frames -> {self.Tg} generated frames, top_k={self.top_k}, hipGraph={'on' if use_graph else 'off'}")
+        if self.ragged:
+            return (f"{self.preset} TTS, RAGGED batch {self.B}/GPU, Lx={self.lxs[0]}..{self.lxs[-1]}, {self.prompt_frames} prompt frames -> "
+                    f"{10 * self.lxs[0] - self.prompt_frames}..{10 * self.lxs[-1] - self.prompt_frames} generated frames per utterance (the reference's length cap), "
+                    f"top_k={self.top_k}, hipGraph={'on' if use_graph else 'off'}")
         return (f"{self.preset} TTS, batch {self.B}/GPU, Lx={self.lx}, {self.prompt_frames} prompt frames -> "
                 f"{self.Tg} generated frames ({(self.prompt_frames + self.Tg) // 50} s total), top_k={self.top_k}, hipGraph={'on' if use_graph else 'off'}")
 
@@ -492,6 +514,38 @@ def configs_block(args, dev, sd830):
             del wl
         except Exception as e:      # reporting only: never lose the headline to it
             out[key] = {"config": what, "error": str(e)}
+    return out
+
+
+def ragged_block(args, dev, sd830):
+    """Utterances of DIFFERENT lengths decoded together (ragged T_g is the one source of imbalance inside a batch): Lx spread
+    2x, so the sequences retire between 250 and 650 generated frames.  Timed twice on one engine: the batch re-packed onto narrower
+    steps as sequences retire (option shrink = 1, the default) and at its fixed starting width (shrink = 0, rounds 1-5)."""
+    out = {}
+    for B in (8, 64):
+        key = f"ragged_{B}"
+        try:
+            wl = Workload("giga830M", "tts", B, 80, 150, 40, args.dtype, dev, use_graph=not args.no_graph, sd=sd830, lx_min=40)
+            r = {"workload": wl.label(not args.no_graph)}
+            for name, val in (("shrink", 1), ("fixed_width", 0)):
+                wl.eng.set_option("shrink", val)
+                wl.call(100)
+                torch.cuda.synchronize()
+                tok, wall, dec, steps, repacks = 0, 0.0, 0.0, 0, 0
+                for i in range(2):
+                    t0 = time.perf_counter()
+                    tok += wl.call(1000 + i)[1]
+                    torch.cuda.synchronize()
+                    wall += time.perf_counter() - t0
+                    dec += wl.eng.last_timing_ms()["decode_ms"]; steps += wl.eng.last_steps
+                    repacks += int(wl.eng.debug_read("host_ms", (8,), torch.float64)[6])
+                r[name] = {"value": round(tok / wall, 1), "unit": "codec-tokens/s", "ms_per_call": round(wall / 2 * 1e3, 2),
+                           "decode_ms": round(dec / 2, 2), "steps": steps // 2, "repacks_per_call": repacks // 2}
+            r["gain_pct"] = round(100.0 * (r["shrink"]["value"] / r["fixed_width"]["value"] - 1.0), 2)
+            out[key] = r
+            del wl
+        except Exception as e:      # reporting only
+            out[key] = {"error": str(e)}
     return out
 
 
@@ -701,12 +755,25 @@ def main():
                     "qkv": "row_gemm_fr1_k<LayerNorm fold, QKV> (8-channel tiles, two k-tiles per MFMA fragment)"}[dom]
         else:
             form = {"ffn2": "rows_gemm_k<plain, split-K slabs>", "ffn1": "rows_gemm_k<LayerNorm fold, ReLU>", "qkv": "rows_gemm_k<LayerNorm fold, QKV>"}[dom]
+        # `achieved` / `frac`: the IN-SITU figure (every launch of the decode loop under rocprofv3, caches as the step leaves them) when the
+        # committed trace belongs to this configuration and this build; otherwise the isolated microbenchmark of this run, which comes out
+        # ~3-5 % higher (a quiet chip) and always rides along as `isolated_*`
+        iso_gbs = k_bytes / (k_ms * 1e-3) / 1e9
+        ins_dom = in_situ(dom, args)
+        tr = pmc_traffic(dom, args)
+        if ins_dom and ins_dom.get("frac"):
+            ach_us, measured = ins_dom["avg_us"], f"in situ: rocprofv3 --kernel-trace average over {ins_dom['calls']} launches of the decode loop, committed trace of this build ({ins_dom['source']})"
+        else:
+            ach_us, measured = k_ms * 1e3, "isolated: the kernel back to back over rotating layers, HIP events on the launch stream (vc_bench_kernel); no in-situ trace of this build and configuration is on file"
+        ach_gbs = k_bytes / (ach_us * 1e-6) / 1e9
         roof = {"bound": "hbm", "kernel": f"{form} ({what}; the longest of the step's per-layer launches)",
-                "achieved": round(k_bytes / (k_ms * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(k_bytes / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(dom, args),
-                "bytes_per_launch": k_bytes, "avg_launch_us": round(k_ms * 1e3, 2),
-                "measured": "isolated: the kernel back to back over rotating layers, HIP events on the launch stream (vc_bench_kernel)",
-                "in_situ": in_situ(dom, args),
+                "achieved": round(ach_gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(ach_gbs / HBM_PEAK_GBS, 4), "traffic": tr["bytes"] if tr else None,
+                "traffic_source": ({k: tr[k] for k in ("source", "box", "lib_stamp")} if tr else None),
+                "bytes_per_launch": k_bytes, "avg_launch_us": round(ach_us, 2),
+                "measured": measured,
+                "isolated_frac": round(iso_gbs / HBM_PEAK_GBS, 4), "isolated_avg_launch_us": round(k_ms * 1e3, 2), "isolated_achieved": round(iso_gbs, 1),
+                "in_situ": ins_dom, "lib_stamp": lib_stamp(),
                 "per_layer_launches": {k: {"isolated_us": kernels[k]["avg_us"], "in_situ": in_situ(k, args)} for k in ("qkv", "attn", "oproj", "ffn1", "ffn2")}}
         # the prefill is GEMM-shaped: MFMA rooflines of its widest block GEMM (FFN up-projection) at the run's own pass
         # size and at a full 512-row pass, and of the MFMA tile attention
@@ -788,6 +855,7 @@ def main():
             # the other BASELINE configurations on their own engines (after the headline's timed region; ~20 s)
             del eng, wl
             out["configs"] = configs_block(args, dev, sd)
+            out["ragged"] = ragged_block(args, dev, sd)
         if n_gpus == 1 and not args.no_codec:
             try:
                 out["codec"] = codec_block(dev)

@@ -231,18 +231,24 @@ int vc_box_probe(long long bytes, int hops, float res[2], void* stream);
  * out[0] rows up to which the finished-row form applies; out[1] form of this pass (0 slabs + rows-GEMM, 1 finished rows, 2 wide
  * decode); out[2] attention splits; out[3] consumer kernel shape (GemmArgs.mt) or -1; out[4] / out[5] producer form of the
  * out-projection / FFN down-projection (1 one piece, 2 K in two halves, 0 = NOT LAUNCHABLE, -1 n/a); out[6] heads-1 folds finished
- * rows itself; out[7] the consumers' tile counts are even.  tests/test_plan_cpu.py walks every model width with it. */
-int vc_debug_plan(const vc_model_cfg* cfg, int compute_dtype, int rows, int32_t out[8]);
+ * rows itself; out[7] the consumers' tile counts are even.
+ * The default forms of rounds 5-6 (-1 where the row count does not take them): out[8] ONE row: the FFN down-projection finishes its row
+ * (row_gemm_fr1_k launchable at this width); out[9] ... and the QKV projection runs in the same paired 8-channel form; out[10] 2..8
+ * finished rows: the FFN down-projection in the paired form (rows_gemm_frp_k); out[11] 17..64 rows: the layer runs on rows_gemm_wd_k
+ * (1) or falls back to rows_gemm_mt_k (0); out[12] / out[13] its K slices for the out-projection / FFN down-projection; out[14] /
+ * out[15] its k-tiles per wave for K = d / K = head_hidden.  tests/test_plan_cpu.py walks every model width with it. */
+int vc_debug_plan(const vc_model_cfg* cfg, int compute_dtype, int rows, int32_t out[16]);
 /* Copies a named internal device buffer to host memory. */
 int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int64_t nbytes);
 /* Timing of the last vc_tts/vc_edit call, measured with HIP events on `stream`:
  * ms[0] = prompt build + prefill, ms[1] = decode loop, ms[2] = whole call. */
 int vc_last_timing(const vc_engine* e, float ms[3]);
-/* Average duration in ms of ONE kernel of the decode step - `which` = "qkv" | "attn" | "oproj" | "ffn1" | "ffn2" (the FFN
- * down-projection: the dominant kernel bench.py's roofline object quotes), "<name>_hot" (the same layer every launch: cache-resident),
- * "pf_ffn1" / "pf_attn" (prefill block GEMM / tile attention, FLOPs instead of bytes) or "step" (a whole decode step without the
- * sampler) - in the form a step of `n_rows` rows really launches, measured with HIP events over `iters` back-to-back launches on
- * `stream` (layers rotate: cold caches), and the algorithmic bytes (FLOPs) one launch moves. */
+/* Average duration in ms of ONE kernel of the decode step - `which` = "qkv" | "attn" | "oproj" | "ffn1" (the FFN up-projection: since
+ * round 5 the longest launch of a one-row layer, the kernel bench.py's roofline object quotes) | "ffn2", "<name>_hot" (the same layer
+ * every launch: cache-resident), "pf_ffn1" / "pf_qkv" / "pf_attn" (prefill block GEMM / tile attention, FLOPs instead of bytes),
+ * "wd_qkv" | "wd_oproj" | "wd_ffn1" | "wd_ffn2" | "wd_ln" | "wd_attn" (the launches of a WIDE decode step, n_rows in 17..64) or "step"
+ * (a whole decode step of up to 16 rows without the sampler) - in the form a step of `n_rows` rows really launches, measured with HIP
+ * events over `iters` back-to-back launches on `stream` (layers rotate: cold caches), and the algorithmic bytes (FLOPs) one launch moves. */
 int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int iters, float* avg_ms,
                     double* alg_bytes, void* stream);
 

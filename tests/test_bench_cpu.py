@@ -48,7 +48,7 @@ def test_option_state_text_round_trips_through_the_bench_helpers():
     takes it (what an in-process A/B restores afterwards)."""
     sys.path.insert(0, ROOT)
     import bench
-    t = "apf=8,0,-1,4,400,700,128|g=8|ls=3|ab=512,256|nt=63,2|fr=16,0,8|ta=2,768|r1=1,1,1,1|gpf=0,0,0|q16=1,1,2"
+    t = "apf=8,0,-1,4,400,700,128|g=8|ls=3|ab=512,256|nt=63,2|fr=16,0,8|ta=2,768|r1=1,1,1,1|gpf=0,0,0|q16=1,1,2,1"
     o = bench.options_object(t)
     assert o["text"] == t and o["attn_pf"]["cut1"] == 400 and o["graph_steps"] == 8 and o["ln_split_rows"] == 3
     assert o["one_row"] == {"fr_one": 1, "ln_trim": 1, "attn_fast": 1, "qkv_p8": 1} and o["nt"] == {"weights_mask": 63, "attn_kv": 2}
@@ -63,14 +63,23 @@ def test_in_situ_figure_is_quoted_only_for_the_configuration_it_was_traced_on(tm
     prof = tmp_path / "profiles"
     prof.mkdir()
     cfg = {"preset": "giga830M", "dtype": "bf16", "batch": 1, "lx": 80, "prompt_frames": 150, "mode": "tts"}
-    (prof / "in_situ.json").write_text(json.dumps({"source": "x", "config": cfg, "kernels": {
+    (prof / "in_situ.json").write_text(json.dumps({"source": "x", "config": cfg, "lib_stamp": "0123456789abcdef", "box": "b", "kernels": {
         "ffn2": {"name": "k", "calls": 10, "avg_us": 7.0, "algorithmic_bytes": 33579008}}}))
+    (prof / "pmc_traffic.json").write_text(json.dumps({"source": "y", "config": cfg, "lib_stamp": "0123456789abcdef", "box": "b", "kernels": {
+        "ffn2": {"fetch_bytes_per_launch": 33700000}}}))
+    (tmp_path / "voicecraft_amd").mkdir()
+    (tmp_path / "voicecraft_amd" / ".build_stamp").write_text("0123456789abcdef" + "f" * 48)
     monkeypatch.setattr(bench, "ROOT", str(tmp_path))
     a = argparse.Namespace(**cfg)
     got = bench.in_situ("ffn2", a)
-    assert got["avg_us"] == 7.0 and abs(got["frac"] - 33579008 / 7e-6 / 8e12) < 1e-3
+    assert got["avg_us"] == 7.0 and abs(got["frac"] - 33579008 / 7e-6 / 8e12) < 1e-3 and got["box"] == "b"
+    assert bench.pmc_traffic("ffn2", a) == {"bytes": 33700000, "source": "y", "box": "b", "lib_stamp": "0123456789abcdef"}
     a.batch = 8
     assert bench.in_situ("ffn2", a) is None
+    # ... and only for the BUILD it was traced on: another digest of the library's sources -> nothing is quoted
+    a.batch = 1
+    (tmp_path / "voicecraft_amd" / ".build_stamp").write_text("f" * 64)
+    assert bench.in_situ("ffn2", a) is None and bench.pmc_traffic("ffn2", a) is None
 
 
 def test_plain_multi_gpu_entry_builds_the_launcher_command_and_refuses_a_box_without_the_gpus():

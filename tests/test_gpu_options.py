@@ -139,7 +139,7 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
             eng.set_option("qkv16", q16)
             eng.set_option("wide_heads", wh)
             eng.set_option("mt_tiles", mt)
-            assert eng.options().endswith(f"|q16={q16},{wh},{mt}")
+            assert f"|q16={q16},{wh},{mt}," in eng.options()
             c0 = eng.launch_counts()
             if B == 1:
                 x, xl, y = prompts[0]
@@ -153,7 +153,7 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
                 for g, w in zip(got, want_res):
                     assert np.array_equal(g, w), q16
             if B > 16:       # heads of a wide step: once on the weight-stationary kernel, or 16 rows at a time on the rows-GEMM
-                assert (c["mt2"] + c["mt4"] > 0) if wh else (c["rows_gemm"] > 0), (wh, c)
+                assert (c["mt2"] + c["mt4"] + c["wd"] > 0) if wh else (c["rows_gemm"] > 0), (wh, c)
             res[(q16, wh, mt)] = got
         if dtype == "bf16" and B > 1:
             same = sum(int(np.array_equal(g1, g0)) for g1, g0 in zip(res[(1, 1, 2)], res[(0, 0, 0)]))
@@ -170,7 +170,10 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
             assert np.abs(lg[1] - lg[0])[live].max() < 0.25, float(np.abs(lg[1] - lg[0])[live].max())
 
 
-WIDE_FORMS = [("mt_tiles", 2), ("mt_tiles", 0), ("mt_tiles", 1), ("mt_tiles", 4)]      # launch forms of the 17..64-row GEMMs
+# launch forms of the linear layers of 17..64-row steps: rows_gemm_wd_k (round 6, the default), and the weight-stationary
+# rows_gemm_mt_k of rounds 2-5 with two / by-tile-count / two-from-33-rows / four weight tiles per workgroup
+WIDE_FORMS = [(("wide_gemm", 1),), (("wide_gemm", 0), ("mt_tiles", 2)), (("wide_gemm", 0), ("mt_tiles", 0)),
+              (("wide_gemm", 0), ("mt_tiles", 1)), (("wide_gemm", 0), ("mt_tiles", 4))]
 
 
 def _free_running_multi(eng, prompts):
@@ -193,11 +196,12 @@ def test_wide_decode_33_to_64_rows_fp32_tokens_equal_the_oracle(preset, B):
     for wh in (1, 0):
         for mt in WIDE_FORMS:
             eng.set_option("wide_heads", wh)
-            eng.set_option(*mt)
+            for name, value in mt:
+                eng.set_option(name, value)
             c0 = eng.launch_counts()
             got = _free_running_multi(eng, prompts)
             c = _delta(eng.launch_counts(), c0)
-            assert c["mt2"] + c["mt4"] + c.get("wd", 0) > 0, (wh, mt, c)
+            assert (c["wd"] > 0 and c["mt2"] + c["mt4"] == 0) if mt[0][1] else (c["mt2"] + c["mt4"] > 0 and c["wd"] == 0), (wh, mt, c)
             for u, (g, w) in enumerate(zip(got, want_res)):
                 assert np.array_equal(g, w), (wh, mt, u)
 
@@ -221,7 +225,11 @@ def test_wide_batch_whose_sequences_retire_at_different_steps(preset, B, graph):
     lens = [w.shape[2] - p[2].shape[1] for w, p in zip(want, prompts)]
     assert min(lens) * 2 <= max(lens), lens                       # the workload really is ragged
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=B, max_positions=256, use_graph=graph)
-    got = _free_running_multi(eng, prompts)
-    for u, (g, w) in enumerate(zip(got, want)):
-        assert g.shape == w.shape and np.array_equal(g, w), (u, g.shape, w.shape)
-    assert eng.last_steps == max(lens) + a.n_codebooks
+    for shrink in (1, 0):      # 1 (default): the live sequences are re-packed onto narrower steps as the others retire; 0: fixed width
+        eng.set_option("shrink", shrink)
+        got = _free_running_multi(eng, prompts)
+        for u, (g, w) in enumerate(zip(got, want)):
+            assert g.shape == w.shape and np.array_equal(g, w), (shrink, u, g.shape, w.shape)
+        assert eng.last_steps == max(lens) + a.n_codebooks
+        repacks = int(eng.debug_read("host_ms", (8,), torch.float64)[6])
+        assert (repacks >= 1) if shrink else (repacks == 0), (shrink, repacks)

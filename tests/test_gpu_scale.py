@@ -121,7 +121,7 @@ def test_thirty_two_row_decode_on_the_weight_stationary_kernel(giga):
     outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
                                        _forced=forced, _logit_steps=n)
     c = delta(eng.launch_counts(), c0)
-    assert c["mt2"] + c["mt4"] > 0, c
+    assert c["mt2"] + c["mt4"] + c["wd"] > 0, c
     lg = lg.cpu().numpy()
     steps = [0, 5, n - 1]
     worst = 0.0
@@ -280,7 +280,7 @@ def test_sixty_four_row_decode_at_giga830M(giga):
     outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3,
                                        _forced=forced, _logit_steps=n)
     c = delta(eng.launch_counts(), c0)
-    wide = c["mt2"] + c["mt4"] + c.get("wd", 0)
+    wide = c["mt2"] + c["mt4"] + c["wd"]
     assert wide >= (4 * L + 2) * (n - 1), c                 # QKV, out-projection, FFN-up, FFN-down of every layer + the two head matrices, per step
     assert c["rows_attn"] >= L * (n - 1) and c["ln_rows"] >= (2 * L + 1) * (n - 1), c
     assert c["rows_gemm_fr"] + c["rows_gemm_frp"] + c["row_gemm_fr1"] == 0, c

@@ -121,6 +121,32 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
             assert vgpr <= 128 and " nt" in body, (name, vgpr)             # 8 waves per workgroup, two workgroups per CU
 
 
+def test_wide_decode_kernel_keeps_every_row_tile_in_flight(kern):
+    """rows_gemm_wd_k (round 6, 17..64-row steps): nothing is staged and nothing is waited for before everything is requested - at
+    d = 2048 / 64 rows a wave asks for its 32 X fragments (plain loads, L2) and then its 16 weight fragments (non-temporal, HBM) in one
+    batch, runs 64 MFMAs into 8 accumulators and meets the other waves at ONE barrier; 512 threads at <= 256 registers, no scratch."""
+    import re
+    sel = {n: v for n, v in kern.items() if "rows_gemm_wd_k<" in n}
+    assert len(sel) >= 80, len(sel)
+    for name, (body, scratch, vgpr) in sel.items():
+        m = re.search(r"rows_gemm_wd_k<(\w+), (\d+), (\d+), (\d+)>", name)
+        assert m, name
+        wt, kpw, rt = m.group(1), int(m.group(2)), int(m.group(3))
+        assert scratch == 0 and vgpr <= 256, (name, scratch, vgpr)
+        assert body.count("s_barrier") == 1, name
+        ck = min(kpw, 8 if wt == "bf16_t" else 4)
+        nt_loads = len(re.findall(r"global_load_dwordx4[^\n]* nt", body))
+        mf = body.count("v_mfma_f32_16x16x32_bf16") if wt == "bf16_t" else body.count("v_mfma_f32_16x16x4_f32") // 4
+        if kpw == ck:         # one chunk: straight-line code, every fragment counted once
+            assert nt_loads == 2 * kpw and mf == 2 * rt * kpw, (name, nt_loads, mf)
+    main = {n: v for n, v in sel.items() if "rows_gemm_wd_k<bf16_t, 8, 4, 2>" in n}
+    assert main
+    for name, (body, _, vgpr) in main.items():      # FFN-up at d = 2048, 33..64 rows
+        first_wait = body.index("s_waitcnt vmcnt")
+        assert len(re.findall(r"global_load_dwordx4", body[:first_wait])) >= 48, name         # 32 X + 16 W (+ the bias) before the first wait
+        assert "ds_write_b128" in body and "ds_read_b128" in body and vgpr <= 256, (name, vgpr)
+
+
 def test_the_non_temporal_hint_survives_in_every_decode_gemm(kern):
     """Through round 3 the hint was a RUNTIME flag: the compiler merged the kernel's two load arms and dropped it - no
     non-temporal load at all in the compiled QKV, out-projection and heads-2 forms, 15 of 16 in the FFN forms (found in the ISA

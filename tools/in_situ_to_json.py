@@ -2,7 +2,7 @@
 (rocprofv3 --kernel-trace over a whole `python bench.py` run, every launch of the decode loop - rotating layers, cold caches), which
 bench.py quotes next to its isolated microbenchmark as `roofline.in_situ` when its own run matches the tag.
 usage: python tools/in_situ_to_json.py <kernel stats .txt> <out .json> [preset dtype batch lx prompt_frames mode]"""
-import json, re, sys
+import json, os, re, socket, sys
 src, dst = sys.argv[1], sys.argv[2]
 cfg = dict(zip(("preset", "dtype", "batch", "lx", "prompt_frames", "mode"), sys.argv[3:9]))
 cfg = {"preset": cfg.get("preset", "giga830M"), "dtype": cfg.get("dtype", "bf16"), "batch": int(cfg.get("batch", 1)),
@@ -33,5 +33,10 @@ for k, ps in pat.items():
                 e["frac_of_8TBs"] = round(alg[k] / (e["avg_us"] * 1e-6) / 8e12, 4)
             out["kernels"][k] = e
             break
+try:      # the library the pass was taken on (digest of its sources, voicecraft_amd/build.py) and the box: bench.py quotes the figures only for the same build
+    out["lib_stamp"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "voicecraft_amd", ".build_stamp")).read()[:16]
+except Exception:
+    out["lib_stamp"] = None
+out["box"] = socket.gethostname()
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

@@ -2,7 +2,7 @@
 correction of gfx950's FETCH_SIZE tally for wide coalesced streams, MI355X_MICROARCH.md §HBM), tagged with the bench
 configuration the pass was taken on - bench.py reports `roofline.traffic` only when its own run matches that tag.
 usage: python tools/pmc_to_json.py <pmc summary .txt> <out .json> [preset dtype batch lx prompt_frames mode]"""
-import json, re, sys
+import json, os, re, socket, sys
 src, dst = sys.argv[1], sys.argv[2]
 cfg = dict(zip(("preset", "dtype", "batch", "lx", "prompt_frames", "mode"), sys.argv[3:9]))
 cfg = {"preset": cfg.get("preset", "giga830M"), "dtype": cfg.get("dtype", "bf16"), "batch": int(cfg.get("batch", 1)),
@@ -26,5 +26,10 @@ for k, ps in pat.items():
                 calls += int(f[0]); tot += int(f[0]) * float(f[1])
             out["kernels"][k] = {"name": p, "calls": calls, "fetch_bytes_per_launch": int(round(2 * tot / calls * 1024)), "algorithmic_bytes": alg[k]}
             break
+try:      # the library the pass was taken on (digest of its sources, voicecraft_amd/build.py) and the box: bench.py quotes the figures only for the same build
+    out["lib_stamp"] = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "voicecraft_amd", ".build_stamp")).read()[:16]
+except Exception:
+    out["lib_stamp"] = None
+out["box"] = socket.gethostname()
 json.dump(out, open(dst, "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))

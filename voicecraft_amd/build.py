@@ -14,7 +14,7 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 CSRC = HERE / "csrc"
 LIB = HERE / "libvcengine.so"
-SOURCES = ["vc_gemm.hip", "vc_gemm_pf.hip", "vc_attn.hip", "vc_tokens.hip", "vc_engine.hip", "vc_codec.hip"]
+SOURCES = ["vc_gemm.hip", "vc_gemm_pf.hip", "vc_gemm_wd.hip", "vc_attn.hip", "vc_tokens.hip", "vc_engine.hip", "vc_codec.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result", "-Wno-unused-value"]
 
 
@@ -56,17 +56,25 @@ def build(force: bool = False, verbose: bool = False, variant: str = "", extra_f
     hipcc = _hipcc()
     procs = []
     objs = []
+    headers = [d for d in deps if d.suffix == ".h"]
     for src in srcs:
         obj = objdir / (src.stem + ".o")
         objs.append(obj)
+        # one translation unit is recompiled only when it, a header or the flags changed (its own stamp next to the object)
+        tu_stamp = objdir / (src.stem + ".stamp")
+        tu_digest = _digest([src, *headers]) + " ".join(FLAGS)
+        if not force and obj.exists() and tu_stamp.exists() and tu_stamp.read_text() == tu_digest:
+            continue
+        tu_stamp.unlink(missing_ok=True)
         cmd = [hipcc, *FLAGS, "-c", str(src), "-o", str(obj)]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
-    for src, p in procs:
+        procs.append((src, tu_stamp, tu_digest, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, tu_stamp, tu_digest, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src.name}:\n{out}")
+        tu_stamp.write_text(tu_digest)
         if verbose and out.strip():
             print(out, file=sys.stderr)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]

@@ -184,6 +184,8 @@ struct SeqState {
   int kept;          // 1 if this sample is the group's kept one (or independent)
   int span_steps[VC_MAX_SPANS];
   int mask_value[VC_MAX_SPANS];   // mask_embedding row inserted before span i (i >= 1)
+  int slot;          // the sequence's index in the CALL (= its KV-cache slot, its rows of the gen / forced / logits_out buffers, its Philox
+                     // stream); equal to its state's index until a wide batch is re-packed onto fewer rows (vc_tokens.hip repack_k)
 };
 
 // ---------------------------------------------------------------- kernel argument blocks
@@ -372,7 +374,7 @@ struct SampleDyn {
   int n_forced;
   int logit_steps;
   int max_steps;            // rows of the gen buffer per sequence this call may fill
-  int pad_;
+  int n_seq;                // sequences of the CALL: row stride of forced / logits_out (the step's row count may have shrunk since)
   uint64_t seed;
   const int64_t* forced;    // [n_forced][B][K] or null
   float* logits_out;        // [logit_steps][B][K][V] or null
@@ -388,6 +390,8 @@ struct SampleArgs {         // engine-constant part (kernel argument)
   SeqState* st;
   int* n_active;
   int* host_active;         // pinned host word (device-visible): set to 0 by the block that retires the last sequence
+  int* host_live;           // pinned host word: sequences still live as the step's sampler launch found them (written by its first workgroup only:
+                            // one writer, never out of order) - what the host's decode loop shrinks a wide batch by
   int* samp;                // scratch [B][K + 2]
   int* gen;                 // [B][gen_stride][K]
   // next-step rows
@@ -422,6 +426,8 @@ hipError_t vc_launch_fold_vecs(const float* W, const float* gamma, const float* 
 hipError_t vc_launch_gemm(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, int groups,
                           hipStream_t s);
 hipError_t vc_launch_gemm_blk(const GemmArgs& a, int dtype, int pro, int epi, int ksplit, hipStream_t s);   // prefill passes (vc_gemm_pf.hip)
+hipError_t vc_launch_gemm_wd(const GemmArgs& a, int dtype, int epi, int ksplit, int groups, hipStream_t s);  // wide decode steps, 17..64 rows (vc_gemm_wd.hip)
+int vc_gemm_wd_kpw(int K, int dtype, int ksplit);   // k-tiles per wave of that kernel for a K slice, 0 = no form
 size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit);
 hipError_t vc_launch_gemm_fr(const GemmArgs& a, int dtype, int pro, hipStream_t s);   // finished-row producers (vc_gemm.hip)
 size_t vc_gemm_fr_lds_bytes(int rows, int K, int dtype);
@@ -435,7 +441,7 @@ extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill blo
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one
 // they compared with the oracle.
 enum { VC_LC_ROWS_GEMM = 0, VC_LC_MT2 = 1, VC_LC_MT4 = 2, VC_LC_BLK64 = 3, VC_LC_BLK128_SBS = 4, VC_LC_BLK128_2X2 = 5,
-       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_ROWS_GEMM_FRP = 15, VC_LC_N = 16 };
+       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_ROWS_GEMM_FRP = 15, VC_LC_WD = 16, VC_LC_N = 17 };
 extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);
@@ -443,6 +449,19 @@ hipError_t vc_launch_tile_attn(const AttnArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_tile_attn64(const AttnArgs& a, hipStream_t s);   // bf16, head_dim 128, prompts on 64-row boundaries
 hipError_t vc_launch_prompt(const PromptArgs& a, hipStream_t s);
 hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s);
+// Re-packs the LIVE sequences of a batch onto rows [0, n_live) of a narrower step (B_new <= B_old rows, n_live <= B_new; stable order):
+// their states, next input rows and row tables move, retired sequences' final states go to st_fin[slot].  vc_tokens.hip repack_k.
+struct RepackArgs {
+  SeqState* st;             // [B_old] in, [B_new] out
+  SeqState* st_fin;         // [max_seqs] final states by slot
+  float* dec_h;             // [B_old][d]
+  int* row_seq;
+  int* row_pos;
+  int* logit_row;
+  int* err;                 // bit 2 raised when more than B_new sequences are still live (host logic error: nothing is moved)
+  int B_old, B_new, d;
+};
+hipError_t vc_launch_repack(const RepackArgs& a, hipStream_t s);
 hipError_t vc_launch_assemble(const AssembleArgs& a, hipStream_t s);
 
 // ---- training objective, teacher-forced (vc_eval_forward; VoiceCraft.forward, models/voicecraft.py:472-559)

@@ -74,14 +74,14 @@ struct vc_engine {
   float *dec_h = nullptr;               // [max(VC_ROWS, max_seqs)][d]
   int NS = VC_ROWS;                     // rows the per-sequence buffers are sized for
   int *dec_row_seq = nullptr, *dec_row_pos = nullptr, *logit_row = nullptr;
-  SeqState *st = nullptr;
+  SeqState *st = nullptr, *st_fin = nullptr;      // st_fin: final states by slot of sequences a re-pack moved out of the step (repack_k)
   long long* dbg_ts = nullptr;
   int *one = nullptr;                   // device word holding 1: the "always active" flag of prefill launches
   int *share_len = nullptr;             // device word: text positions shared with sequence 0 (AttnArgs.share_len), 0 outside such calls
   int *n_active = nullptr, *samp = nullptr, *cond = nullptr, *amax = nullptr, *gen = nullptr, *err_flag = nullptr;
   int gen_cap = 0;
   // pinned host staging
-  SeqState *h_st = nullptr;
+  SeqState *h_st = nullptr, *h_st2 = nullptr;
   int *h_flag = nullptr;                // [0] error/poll word, [1] staging, [8] "sequences still active" written by the device
   SampleDyn *h_dyn = nullptr, *d_dyn = nullptr;   // per-call sampler values (vc_common.h)
   // captured decode steps, kept across calls: key = (sequences, rows per sequence, best-of-N)
@@ -163,6 +163,16 @@ struct vc_engine {
   // workgroups of 512 threads - every CU busy - measured -2.6 % per step at 32 rows and -3.0 % at 64, profiles/r05t_mt_tiles_ab.log; 4 tiles
   // everywhere +4.2 %), 0 = by tile count (4 from 512 tiles on: the rule of rounds 2-4), 1 = two tiles from 33 rows on, 4 forced
   int mt_tiles = 2;
+  // option "wide_gemm" (round 6): the linear layers of 17..64-row steps on rows_gemm_wd_k (vc_gemm_wd.hip: every row tile of the step in
+  // flight at once, X fragments straight from L2 into registers, one barrier per launch) instead of the weight-stationary
+  // rows_gemm_mt_k, which walks the row tiles one after the other; 0 = the round-2..5 kernel (its "mt_tiles" then applies)
+  int wide_gemm = 1;
+  // option "shrink" (round 6): a multi-utterance call whose sequences retire at different steps re-packs the live ones onto the rows of a
+  // narrower step (the next power of two >= the live count: 64 -> 32 -> 16 -> 8 -> 4 -> 2 -> 1) instead of keeping its launch form until
+  // the longest sequence ends; 0 = the fixed width of rounds 1-5.  Results do not depend on it: everything per sequence is indexed by its slot.
+  int shrink = 1;
+  int cur_rows = 0;                     // rows per step the last decode loop ended on (tts_run reads the states back accordingly)
+  int h_parts = 0;                      // split-K slabs the last pass left pending on hB (what the heads' LayerNorm has to sum)
   // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
   // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
   int ln_trim = 1;
@@ -456,6 +466,7 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   // it and leaves h' in hA for the down-projection's epilogue
   const bool fd = fd_one(e, rs.n_rows);
   e->finished_rows_h = fd;
+  e->h_parts = e->p_f2.ksplit;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
     const float* h_res = (l == 0) ? rs.h_in : e->hB;
@@ -577,7 +588,7 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
     GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
     g.Wp = e->Wh1; nt_bit(e, g, NT_H1); g.bias = e->bh1;
     g.h_in = e->hB + (size_t)in_row0 * e->d; g.h_out = nullptr;
-    g.parts = e->parts + (size_t)in_row0 * e->d; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
+    g.parts = e->parts + (size_t)in_row0 * e->d; g.n_parts = e->h_parts; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     if (e->finished_rows_h) { g.n_parts = 0; g.has_prev_bias = 0; }       // the finished-row form left the whole residual in hB
     g.wg = e->wg_h1; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
@@ -605,20 +616,23 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
 // 17..64 rows (wide decode steps): the final LayerNorm once per row (ln_rows_k), then both head matrices on the weight-stationary
 // kernel of those steps (rows_gemm_mt_k: every weight read ONCE per step) instead of once per 16 rows - at 64 rows the 16-row passes
 // streamed the 33.6 MB of head weights four times (option "wide_heads").
+bool use_wd(const vc_engine* e, int rows);
 int run_heads_wide(vc_engine* e, int n, const int* n_active, hipStream_t s) {
   RowSrc rs{};
   rs.n_rows = n; rs.n_active = n_active;
+  const bool wd = use_wd(e, n);
   {
     GemmArgs g = base_args(e, rs, e->p_h1, e->K * e->P, e->d);
     g.Wp = e->Wh1; nt_bit(e, g, NT_H1); g.bias = e->bh1;
     g.h_in = e->hB; g.h_out = nullptr;
-    g.parts = e->parts; g.n_parts = e->p_f2.ksplit; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
+    g.parts = e->parts; g.n_parts = e->h_parts; g.prev_bias = e->layers[e->L - 1].b2; g.has_prev_bias = 1;
     g.wg = e->wg_h1;
     g.out = e->hh; g.out_ld = e->K * e->P;
     g.x_out = e->xn;
     HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
     g.x_in = e->xn; g.x_ld = e->d; g.mt = 2;
-    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_GELU, 1, 1, s));
+    if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_GELU, 1, 1, s));
+    else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_GELU, 1, 1, s));
   }
   {
     GemmArgs g = base_args(e, rs, e->p_h2, e->V, e->P);
@@ -626,7 +640,8 @@ int run_heads_wide(vc_engine* e, int n, const int* n_active, hipStream_t s) {
     g.w_group_stride = e->wh2_group_stride; g.bias_group_stride = e->V;
     g.x_in = e->hh; g.x_ld = e->K * e->P; g.x_group_stride = e->P;
     g.out = e->logits; g.mt = 2;
-    HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
+    if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_LOGITS, 1, e->K, s));
+    else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_LOGITS, 1, e->K, s));
   }
   return VC_OK;
 }
@@ -656,18 +671,41 @@ bool use_qkv16(const vc_engine* e, int rows, int mtv) {
   return !(w12 >= 240 && w16 < 240);
 }
 
+// K slices of a split-K producer on the wide-decode kernel (rows_gemm_wd_k: two 16-channel tiles per workgroup, the slice split over
+// 8 waves): the fewest slices that put a workgroup on every CU, among those the kernel has a form for; 0 = none.
+int wd_ksplit(const vc_engine* e, int N, int Kdim) {
+  const int n_wg = (N / 16 + 1) / 2;
+  int best = 0;
+  for (int ks = 1; ks <= VC_MAX_KSPLIT; ks *= 2) {
+    if (!vc_gemm_wd_kpw(Kdim, e->dtype, ks)) continue;
+    best = ks;
+    if (n_wg * ks >= 256) break;
+  }
+  return best;
+}
+// Does a pass of `rows` rows run its linear layers on rows_gemm_wd_k?  (Every matrix of the layer must have a form - the QKV projection
+// needs the 16-channel image.)
+bool use_wd(const vc_engine* e, int rows) {
+  if (!e->wide_gemm || rows <= VC_ROWS || rows > VC_MAX_SEQS || e->layers.empty() || !e->layers[0].Wqkv16 || !e->qkv16) return false;
+  const int d = e->d;
+  return vc_gemm_wd_kpw(d, e->dtype, 1) && wd_ksplit(e, d, d) && wd_ksplit(e, d, 4 * d) && vc_gemm_wd_kpw(e->P, e->dtype, 1);
+}
+
 int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
   e->finished_rows_h = false;           // this pass leaves h + split-K slabs
   // prefill passes run on the block GEMM (mt = 1); decode passes of 17..64 rows (n_active set) are still weight
   // streams: they take the weight-stationary multi-tile kernel (mt = 2), which reads every weight once at the decode rate
   const int mtv = (rs.n_active != nullptr && rs.n_rows <= VC_MAX_SEQS && !getenv("VC_WIDE_BLK")) ? 2 : 1;
+  const bool wd = mtv == 2 && use_wd(e, rs.n_rows);                 // wide decode step on rows_gemm_wd_k
+  const int ks_o = wd ? wd_ksplit(e, d, d) : e->p_o.ksplit, ks_f2 = wd ? wd_ksplit(e, d, 4 * d) : e->p_f2.ksplit;
+  e->h_parts = ks_f2;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
     {
       GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
       g.h_in = (l == 0) ? rs.h_in : e->hB; g.h_out = e->hA; g.parts = e->parts;
-      g.n_parts = (l == 0) ? 0 : e->p_f2.ksplit;
+      g.n_parts = (l == 0) ? 0 : ks_f2;
       g.prev_bias = (l == 0) ? ly.bo : e->layers[l - 1].b2; g.has_prev_bias = (l == 0) ? 0 : 1;
       g.x_out = e->xn;
       // (no piggyback prefetch on the LayerNorm launches of WIDE decode passes: measured at 32 rows with the tiles grouped as
@@ -677,7 +715,8 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       if (use_qkv16(e, rs.n_rows, mtv)) {     // every A lane a weight: the 16-channel image
         g.Wp = ly.Wqkv16; g.n_tiles = e->p_qkv16.n_tiles; g.KT = e->p_qkv16.KT; g.nchunk = e->p_qkv16.nchunk;
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV16, 1, 1, s));
+        if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_QKV16, 1, 1, s));
+        else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV16, 1, 1, s));
       } else {
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
       }
@@ -701,7 +740,8 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wo; nt_bit(e, g, NT_O); g.part_out = e->parts; g.mt = mtv;
       if (rs.nsplit == 1) {
         g.x_in = e->xn; g.x_ld = d;
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_o.ksplit, 1, s));
+        if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_PART, ks_o, 1, s));
+        else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_o.ksplit, 1, s));
       } else {
         g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
@@ -709,16 +749,18 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
     }
     {
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
-      g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
+      g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = ks_o; g.prev_bias = ly.bo; g.has_prev_bias = 1;
       g.x_out = e->xn;
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
       g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = mtv;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
+      if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_RELU, 1, 1, s));
+      else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
     }
     {
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W2; nt_bit(e, g, NT_F2); g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts; g.mt = mtv;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
+      if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_PART, ks_f2, 1, s));
+      else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
     }
   }
   return VC_OK;
@@ -805,7 +847,7 @@ SampleArgs make_sample_args(vc_engine* e, int B, int rps) {
   memset(&a, 0, sizeof a);
   a.logits = e->logits; a.B = B; a.K = e->K; a.V = e->V; a.d = e->d;
   a.empty_token = e->cfg.empty_token; a.gen_stride = e->gen_cap; a.dyn = e->d_dyn;
-  a.st = e->st; a.n_active = e->n_active; a.host_active = e->h_flag + 8; a.samp = e->samp;
+  a.st = e->st; a.n_active = e->n_active; a.host_active = e->h_flag + 8; a.host_live = e->h_flag + 9; a.samp = e->samp;
   a.gen = e->gen;
   a.rps = rps; a.dec_h = e->dec_h; a.row_seq = e->dec_row_seq; a.row_pos = e->dec_row_pos;
   a.logit_row = e->logit_row;
@@ -815,7 +857,7 @@ SampleArgs make_sample_args(vc_engine* e, int B, int rps) {
 }
 
 int push_sample_dyn(vc_engine* e, const vc_sample_cfg* sc, const int64_t* forced, int n_forced, float* logits_out,
-                    int logit_steps, int max_steps, hipStream_t s) {
+                    int logit_steps, int n_seq, hipStream_t s) {
   SampleDyn& d = *e->h_dyn;
   memset(&d, 0, sizeof d);
   d.top_k = sc->top_k; d.top_p = sc->top_p; d.temperature = sc->temperature;
@@ -827,8 +869,8 @@ int push_sample_dyn(vc_engine* e, const vc_sample_cfg* sc, const int64_t* forced
   d.seed = sc->seed;
   d.forced = forced; d.n_forced = forced ? n_forced : 0; d.forced_mode = sc->forced_mode;
   d.logits_out = logits_out; d.logit_steps = logits_out ? logit_steps : 0;
-  (void)max_steps;
   d.max_steps = e->gen_cap;                               // rows of the gen buffer per sequence
+  d.n_seq = n_seq;                                        // sequences of the call (row stride of forced / logits_out)
   d.dbg_ts = getenv("VC_SAMPLER_TS") ? e->dbg_ts : nullptr;
   HIPCHK(e, hipMemcpyAsync(e->d_dyn, e->h_dyn, sizeof(SampleDyn), hipMemcpyHostToDevice, s));
   return VC_OK;
@@ -864,11 +906,18 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
 // length); refresh_opt_state() folds it into the key of the captured graphs
 void refresh_opt_state(vc_engine* e);
 
-int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped, const vc_sample_cfg* sc,
+int decode_loop(vc_engine* e, const SampleArgs& sa0, int B0, int rps, bool grouped, const vc_sample_cfg* sc,
                 int max_steps, int* steps_run, hipStream_t s, int pos0 = 0, bool precapture_only = false) {
   const int G = std::max(1, e->steps_per_graph);
   const double t0 = now_ms();
   if (precapture_only) e->host_ms[1] = e->host_ms[2] = 0;
+  // Rows per step.  A multi-utterance call starts with one row per sequence; when few enough sequences are left (option "shrink") the
+  // live ones are re-packed onto the rows of a narrower step - the next power of two >= the live count - and the loop goes on with
+  // that width's captured graph (graphs are keyed by width).  B / sa = the width in force.
+  int B = B0;
+  SampleArgs sa = sa0;
+  const bool can_shrink = e->shrink && !grouped && rps == 1 && B0 > 1;
+  auto width_for = [](int live) { int p = 1; while (p < live) p *= 2; return p; };
   // One captured graph per (shape, option state).  The only thing that varies INSIDE a call is the prefetch length of the one-row
   // attention launch: it is worth most while the context is short (the launch's own K/V traffic grows with the position and the
   // window it leaves shrinks), so the host - which knows how many steps it has launched - picks full / half / none per graph of G
@@ -922,16 +971,38 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
       hipGraphExec_t exec = nullptr;
       rc0 = exec_for(sc_k, &exec);
     }
+    if (can_shrink)            // ... and the narrower widths a shrinking batch passes through
+      for (int w = width_for(B0) / 2; w >= 1 && rc0 == VC_OK; w /= 2) {
+        if (w >= B0) continue;
+        B = w; sa = make_sample_args(e, w, rps);
+        hipGraphExec_t exec = nullptr;
+        rc0 = exec_for(4, &exec);
+      }
     return rc0;
   }
   const double t1 = now_ms();
   volatile int* live = e->h_flag + 8;
+  volatile int* live_n = e->h_flag + 9;                   // sequences still live, as the last finished step's sampler saw them
   int launched = 0, rc = VC_OK, batch = 0;
   while (launched < max_steps && rc == VC_OK) {
     if (batch >= 2) {   // pace: at most two batches in flight; the older one must have ended before a third is queued
       hipError_t we = hipEventSynchronize(e->ev_pace[batch & 1]);
       if (we != hipSuccess) { rc = fail(e, VC_EHIP, "pacing event: %s", hipGetErrorString(we)); break; }
       if (*live <= 0) break;
+      if (can_shrink) {
+        const int n_live = *live_n;                       // (only ever decreases; the steps already queued can only lower it further)
+        const int w = n_live >= 1 ? width_for(n_live) : B;
+        if (w < B) {
+          RepackArgs ra;
+          memset(&ra, 0, sizeof ra);
+          ra.st = e->st; ra.st_fin = e->st_fin; ra.dec_h = e->dec_h; ra.row_seq = e->dec_row_seq; ra.row_pos = e->dec_row_pos;
+          ra.logit_row = e->logit_row; ra.err = e->err_flag; ra.B_old = B; ra.B_new = w; ra.d = e->d;
+          hipError_t re = vc_launch_repack(ra, s);
+          if (re != hipSuccess) { rc = fail(e, VC_EHIP, "re-pack launch: %s", hipGetErrorString(re)); break; }
+          B = w; sa = make_sample_args(e, w, rps);
+          e->host_ms[6] += 1;                             // re-packs of this call
+        }
+      }
     }
     const int scale = scale_at(pos0 + launched);
     if (sc->use_graph) {
@@ -955,6 +1026,7 @@ int decode_loop(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
   e->host_ms[3] = now_ms() - t1;
   e->host_ms[4] = 0;
   e->host_ms[5] = launched;                               // decode steps LAUNCHED (a multiple of steps_per_graph; the tail are no-ops)
+  e->cur_rows = B;
   if (steps_run) *steps_run = launched;
   return rc;
 }
@@ -993,6 +1065,8 @@ int check_err_flag(vc_engine* e, hipStream_t s) {
     (void)hipMemsetAsync(e->err_flag, 0, sizeof(int), s);   // already on the error path
     if (bits & 2)
       return fail(e, VC_EINVAL, "shared_text_prefix: a sequence's text differs from sequence 0's inside the shared prefix");
+    if (bits & 4)
+      return fail(e, VC_ESTATE, "internal: a re-pack found more live sequences than the narrower step has rows");
     return fail(e, VC_EINVAL, "token id out of range in x or y (text rows %d, audio vocab %d)", e->cfg.text_rows, e->V);
   }
   return VC_OK;
@@ -1036,6 +1110,8 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "mt_tiles") {
     if (v0 != 0 && v0 != 1 && v0 != 2 && v0 != 4) return fail(e, VC_EINVAL, "option 'mt_tiles': 0 (by tile count), 1 (two tiles from 33 rows on), 2 or 4");
     e->mt_tiles = v0;
+  } else if (name == "wide_gemm") { e->wide_gemm = v0 ? 1 : 0;
+  } else if (name == "shrink") { e->shrink = v0 ? 1 : 0;
   } else if (name == "qkv16") {
     if (v0 && !e->layers.empty() && !e->layers[0].Wqkv16)
       return fail(e, VC_ESTATE, "option 'qkv16': this engine was created with VC_QKV16=0 and holds no 16-channel image of the QKV matrix");
@@ -1052,10 +1128,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d|q16=%d,%d,%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d|q16=%d,%d,%d,%d|sh=%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb, e->qkv16, e->wide_heads, e->mt_tiles);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb, e->qkv16, e->wide_heads, e->mt_tiles, e->wide_gemm, e->shrink);
   e->opt_state = buf;
 }
 
@@ -1063,7 +1139,7 @@ void refresh_opt_state(vc_engine* e) {
 
 // =====================================================================================  C ABI
 // Host-only: how a decode pass of `rows` rows would be launched for this model shape and compute dtype (no engine, no GPU).
-extern "C" int vc_debug_plan(const vc_model_cfg* c, int compute_dtype, int rows, int32_t out[8]) {
+extern "C" int vc_debug_plan(const vc_model_cfg* c, int compute_dtype, int rows, int32_t out[16]) {
   if (!c || !out || rows < 1 || rows > VC_MAX_SEQS || c->d_model <= 0 || c->nhead <= 0 || c->d_model % c->nhead) return VC_EINVAL;
   if (compute_dtype != VC_DTYPE_BF16 && compute_dtype != VC_DTYPE_F32) return VC_EINVAL;
   vc_engine e;
@@ -1079,6 +1155,20 @@ extern "C" int vc_debug_plan(const vc_model_cfg* c, int compute_dtype, int rows,
   out[5] = fr ? vc_gemm_fr_form(rows, d, 4 * d, compute_dtype, PRO_PLAIN, 1) : -1;                      // FFN-down producer form
   out[6] = fr && rows <= VC_FR_MAX_ROWS ? 1 : 0;                              // heads-1 folds finished rows itself (else LayerNorm launch)
   out[7] = (3 * d / VC_TH_QKV) % 2 == 0 && (4 * d / 16) % 2 == 0 ? 1 : 0;     // the consumers' tile counts are even (two tiles per workgroup)
+  // the default forms of rounds 5-6, from the launchers' own predicates
+  for (int i = 8; i < 16; ++i) out[i] = -1;
+  if (rows == 1) {
+    out[8] = vc_gemm_fr1_ok(d, 4 * d, compute_dtype, VC_FR_WAVES) ? 1 : 0;                       // fr_one: FFN-down finishes its row
+    out[9] = out[8] && vc_gemm_fr1_ok(3 * d, d, compute_dtype, 4) ? 1 : 0;                       // qkv_p8: the paired QKV projection behind it
+  }
+  if (fr && rows <= VC_FR_MAX_ROWS) out[10] = vc_gemm_frp_ok(rows, d, 4 * d, compute_dtype) ? 1 : 0;   // fr_pair
+  if (rows > VC_ROWS) {
+    e.P = c->head_hidden;
+    const int ko = wd_ksplit(&e, d, d), kf = wd_ksplit(&e, d, 4 * d);
+    out[12] = ko; out[13] = kf;
+    out[14] = vc_gemm_wd_kpw(d, compute_dtype, 1); out[15] = vc_gemm_wd_kpw(c->head_hidden, compute_dtype, 1);
+    out[11] = (ko && kf && out[14] && out[15]) ? 1 : 0;
+  }
   return VC_OK;
 }
 
@@ -1134,6 +1224,7 @@ extern "C" void vc_destroy(vc_engine* e) {
   for (auto& kv : e->raw) if (kv.second.dev) (void)hipFree(kv.second.dev);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->h_st) (void)hipHostFree(e->h_st);
+  if (e->h_st2) (void)hipHostFree(e->h_st2);
   if (e->h_flag) (void)hipHostFree(e->h_flag);
   if (e->h_dyn) (void)hipHostFree(e->h_dyn);
   for (auto& kv : e->graphs) if (kv.second) (void)hipGraphExecDestroy(kv.second);
@@ -1326,6 +1417,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->dec_row_pos, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->logit_row, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->st, (size_t)e->NS))) return rc;
+  if ((rc = dalloc(e, &e->st_fin, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
@@ -1342,6 +1434,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipMemset(e->n_active, 0, 16));
   { const int one[4] = {1, 1, 1, 1}; HIPCHK(e, hipMemcpy(e->one, one, 16, hipMemcpyHostToDevice)); }
   HIPCHK(e, hipHostMalloc((void**)&e->h_st, sizeof(SeqState) * e->NS));
+  HIPCHK(e, hipHostMalloc((void**)&e->h_st2, sizeof(SeqState) * e->NS));
   HIPCHK(e, hipHostMalloc((void**)&e->h_flag, 64));
   memset(e->h_flag, 0, 64);
   HIPCHK(e, hipHostMalloc((void**)&e->h_dyn, sizeof(SampleDyn)));
@@ -1356,7 +1449,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_MT_TILES", "mt_tiles"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1419,6 +1512,7 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
       pas[b].x_shared = jobs[0].x;                        // ... and checked on the device to be the same text (prompt_k)
       slots[b] = b;
       e->h_st[b] = init_state(e, j.Lx, j.T + 1, true, 1);
+      e->h_st[b].slot = b;
     }
     e->h_flag[2] = shared_prefix;
     HIPCHK(e, hipMemcpyAsync(e->share_len, e->h_flag + 2, sizeof(int), hipMemcpyHostToDevice, s));
@@ -1436,14 +1530,18 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
     for (int b = 1; b < B; ++b) {   // every sample starts from the same first-step logits
       HIPCHK(e, hipMemcpyAsync(e->logits + (size_t)b * K * e->V, e->logits, (size_t)K * e->V * 4, hipMemcpyDeviceToDevice, s));
       e->h_st[b] = e->h_st[0];
+      e->h_st[b].slot = b;
     }
     for (int b = 0; b < B; ++b) e->h_st[b].group = 0;
   }
   HIPCHK(e, hipMemcpyAsync(e->st, e->h_st, sizeof(SeqState) * B, hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemsetAsync(e->st_fin, 0, sizeof(SeqState) * B, s));
   e->h_flag[1] = B;
   e->h_flag[8] = B;
+  e->h_flag[9] = B;
+  e->host_ms[6] = 0;
   HIPCHK(e, hipMemcpyAsync(e->n_active, e->h_flag + 1, sizeof(int), hipMemcpyHostToDevice, s));
-  int rc = push_sample_dyn(e, sc, forced, n_forced, logits_out, logit_steps, max_steps, s);
+  int rc = push_sample_dyn(e, sc, forced, n_forced, logits_out, logit_steps, B, s);
   if (rc) return rc;
   rc = check_err_flag(e, s);   // also orders the pinned-buffer reuse
   if (rc) return rc;
@@ -1459,8 +1557,21 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s, pos0);
   if (rc) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
-  HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
-  HIPCHK(e, hipStreamSynchronize(s));
+  if (e->cur_rows == B) {
+    HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+  } else {      // the batch was re-packed onto fewer rows on the way: final states = the parked ones + the rows of the last layout, by slot
+    const int Bc = e->cur_rows;
+    HIPCHK(e, hipMemcpyAsync(e->h_st, e->st_fin, sizeof(SeqState) * B, hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipMemcpyAsync(e->h_st2, e->st, sizeof(SeqState) * Bc, hipMemcpyDeviceToHost, s));
+    HIPCHK(e, hipStreamSynchronize(s));
+    for (int r = 0; r < Bc; ++r) {
+      const int slot = e->h_st2[r].slot;
+      if (slot >= 0 && slot < B) e->h_st[slot] = e->h_st2[r];
+    }
+    rc = check_err_flag(e, s);
+    if (rc) return rc;
+  }
   HIPCHK(e, hipEventElapsedTime(&e->ms[0], e->ev[0], e->ev[1]));
   HIPCHK(e, hipEventElapsedTime(&e->ms[1], e->ev[1], e->ev[2]));
   e->ms[2] = e->ms[0] + e->ms[1];
@@ -1616,7 +1727,7 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   e->h_flag[1] = 1;
   e->h_flag[8] = 1;
   HIPCHK(e, hipMemcpyAsync(e->n_active, e->h_flag + 1, sizeof(int), hipMemcpyHostToDevice, s));
-  rc = push_sample_dyn(e, sc, forced_dev, n_forced, logits_dev, logit_steps, max_steps, s);
+  rc = push_sample_dyn(e, sc, forced_dev, n_forced, logits_dev, logit_steps, 1, s);
   if (rc) return rc;
   rc = check_err_flag(e, s);
   if (rc) return rc;
@@ -1905,15 +2016,17 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
   if (rc) return rc;
   if (!which || n_rows < 1 || iters < 1 || !avg_ms) return fail(e, VC_EINVAL, "bad argument to vc_bench_kernel");
   const bool pf = std::string(which).rfind("pf_", 0) == 0;      // prefill block GEMM: up to VC_MAX_ROWS rows
-  if (n_rows > (pf ? VC_MAX_ROWS : VC_ROWS)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed %d", n_rows, pf ? VC_MAX_ROWS : VC_ROWS);
+  const bool wide = std::string(which).rfind("wd_", 0) == 0;    // a linear layer of a wide decode step: 17..VC_MAX_SEQS rows
+  if (wide && n_rows <= VC_ROWS) return fail(e, VC_EINVAL, "vc_bench_kernel: '%s' takes 17..%d rows", which, VC_MAX_SEQS);
+  if (n_rows > (pf ? VC_MAX_ROWS : wide ? VC_MAX_SEQS : VC_ROWS)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed %d", n_rows, pf ? VC_MAX_ROWS : wide ? VC_MAX_SEQS : VC_ROWS);
   if (pf && (n_rows > e->emb_cap || ((std::string(which) == "pf_attn" || std::string(which) == "pf_qkv") && n_rows > e->S_max)))
     return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed the prefill arena / cache", n_rows);
   hipStream_t s = stream ? (hipStream_t)stream : e->own_stream;
   const std::string w = which;
   const int d = e->d;
   // neutral rows: sequence 0, positions 0..n_rows-1 (position only matters to attention/caches)
-  std::vector<int> seq(VC_ROWS, 0), pos(VC_ROWS, 0);
-  for (int i = 0; i < VC_ROWS; ++i) pos[i] = i;
+  std::vector<int> seq(VC_MAX_SEQS, 0), pos(VC_MAX_SEQS, 0);
+  for (int i = 0; i < VC_MAX_SEQS; ++i) pos[i] = i;
   if (std::string(which).rfind("attn", 0) == 0)          // attention: a 16 s utterance's worth of cached positions
     for (int i = 0; i < VC_ROWS; ++i) pos[i] = std::min(e->S_max - 1, 883);
   if (pf) {   // prefill row tables: sequence 0, positions 0..n_rows-1
@@ -1923,8 +2036,16 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     HIPCHK(e, hipMemcpyAsync(e->pre_row_pos, ppos.data(), (size_t)n_rows * 4, hipMemcpyHostToDevice, s));
     HIPCHK(e, hipStreamSynchronize(s));                   // the staging vectors die with this scope
   }
-  HIPCHK(e, hipMemcpyAsync(e->dec_row_seq, seq.data(), VC_ROWS * 4, hipMemcpyHostToDevice, s));
-  HIPCHK(e, hipMemcpyAsync(e->dec_row_pos, pos.data(), VC_ROWS * 4, hipMemcpyHostToDevice, s));
+  if (w == "wd_attn")      // every row its own sequence slot, at the last position of a 16 s utterance: n_rows caches streamed
+    for (int i = 0; i < VC_MAX_SEQS; ++i) { seq[i] = i % std::max(1, e->B_max); pos[i] = std::min(e->S_max - 1, 883); }
+  const int n_tab = wide ? std::min(e->NS, VC_MAX_SEQS) : VC_ROWS;      // (wide: rows 0..n_rows-1 of sequence 0, positions 0.. - needs max_positions >= n_rows)
+  if (wide && (n_rows > e->NS || n_rows > e->S_max || n_rows > e->B_max)) return fail(e, VC_EINVAL, "vc_bench_kernel: %d rows exceed max_seqs / max_positions", n_rows);
+  HIPCHK(e, hipMemcpyAsync(e->dec_row_seq, seq.data(), (size_t)n_tab * 4, hipMemcpyHostToDevice, s));
+  HIPCHK(e, hipMemcpyAsync(e->dec_row_pos, pos.data(), (size_t)n_tab * 4, hipMemcpyHostToDevice, s));
+  if (wide) {
+    HIPCHK(e, hipMemsetAsync(e->act, 0, (size_t)n_rows * 4 * d * e->esz, s));
+    HIPCHK(e, hipMemsetAsync(e->xn, 0, (size_t)n_rows * d * e->esz, s));
+  }
   HIPCHK(e, hipMemsetAsync(e->dec_h, 0, (size_t)VC_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->hA, 0, (size_t)VC_ROWS * d * 4, s));
   HIPCHK(e, hipMemsetAsync(e->hB, 0, (size_t)VC_ROWS * d * 4, s));
@@ -1945,6 +2066,55 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
     const bool split_ln = n_rows >= e->ln_split_rows;   // the engine then normalises in ln_rows_k and takes the plain prologue
+    if (wide) {      // one linear layer of a 17..64-row step, in the form prefill_rows launches it there (options wide_gemm / mt_tiles / qkv16)
+      const bool wd = use_wd(e, n_rows);
+      RowSrc rw = rs;
+      rw.n_active = e->one; rw.nsplit = 1;
+      if (w == "wd_ffn1") {
+        GemmArgs g = base_args(e, rw, e->p_f1, 4 * d, d);
+        g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.x_in = e->xn; g.x_ld = d; g.out = e->act; g.out_ld = 4 * d; g.mt = 2;
+        if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_RELU, 1, 1, s));
+        else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_RELU, 1, 1, s));
+      } else if (w == "wd_ffn2") {
+        GemmArgs g = base_args(e, rw, e->p_f2, d, 4 * d);
+        g.Wp = ly.W2; nt_bit(e, g, NT_F2); g.x_in = e->act; g.x_ld = 4 * d; g.part_out = e->parts; g.mt = 2;
+        if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_PART, wd_ksplit(e, d, 4 * d), 1, s));
+        else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_f2.ksplit, 1, s));
+      } else if (w == "wd_oproj") {
+        GemmArgs g = base_args(e, rw, e->p_o, d, d);
+        g.Wp = ly.Wo; nt_bit(e, g, NT_O); g.x_in = e->xn; g.x_ld = d; g.part_out = e->parts; g.mt = 2;
+        if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_PART, wd_ksplit(e, d, d), 1, s));
+        else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_PART, e->p_o.ksplit, 1, s));
+      } else if (w == "wd_qkv") {
+        GemmArgs g = base_args(e, rw, e->p_qkv, 3 * d, d);
+        g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = 2;
+        g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
+        if (use_qkv16(e, n_rows, 2)) {
+          g.Wp = ly.Wqkv16; g.n_tiles = e->p_qkv16.n_tiles; g.KT = e->p_qkv16.KT; g.nchunk = e->p_qkv16.nchunk;
+          if (wd) HIPCHK(e, vc_launch_gemm_wd(g, e->dtype, EPI_QKV16, 1, 1, s));
+          else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV16, 1, 1, s));
+        } else {
+          HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_PLAIN, EPI_QKV, 1, 1, s));
+        }
+      } else if (w == "wd_ln") {      // the per-row LayerNorm launch in front of the FFN up-projection (h + bias + the out-projection's slabs)
+        GemmArgs g = base_args(e, rw, e->p_f1, 4 * d, d);
+        g.h_in = e->hA; g.h_out = e->hB; g.parts = e->parts; g.n_parts = wd ? wd_ksplit(e, d, d) : e->p_o.ksplit; g.prev_bias = ly.bo; g.has_prev_bias = 1;
+        g.x_out = e->xn;
+        HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
+      } else if (w == "wd_attn") {    // the decode attention of that step: n_rows rows of ONE sequence slot at its last position (timing only)
+        AttnArgs a;
+        memset(&a, 0, sizeof a);
+        a.q = e->q; a.kcache = ly.kc; a.vcache = ly.vc; a.cache_seq_stride = (long)e->H * e->S_max * e->hd;
+        a.S_max = e->S_max; a.H = e->H; a.hd = e->hd; a.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7; a.d = d; a.nsplit = 1; a.scale = 1.0f / sqrtf((float)e->hd);
+        a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
+        a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = attn_nt_for(e, n_rows); a.x_out = e->xn;
+        a.fast = e->attn_fast;
+        HIPCHK(e, vc_launch_attn(a, e->dtype, n_rows, s));
+      } else {
+        return fail(e, VC_EINVAL, "unknown kernel '%s'", which);
+      }
+      return VC_OK;
+    }
     if (n_rows >= 2 && n_rows <= fr_max_rows(e) && (w == "ffn1" || w == "ffn2" || w == "qkv" || w == "oproj")) {
       // the forms a step of this many rows really launches (forward_rows_fr): finished rows in, finished rows out
       if (w == "ffn1") {
@@ -2059,7 +2229,13 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     const double es = e->esz;
     const std::string& w = w2;
     double b = 0;
-    if (w == "ffn1") b = 4.0 * d * d * es + n_rows * (d * 4.0 + 4.0 * d * es);
+    if (w == "wd_ffn1") b = 4.0 * d * d * es + n_rows * (d * es + 4.0 * d * es);
+    else if (w == "wd_ffn2") b = 4.0 * d * d * es + n_rows * (4.0 * d * es + d * 4.0 * (use_wd(e, n_rows) ? wd_ksplit(e, d, 4 * d) : e->p_f2.ksplit));
+    else if (w == "wd_qkv") b = 3.0 * d * d * es + n_rows * (d * es + d * 4.0 + 2.0 * d * es);
+    else if (w == "wd_oproj") b = 1.0 * d * d * es + n_rows * (d * es + d * 4.0 * (use_wd(e, n_rows) ? wd_ksplit(e, d, d) : e->p_o.ksplit));
+    else if (w == "wd_ln") b = n_rows * (d * 4.0 * (2 + (use_wd(e, n_rows) ? wd_ksplit(e, d, d) : e->p_o.ksplit)) + d * es);
+    else if (w == "wd_attn") b = n_rows * 2.0 * d * es * (std::min(e->S_max - 1, 883) + 1);
+    else if (w == "ffn1") b = 4.0 * d * d * es + n_rows * (d * 4.0 + 4.0 * d * es);
     else if (w == "ffn2") b = 4.0 * d * d * es + n_rows * (4.0 * d * es + d * 4.0);
     else if (w == "qkv") b = 3.0 * d * d * es + n_rows * (d * 4.0 + 3.0 * d * es);
     else if (w == "oproj") b = 1.0 * d * d * es + n_rows * (d * 4.0 * 2);

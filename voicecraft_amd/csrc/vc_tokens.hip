@@ -1,6 +1,7 @@
 // vc_tokens.hip — the integer side of the path: delayed-codebook pattern kernels, prompt
 // construction (+ embedding gather), the device-side sampler / end-of-generation state machine
 // and the output assembly.  Everything here that produces token ids is bit-exact by contract.
+#include <stddef.h>
 #include <string.h>
 #include <algorithm>
 #include "vc_common.h"
@@ -331,7 +332,7 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, const SampleDy
   // the fields this phase reads, fetched from LDS in one go
   const int st_done = sp->done, step = sp->total_steps, term = sp->term_token, kill = sp->kill_token, n_eog = sp->n_eog;
   const int min_gen = sp->min_gen, cur_num_gen = sp->cur_num_gen, prev_token = sp->prev_token, consec = sp->consec_silence;
-  const int y_len = sp->y_len, cap_len = sp->cap_len;
+  const int y_len = sp->y_len, cap_len = sp->cap_len, slot = sp->slot;
   if (st_done) return;
   const int V = a.V;
   const int VP = ((V + 63) >> 6) << 6;
@@ -347,7 +348,7 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, const SampleDy
       for (int j = 0; j < VC_VPL; ++j) v[j] = row[min(lane + 64 * j, V - 1)];
     }
     if (dy.logits_out && step < dy.logit_steps) {
-      float* lo = dy.logits_out + (((long)step * a.B + b) * a.K + k) * V;
+      float* lo = dy.logits_out + (((long)step * dy.n_seq + slot) * a.K + k) * V;
 #pragma unroll
       for (int j = 0; j < VC_VPL; ++j) if (lane + 64 * j < V) lo[lane + 64 * j] = v[j];
     }
@@ -387,10 +388,10 @@ __device__ __forceinline__ void sample_phase(const SampleArgs& a, const SampleDy
       bi = wave_min_i(bi);
     }
     VC_TS(2);
-    const float u = philox_uniform(dy.seed, (uint32_t)b, (uint32_t)step, (uint32_t)k);
+    const float u = philox_uniform(dy.seed, (uint32_t)slot, (uint32_t)step, (uint32_t)k);
     int tok = filter_draw(dy.top_k, dy.top_p, dy.temperature, v, bv, V, u);
     if (dy.forced && dy.forced_mode == 1 && step < dy.n_forced)      // replay of recorded reference draws (parity tests)
-      tok = (int)dy.forced[((long)step * a.B + b) * a.K + k];
+      tok = (int)dy.forced[((long)step * dy.n_seq + slot) * a.K + k];
     if (lane == 0) {
       xs[k] = tok;
       if (k == 0) xs[a.K] = bi;
@@ -415,7 +416,7 @@ __device__ void advance_phase(const SampleArgs& a, const SampleDyn& dy, int b, b
   const int K = a.K;
   if (tid == 0) {
     // scalar fields in registers (fetched from LDS in one go); only the span arrays are indexed dynamically
-    const int done0 = sp->done, Lx = sp->Lx, term = sp->term_token, group = sp->group, n_spans = sp->n_spans;
+    const int done0 = sp->done, Lx = sp->Lx, term = sp->term_token, group = sp->group, n_spans = sp->n_spans, slot = sp->slot;
     int n_eog = sp->n_eog, cur = sp->cur_num_gen, prev = sp->prev_token, consec = sp->consec_silence;
     int span = sp->span, total = sp->total_steps, y_len = sp->y_len;
     int mode = 0, mask = 0, ylen_row = y_len;
@@ -441,7 +442,7 @@ __device__ void advance_phase(const SampleArgs& a, const SampleDyn& dy, int b, b
           if (k < K && k > cur) tok[k] = a.empty_token;
         if (forced) {
 #pragma unroll
-          for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) tok[k] = (int)dy.forced[((long)step * a.B + b) * K + k];
+          for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) tok[k] = (int)dy.forced[((long)step * dy.n_seq + slot) * K + k];
           cond = (tok[0] == term);
         }
         if (cond) { tok[0] = term; n_eog = 1; }
@@ -455,7 +456,7 @@ __device__ void advance_phase(const SampleArgs& a, const SampleDyn& dy, int b, b
         }
         if (forced) {
 #pragma unroll
-          for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) tok[k] = (int)dy.forced[((long)step * a.B + b) * K + k];
+          for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) tok[k] = (int)dy.forced[((long)step * dy.n_seq + slot) * K + k];
         }
         n_eog += 1;
       }
@@ -466,7 +467,7 @@ __device__ void advance_phase(const SampleArgs& a, const SampleDyn& dy, int b, b
       for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) asm volatile("" : "+v"(tok[k]));
       if (step < dy.max_steps) {
 #pragma unroll
-        for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) a.gen[((long)b * a.gen_stride + step) * K + k] = tok[k];
+        for (int k = 0; k < VC_MAX_CODEBOOKS; ++k) if (k < K) a.gen[((long)slot * a.gen_stride + step) * K + k] = tok[k];
       }
       total = step + 1;
 #pragma unroll
@@ -506,7 +507,7 @@ __device__ void advance_phase(const SampleArgs& a, const SampleDyn& dy, int b, b
     s_mode = mode; s_mask = mask; s_ylen = ylen_row; s_Lx = Lx;
     const int r0 = b * a.rps;
     for (int i = 0; i < a.rps; ++i) {
-      a.row_seq[r0 + i] = b;
+      a.row_seq[r0 + i] = slot;
       a.row_pos[r0 + i] = (i < mode) ? (Lx + ylen_row + i) : -1;
     }
     a.logit_row[b] = r0 + (mode == 3 ? 2 : 0);
@@ -603,6 +604,7 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   const SampleDyn dy = *a.dyn;
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
+  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.host_live, active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   VC_TS(0);
   if (dy.dbg_ts && b < 8 && threadIdx.x == 0) {   // diagnosis: entry / exit clock of every block
     dy.dbg_ts[16 + 2 * b] = t_entry;
@@ -674,6 +676,67 @@ hipError_t vc_launch_sample(const SampleArgs& a, bool grouped, hipStream_t s) {
     hipLaunchKernelGGL(sample_only_k, dim3(a.B), dim3(256), lds, s, a);
     hipLaunchKernelGGL(advance_only_k, dim3(a.B), dim3(256), 0, s, a);
   }
+  return hipGetLastError();
+}
+
+// =============================================================== re-packing a wide batch onto fewer rows
+// A multi-utterance call keeps one ROW of the decode step per sequence; sequences retire at different steps (their own terminator /
+// length cap, models/voicecraft.py:1041-1045 per sequence), and a retired row idles in place.  Once few enough are left for a
+// narrower launch form, the host's decode loop queues this kernel between two graphs: the live sequences move - in their order - to rows
+// [0, n_live) (state, next input row, row tables), rows [n_live, B_new) become inactive fillers, and the final states of the retired
+// ones are parked in st_fin[slot].  Everything per-SEQUENCE (KV cache, gen log, forced / logits_out rows, Philox stream) is
+// indexed by SeqState.slot and does not move.  One workgroup; runs a handful of times per call.
+__global__ __launch_bounds__(256) void repack_k(const RepackArgs a) {
+  __shared__ SeqState s_st[VC_MAX_SEQS];
+  __shared__ int s_src[VC_MAX_SEQS], s_pos[VC_MAX_SEQS], s_live;
+  const int tid = threadIdx.x;
+  constexpr int W = sizeof(SeqState) / 4;
+  for (int i = tid; i < a.B_old * W; i += blockDim.x) reinterpret_cast<int*>(s_st)[i] = reinterpret_cast<const int*>(a.st)[i];
+  if (tid < a.B_old) s_pos[tid] = a.row_pos[tid];
+  __syncthreads();
+  if (tid == 0) {
+    int n = 0;
+    for (int r = 0; r < a.B_old; ++r)
+      if (!s_st[r].done) s_src[n++] = r;
+    s_live = n;
+    if (n > a.B_new) atomicOr(a.err, 4);
+  }
+  __syncthreads();
+  const int n_live = s_live;
+  if (n_live > a.B_new) return;
+  // final states of the retired sequences, by slot
+  for (int r = 0; r < a.B_old; ++r) {
+    if (!s_st[r].done || s_st[r].slot < 0) continue;
+    if (tid < W) reinterpret_cast<int*>(a.st_fin + s_st[r].slot)[tid] = reinterpret_cast<const int*>(s_st + r)[tid];
+  }
+  // states and row tables of the new layout
+  for (int r = 0; r < a.B_new; ++r) {
+    if (r < n_live) {
+      if (tid < W) reinterpret_cast<int*>(a.st + r)[tid] = reinterpret_cast<const int*>(s_st + s_src[r])[tid];
+      if (tid == 0) { a.row_seq[r] = s_st[s_src[r]].slot; a.row_pos[r] = s_pos[s_src[r]]; a.logit_row[r] = r; }
+    } else {       // filler: a finished state that owns no sequence
+      if (tid < W) reinterpret_cast<int*>(a.st + r)[tid] = (tid == (int)(offsetof(SeqState, done) / 4)) ? 1 : (tid == (int)(offsetof(SeqState, slot) / 4)) ? -1 : 0;
+      if (tid == 0) { a.row_seq[r] = 0; a.row_pos[r] = -1; a.logit_row[r] = r; }
+    }
+  }
+  // next input rows: source index >= destination and increasing, so walking the destinations in order never reads a row already overwritten
+  const int nq = a.d >> 2;
+  for (int r = 0; r < n_live; ++r) {
+    const int src = s_src[r];
+    if (src == r) continue;
+    const float4* sp = reinterpret_cast<const float4*>(a.dec_h + (long)src * a.d);
+    float4* dp = reinterpret_cast<float4*>(a.dec_h + (long)r * a.d);
+    float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+    if (tid < nq) v0 = sp[tid];
+    if (tid + 256 < nq) v1 = sp[tid + 256];
+    if (tid < nq) dp[tid] = v0;
+    if (tid + 256 < nq) dp[tid + 256] = v1;
+    __syncthreads();
+  }
+}
+hipError_t vc_launch_repack(const RepackArgs& a, hipStream_t s) {
+  if (a.B_old < 1 || a.B_old > VC_MAX_SEQS || a.B_new < 1 || a.B_new > a.B_old || a.d > 2048) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(repack_k, dim3(1), dim3(256), 0, s, a);
   return hipGetLastError();
 }
 

@@ -466,12 +466,12 @@ class VoiceCraftEngine:
         return ms.value, nbytes.value
 
     LAUNCH_FORMS = ("rows_gemm", "mt2", "mt4", "blk64", "blk128_sbs", "blk128_2x2", "blk64_occ2", "ln_rows", "rows_attn",
-                    "tile_attn", "rows_gemm_fr", "big256", "big128", "row_gemm_fr1", "tile_attn64", "rows_gemm_frp")
+                    "tile_attn", "rows_gemm_fr", "big256", "big128", "row_gemm_fr1", "tile_attn64", "rows_gemm_frp", "wd")
 
     def launch_counts(self) -> dict:
         """Process-wide census of the kernel FORMS launched so far (vc_common.h VC_LC_*): the parity tests take the
         difference around a call to assert which form a benchmarked shape really runs on."""
-        c = self.debug_read("launch_counts", (16,), torch.int64)
+        c = self.debug_read("launch_counts", (len(self.LAUNCH_FORMS),), torch.int64)
         return {n: int(c[i]) for i, n in enumerate(self.LAUNCH_FORMS)}
 
     def debug_read(self, name: str, shape, dtype=torch.float32) -> torch.Tensor:
