@@ -60,9 +60,9 @@ def parse():
                    help="collective backend for N > 1: nccl = RCCL over xGMI (one GPU per rank); gloo = host collectives, usable when "
                         "several ranks share ONE GPU (VC_RANKS_SHARE_DEVICE=1: the single-GPU test of the N > 1 code path)")
     p.add_argument("--ab", default="auto", metavar="KNOB=A:B",
-                   help="in-process A/B of one engine option (vc_set_option), e.g. attn_pf=0:8,0,32 - interleaved pairs of whole calls, "
+                   help="in-process A/B of one engine option (vc_set_option), e.g. fr_one=0:1 - interleaved pairs of whole calls, "
                         "reported as the `ab` object of the JSON line.  auto (default, N = 1 only): the default-ON launch-shape feature "
-                        "of this run's step - attn_pf=0:8,0,-1 (half of every FFN-up tile) at one row per step, finished_rows=0:16 at 2..16 rows, attn_nt=0:2 above; none: skip")
+                        "of this run's step - fr_one=0:1 at one row per step, finished_rows=0:16 at 2..16 rows, wide_gemm=0:1 above; none: skip")
     p.add_argument("--ab-pairs", type=int, default=7)
     return p.parse_args()
 
@@ -119,10 +119,10 @@ def in_situ(kernel, args):
 
 
 # option name -> (key of the option-state text, positions of its values there)
-OPTION_STATE = {"attn_pf": ("apf", (0, 1, 2)), "attn_pf_cut": ("apf", (4, 5, 6)), "graph_steps": ("g", (0,)),
+OPTION_STATE = {"graph_steps": ("g", (0,)),
                 "ln_split_rows": ("ls", (0,)), "attn_blocks": ("ab", (0,)), "attn_blocks1": ("ab", (1,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)),
                 "finished_rows": ("fr", (0,)), "lnw_tiles": ("fr", (1,)), "fr_split_rows": ("fr", (2,)), "fr_pair": ("fr", (3,)), "tile_attn": ("ta", (0, 1)),
-                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "gemm_pf": ("gpf", (0, 1, 2)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,)), "mt_tiles": ("q16", (2,)), "wide_gemm": ("q16", (3,)), "shrink": ("sh", (0,))}
+                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,)), "mt_tiles": ("q16", (2,)), "wide_gemm": ("q16", (3,)), "shrink": ("sh", (0,))}
 
 
 def option_value(text, knob):
@@ -172,10 +172,10 @@ def sampler_block(wl, box):
 
 def options_object(text):
     """The engine's option state (a compact text, vc_debug_read "options") as a JSON object."""
-    names = {"apf": ("attn_pf", ["slices", "wo_kb", "w1_kb", "scale_quarters", "cut1", "cut2", "cut0"]), 
+    names = {
              "g": ("graph_steps", None), "ls": ("ln_split_rows", None), "ab": ("attn_blocks", ["several_rows", "one_row"]),
              "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "lnw_tiles", "split_rows", "paired"]),
-             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "gpf": ("gemm_pf", ["workgroups", "ffn_down_kb", "ffn_up_kb"]), "q16": ("many_rows", ["qkv16", "wide_heads", "mt_tiles", "wide_gemm"]), "sh": ("shrink", None)}
+             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "q16": ("many_rows", ["qkv16", "wide_heads", "mt_tiles", "wide_gemm"]), "sh": ("shrink", ["on", "wd_order"])}
     out = {"text": text}
     try:
         for part in text.split("|"):
@@ -833,11 +833,10 @@ def main():
         ab = args.ab
         more = []
         if ab == "auto":       # every default-ON feature has to show its gain in the line the driver records: the largest one in `ab`,
-            # the other one-row forms of round 5 in `ab_more` (fewer pairs).  The attention launch's prefetch role is default OFF since
-            # round 5 (it costs 0.4-1.9 % next to the leaner kernels, profiles/r05b_*, r05c_*): its A/B stays in `ab_more` as the standing check
-            ab = ("fr_one=0:1" if B == 1 else "finished_rows=0:16" if B <= 16 else "attn_nt=0:2")
+            # the other one-row forms of round 5 in `ab_more` (fewer pairs).  (The prefetch roles of rounds 3-5 left the tree in round 6.)
+            ab = ("fr_one=0:1" if B == 1 else "finished_rows=0:16" if B <= 16 else "wide_gemm=0:1")
             if B == 1:
-                more = ["qkv_p8=0:1", "ln_trim=0:1", "gemm_pf=0:128,-1,0", "attn_pf=0:8,0,-1"]
+                more = ["qkv_p8=0:1", "ln_trim=0:1"]
         if n_gpus == 1 and ab and ab != "none":
             try:
                 out["ab"] = ab_block(eng, one_step, ab, max(3, args.ab_pairs))

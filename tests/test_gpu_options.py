@@ -18,6 +18,7 @@ def _delta(after, before):
 
 def _oracle_traces(a, sd, prompts):
     from oracle.voicecraft_oracle import VoiceCraftOracle
+    torch.set_num_threads(min(4, torch.get_num_threads()))      # tiny models: a host with 100+ cores spends its time in thread hand-offs otherwise
     orc = VoiceCraftOracle(a, sd)
     traces, want_res = [], []
     for (xx, xl, yy) in prompts:
@@ -105,16 +106,17 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
     x, xl, y = synth.random_prompt(a, 6, 21, seed=11)
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=2, max_positions=256)
     base = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
-    for name, value in [("attn_pf", "0"), ("attn_pf", "8,0,32"), ("attn_pf", "4,16,16"), ("attn_pf_cut", "0,0"), ("attn_pf_cut", "30,40,28"),
-                        ("attn_pf", "8,0,-1"), ("attn_nt", "1"), ("attn_nt", "0"), ("nt", "28"), ("nt", "0"), ("nt", "63"), ("graph_steps", "3"), ("attn_blocks1", "64"),
-                        ("ln_split_rows", "2"), ("graph_steps", "8")]:
+    for name, value in [("attn_nt", "1"), ("attn_nt", "0"), ("nt", "28"), ("nt", "0"), ("nt", "63"), ("graph_steps", "3"), ("attn_blocks1", "64"),
+                        ("ln_split_rows", "2"), ("graph_steps", "8"), ("shrink", "0"), ("wide_gemm", "0")]:
         eng.set_option(name, value)
         got = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
         assert np.array_equal(got, base), (name, value)
     with pytest.raises(AssertionError):
         eng.set_option("no_such_option", "1")
     with pytest.raises(AssertionError):
-        eng.set_option("attn_pf", "many")
+        eng.set_option("graph_steps", "many")
+    with pytest.raises(AssertionError):
+        eng.set_option("attn_pf", "8")          # the prefetch roles of rounds 3-5 are gone
 
 
 @pytest.mark.parametrize("preset,B", [("tiny", 1), ("tiny_h16", 1), ("tiny128", 20)])
@@ -181,7 +183,7 @@ def _free_running_multi(eng, prompts):
     return [res.cpu().numpy() for (res, gen) in outs]
 
 
-@pytest.mark.parametrize("preset,B", [("tiny128", 40), ("tiny_h16", 48), ("tiny128", 64), ("tiny", 33)])
+@pytest.mark.parametrize("preset,B", [("tiny_h16", 48), ("tiny128", 64), ("tiny", 33)])
 def test_wide_decode_33_to_64_rows_fp32_tokens_equal_the_oracle(preset, B):
     """33..64 sequences per step (row tiles 3 and 4 of the wide-decode kernel, the 64-row attention grid, the sampler on 64
     workgroups, the heads beyond 32 rows): exact mode, FREE-running greedy tokens of every sequence equal its own oracle run, in
@@ -207,8 +209,10 @@ def test_wide_decode_33_to_64_rows_fp32_tokens_equal_the_oracle(preset, B):
 
 
 
-@pytest.mark.parametrize("graph", [True, False])
-@pytest.mark.parametrize("preset,B", [("tiny128", 40), ("tiny_h16", 64), ("tiny128", 20), ("tiny", 9)])
+_RAGGED_ORACLE = {}      # (preset, B) -> the oracle's outputs: shared by the graph / eager runs of a shape
+
+
+@pytest.mark.parametrize("preset,B,graph", [("tiny_h16", 64, True), ("tiny_h16", 64, False), ("tiny128", 40, True), ("tiny128", 20, False), ("tiny", 9, True)])
 def test_wide_batch_whose_sequences_retire_at_different_steps(preset, B, graph):
     """A batch with LIVE terminators (the `boost` of oracle/gen_golden.py's un-muted cases): the sequences end anywhere between
     ~11 and ~50 generated frames, so most rows of a 17+-row step go idle long before the last one ends - sampled / arg-max
@@ -220,8 +224,11 @@ def test_wide_batch_whose_sequences_retire_at_different_steps(preset, B, graph):
     a = synth.make_args(preset)
     sd = synth.make_state_dict(a, seed=4, mute_eos=False, boost=[(0, 2051, 0.45)])
     prompts = [synth.random_prompt(a, 4 + (u % 5), 9 + 3 * (u % 7), seed=700 + u) for u in range(B)]
-    orc = VoiceCraftOracle(a, sd)
-    want = [orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3)[0].numpy() for (xx, xl, yy) in prompts]
+    if (preset, B) not in _RAGGED_ORACLE:
+        torch.set_num_threads(min(4, torch.get_num_threads()))
+        orc = VoiceCraftOracle(a, sd)
+        _RAGGED_ORACLE[(preset, B)] = [orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3)[0].numpy() for (xx, xl, yy) in prompts]
+    want = _RAGGED_ORACLE[(preset, B)]
     lens = [w.shape[2] - p[2].shape[1] for w, p in zip(want, prompts)]
     assert min(lens) * 2 <= max(lens), lens                       # the workload really is ragged
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=B, max_positions=256, use_graph=graph)

@@ -26,6 +26,6 @@ echo "== FETCH_SIZE pass"; bash tools/prof_pmc.sh ${TAG}_fetch FETCH_SIZE --ab n
 python tools/pmc_to_json.py $O/${TAG}_fetch_pmc.txt $O/pmc_traffic.json > /dev/null
 if [ "${SHORT:-0}" = "1" ]; then exit 0; fi      # SHORT=1: suite + smoke + bench + the two profiles only
 echo "== in-kernel stamps"; timeout 200 python tools/kernel_ts.py giga830M 1 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_kernel_stamps_giga830M.log
-echo "== giga330M"; timeout 300 python tools/ab_sweep.py --preset giga330M fr_one=0:1 gemm_pf=0:128,-1,0 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_330M.log
+echo "== giga330M"; timeout 300 python tools/ab_sweep.py --preset giga330M fr_one=0:1 qkv_p8=0:1 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_330M.log
 echo "== 8 rows"; timeout 300 python tools/ab_sweep.py --batch 8 fr_pair=0:1 finished_rows=0:16 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_b8.log
 bash tools/prof_decode.sh ${TAG}_b8 --batch 8 --no-codec --ab none; head -12 $O/${TAG}_b8_rocprof_kernel_stats.txt

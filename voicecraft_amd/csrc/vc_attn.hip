@@ -32,22 +32,7 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 #define VC_ATT_WAVES 8
 #endif
 
-// ---------------------------------------------------------------- piggyback weight prefetch (decode, one row)
-// At one row per step the attention launch is the only one of a layer that does not saturate HBM (7 MB of K/V in 5 us on
-// half the CUs), and the launches behind it start cold: the FFN up-projection takes 5.1 us instead of 9.1 when its weights are
-// still in L2 (profiles/r03_prefetch_probe.log).  The launch carries pf_z extra grid.z slices of workgroups that read the
-// leading bytes of up to two matrices' tiles (vc_common.h vc_prefetch_tiles).
-// Which workgroups take the role is decided from blockIdx alone (round 5): the role exists only in the PF instantiation, whose launches
-// have EXACTLY VC_MAX_NSPLIT split slices (every one-row launch: min(256 / heads, 8)), so the test is `blockIdx.z >= 8` against a
-// constant.  It used to be `blockIdx.z >= a.nsplit` - a kernel argument - and the compiler put that scalar load, its wait and the
-// branch in front of every other argument load of the attention path (one more dependent scalar round trip per launch).  The
-// prefetch slices stay BEHIND the split slices in launch order (interleaving them - odd z - measured +1.85 % per step with the role
-// on, profiles/r05b_ab_prefetch_roles_830M.log: the prefetchers then compete with the first attention workgroups' own K/V requests).
-__device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
-  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-  vc_prefetch_tiles(a.pf, 2, lin, gridDim.x * gridDim.y * (unsigned)VC_MAX_NSPLIT, gridDim.x * gridDim.y * (gridDim.z - (unsigned)VC_MAX_NSPLIT));
-}
-
+// ---------------------------------------------------------------- decode attention
 // NT: K/V rows are requested with the non-temporal hint (every cached row is read exactly once per step and never again before
 // the next step's 1.7 GB of weights have gone through the caches) - a template parameter so that the hint cannot be merged away
 // (vc_gemm.hip rows_gemm_k), chosen per launch from AttnArgs.nt (option "attn_nt").
@@ -57,7 +42,7 @@ __device__ __forceinline__ void prefetch_role(const AttnArgs& a) {
 // maximum: no rescaling per visit (one per batch of 4), and the position groups of a wave merge by plain additions (no
 // exponentials, no multiplies).  In bf16 mode the exponentials are hardware exp2 (v_exp_f32, q pre-scaled by log2 e; the exported
 // maximum is converted back to natural units for the out-projection's merge); the exact fp32 mode keeps expf.
-template <typename WT, bool NT, bool FAST, bool PF>
+template <typename WT, bool NT, bool FAST>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;
   constexpr int NW = VC_ATT_WAVES;
@@ -70,9 +55,6 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
   __shared__ float s_o[NW][128];
   VC_KTS_DECL();
   VC_KTS(0);
-  if constexpr (PF) {
-    if (blockIdx.z >= VC_MAX_NSPLIT) { prefetch_role(a); return; }     // (wave-uniform, decided from the workgroup id alone)
-  }
   const int r = blockIdx.x, h = blockIdx.y, sp = blockIdx.z;     // grid.x == n_rows
   // ONE scalar round trip for everything the addresses depend on.  Written as plain C these four came out as VECTOR loads (the
   // compiler cannot prove them invariant) and `share` was sunk behind the branch below - two dependent vector round trips before the
@@ -287,15 +269,11 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
 }
 
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s) {
-  // prefetch role: pf_z extra slices behind the split slices; only in launches of exactly VC_MAX_NSPLIT split slices (the role's test
-  // is against that constant) and where a workgroup's XCD follows from its (row, head) index
-  const bool pf = a.pf_z > 0 && (a.pf[0].len > 0 || a.pf[1].len > 0) && a.nsplit == VC_MAX_NSPLIT && ((rows_cap * a.H) % 8 == 0);
-  dim3 grid(rows_cap, a.H, a.nsplit + (pf ? a.pf_z : 0));
+  dim3 grid(rows_cap, a.H, a.nsplit);
   ++vc_launch_counts[VC_LC_ROWS_ATTN];
   AttnArgs b = a;
   b.inv_nsplit = nextafterf(1.0f / (float)a.nsplit, 2.0f);
-#define VC_ATTN_GO(WT_, NT_, F_) { if (pf) hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b); \
-                                   else hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_, false>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b); }
+#define VC_ATTN_GO(WT_, NT_, F_) hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b);
   if (dtype == VC_DTYPE_BF16) {
     if (a.fast) { if (a.nt) VC_ATTN_GO(bf16_t, true, true) else VC_ATTN_GO(bf16_t, false, true) }
     else { if (a.nt) VC_ATTN_GO(bf16_t, true, false) else VC_ATTN_GO(bf16_t, false, false) }

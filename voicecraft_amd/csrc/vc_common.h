@@ -200,50 +200,6 @@ constexpr bool vc_is_qkv(int epi) { return epi == EPI_QKV || epi == EPI_QKV16; }
                             // out-projection, X of the FFN down-projection (rows x 4d elements) in LDS in one piece; 9..VC_ROWS rows: two
                             // rows per wave, unsplit attention, FFN down-projection through LDS in two halves (rows_gemm_fr2_k)
 
-// ---------------------------------------------------------------- piggyback weight prefetch
-// A launch that leaves HBM idle (the one-row attention launch, the per-row LayerNorm launches of a several-row step) carries
-// extra workgroups that do none of its work: they pull the head of the NEXT launches' weight tiles into the L2 of the XCD whose
-// workgroups will read them.  "The right L2" is the point: each XCD has its own, and a GEMM workgroup x (= weight tile x)
-// runs on XCD x % 8 because the hardware deals workgroups to the XCDs round-robin in launch order - so a prefetch workgroup
-// derives its XCD from its own launch-order index `lin` and takes that XCD's tiles.  No synchronisation, no extra launch, no
-// second stream (round 1's fork/join per layer and round 3's paced side-stream prefetcher both cost more than the misses
-// they removed); if the dealing order ever differs the only loss is the hit rate.
-struct PfSeg {              // a packed weight matrix whose workgroup x reads tile x (rows_gemm_k: grid.x = tile, XCD = x % 8)
-  const char* base;
-  int n_tiles;              // multiple of 8
-  int tile_bytes;           // bytes between consecutive tiles
-  int len;                  // leading bytes of every tile to fetch (multiple of 8 KB; 0 = segment unused)
-  int sub;                  // consecutive tiles read by ONE consumer workgroup (rows_gemm_mt_k: 2 or 4; 0 / 1 = one tile each)
-};
-#ifdef __HIPCC__
-// lin0 (a multiple of 8) = launch-order index of the first prefetch workgroup, npf = how many there are
-__device__ __forceinline__ void vc_prefetch_tiles(const PfSeg* segs, int nseg, unsigned lin, unsigned lin0, unsigned npf) {
-  const unsigned xcd = lin & 7u;
-  const unsigned j = (lin - lin0) >> 3, nj = max(npf >> 3, 1u);            // this workgroup among its XCD's prefetchers
-  const unsigned tid = threadIdx.x, nthr = blockDim.x;
-  // The loads land in ONE register quad that stays live ("+v") until the final wait: the compiler treats an asm load as
-  // complete when the statement ends, so a dead "=v" destination is handed to the next address computation while the
-  // data is still in flight (first version: the late write corrupted a later address - memory aperture violation).
-  u32x4 sink = {0u, 0u, 0u, 0u};
-  for (int sgi = 0; sgi < nseg; ++sgi) {
-    const PfSeg sg = segs[sgi];
-    if (sg.len <= 0) continue;
-    const unsigned sub = (unsigned)max(sg.sub, 1);
-    for (unsigned t = j; t < (unsigned)sg.n_tiles / (8u * sub); t += nj) {     // consumer workgroup xcd + 8 t
-      for (unsigned q = 0; q < sub; ++q) {
-        const char* src = sg.base + (size_t)((xcd + 8u * t) * sub + q) * (size_t)sg.tile_bytes;
-        for (unsigned off = tid * 16u; off < (unsigned)sg.len; off += nthr * 16u)
-          asm volatile("global_load_dwordx4 %0, %1, off" : "+v"(sink) : "v"(src + off));
-      }
-    }
-  }
-  // (no "memory" clobber on these statements: the loads change nothing the program reads, volatile asms keep their order among
-  // themselves, and a clobber anywhere in a kernel makes hipcc turn every scalar load of the OTHER path - `*a.n_active`, the row's
-  // position - into a vector load: seen in the ISA of the rows-GEMM once it hosted this role, round 5)
-  asm volatile("s_waitcnt vmcnt(0)" : "+v"(sink));
-}
-#endif
-
 struct GemmArgs {
   // weights, packed [group][n_tile][k_tile][lane] x 16 bytes
   const uint4* Wp;
@@ -299,9 +255,6 @@ struct GemmArgs {
   float* part_out;          // PART: [ksplit][rows_cap][N]
   void* x_out;              // ln_rows_k: normalised rows, WT [rows][d]
   long long* dbg_ts;        // shader-clock stamps (diagnostic builds with -DVC_KERNEL_TS only)
-  PfSeg pf;                 // ln_rows_k, rows_gemm_k (one tile per workgroup), row_gemm_fr1_k: pf_blocks extra workgroups
-  int pf_blocks;            // prefetch the head of this matrix's tiles (vc_prefetch_tiles); 0 = none
-  PfSeg pf2;                // rows_gemm_k: a second matrix for the same role (len 0 = unused)
 };
 
 struct AttnArgs {
@@ -323,10 +276,6 @@ struct AttnArgs {
   float* att_ml;
   void* x_out;              // nsplit == 1 only: normalised output rows, WT [rows][d] (the out-projection then takes the plain prologue)
   long long* dbg_ts;        // diagnostic builds only
-  // rows_attn_k only: pf_z extra grid.z slices of workgroups BEHIND the VC_MAX_NSPLIT split slices that do no attention - they pull the
-  // head of the NEXT launches' weight tiles into the L2 of the XCD whose workgroups will read them (vc_attn.hip); 0 = none
-  PfSeg pf[2];
-  int pf_z;
   int nt;                   // rows_attn_k: K/V rows requested with the non-temporal hint
   int fast;                 // rows_attn_k: 1 = the round-5 form (wave maximum before any exponential; bf16 mode: hardware exp2)
 };

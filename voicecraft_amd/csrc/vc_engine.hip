@@ -100,25 +100,6 @@ struct vc_engine {
   // (in-process A/Bs, profiles/r04d_bench_*attn_nt*: one row +0.3 % +- 0.09 - there the launch is latency-bound and carries the prefetch
   // role -, 8 rows -4.8 % +- 0.05, 32 rows -6.5 % +- 0.05: several caches stream 58-230 MB per layer through L2 otherwise)
   int attn_nt = 2;
-  // piggyback weight prefetch of the one-row attention launch (vc_attn.hip prefetch_role): VC_ATTN_PF=z[,wo_kb[,w1_kb]], 0 = off.
-  // Measured (profiles/r03g_attn_prefetch_sweep.log): 8 slices x the first 32 KB of every FFN-up tile 0.598 -> 0.589 ms per step;
-  // the out-projection's own matrix gains nothing (that launch waits for the attention partials, not for its weights),
-  // 48-64 KB per tile or 4 slices lose (the attention launch ends with its slowest prefetcher).
-  // (letting the prefetch workgroups start late, so that the attention workgroups' own K/V requests go out first, was measured in
-  // round 4: 0.4 us no effect, 0.8 us +1.7 %, 1.7 us +2.8 % per step - profiles/r04c_bench_apf_delay*.json.log; not carried)
-  // FFN-up KB < 0 (default): HALF of every tile - 32 KB at d = 2048 (re-swept in round 4 with the hint on every matrix: 24 / 40 / 48 /
-  // 64 KB cost +1.0 / +1.2 / +3.0 / +4.0 % against 32), 16 KB at d = 1024 (giga330M: 16 against 32 KB -4.2 % +- 0.03; r04e_bench_*apf*)
-  // Round 5: default OFF.  With the one-row kernels of this round (finished rows, trimmed prologues, scalar batch in the attention
-  // launch) the role costs more than it saves on every box measured: +1.85 % +- 0.004 (slices interleaved), +0.87 % +- 0.3 / +0.36 % at
-  // giga330M / 0.0 % editing (slices behind the splits) in in-process A/Bs, profiles/r05b_*, r05c_*.  The option stays.
-  int apf_z = 0, apf_wo_kb = 0, apf_w1_kb = -1;
-  int apf_scale = 4;                    // quarters of the configured length in force (decode_loop: per graph, by context length)
-  // option "attn_pf_cut" = "p1,p2[,p0]": half the length from cached position p1, none from p2, none below p0; 0,0 = never cut.
-  // Measured per context range on a box where the uncut role gained only 0.2 % over a whole utterance (profiles/r04h_*): positions
-  // 41-221 +0.5 %, 141-441 -1.5 %, 461-661 +1.4 %, 731-884 +1.5 %, editing (793+) +1.4 % - the launch's own K/V traffic grows
-  // with the position and the window it leaves shrinks.  Cuts against uncut there: 400,700 -2.0 % (TTS) / -2.7 % (editing), 500,800
-  // -0.7 / -1.8, 300,600 -0.9, 600,900 -0.2.
-  int apf_cut1 = 400, apf_cut2 = 700, apf_cut0 = 128;
   int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
   // finished-row form of decode passes of 2..fr_rows rows (forward_rows_fr): 0 = off.  VC_FINISHED_ROWS / option "finished_rows"
   int fr_rows = VC_ROWS;
@@ -137,15 +118,6 @@ struct vc_engine {
   // two k-tiles per MFMA fragment, residual + bias added) instead of leaving 4 split-K slabs, so the next layer's QKV projection (and
   // heads-1) reads one 8 KB row instead of h + bias + 4 slabs = 40 KB in each of its 512 workgroups; 0 = off
   int fr_one = 1;
-  // option "gemm_pf" = "blocks,f2_kb[,f1_kb]" (round 5): the prefetch role hosted by the one-row out-projection launch - it waits for the
-  // attention partials and streams 8.4 MB in ~4.5 us.  `blocks` extra workgroups pull the first f2_kb KB of every FFN down-projection
-  // tile (the launch after next) and, if f1_kb > 0, the first f1_kb KB of every FFN-up tile (the next launch).  0 = off.
-  // Measured with the attention launch's role off (profiles/r05c_ab_gemm_pf_attention_role_off_830M.log, r05d_*, r05e_*): 128 workgroups x
-  // 16 KB of every FFN-down tile -0.57 % +- 0.06 / -1.17 % +- 0.02 at giga830M on two boxes (32 KB: 0.0; 256 workgroups: 0.0), giga330M
-  // 32 KB -0.84 % +- 0.06 / 16 KB -0.53 %; + 16 KB of the FFN-up tiles +2.4 % (giga330M +0.5 %), INSTEAD of the FFN-down tiles +0.2 %.
-  // The NEXT layer's QKV tiles under the FFN-up launch (a first form of this option) lost 3.8 % at giga330M and left the tree.
-  // f2_kb < 0 = by width: 16 KB at d >= 2048, 32 KB below.
-  int gpf_blocks = 128, gpf_f2_kb = -1, gpf_f1_kb = 0;
   // option "fr_pair" (round 5): the FFN down-projection of 2..8-row steps with two k-tiles per MFMA fragment (rows_gemm_frp_k) instead
   // of half-filled 8-channel fragments (rows_gemm_fr_k)
   int fr_pair = 1;
@@ -167,6 +139,7 @@ struct vc_engine {
   // flight at once, X fragments straight from L2 into registers, one barrier per launch) instead of the weight-stationary
   // rows_gemm_mt_k, which walks the row tiles one after the other; 0 = the round-2..5 kernel (its "mt_tiles" then applies)
   int wide_gemm = 1;
+  int wd_order = 0;                     // measurement option "wd_order": request order inside rows_gemm_wd_k (vc_gemm_wd.hip ORD)
   // option "shrink" (round 6): a multi-utterance call whose sequences retire at different steps re-packs the live ones onto the rows of a
   // narrower step (the next power of two >= the live count: 64 -> 32 -> 16 -> 8 -> 4 -> 2 -> 1) instead of keeping its launch form until
   // the longest sequence ends; 0 = the fixed width of rounds 1-5.  Results do not depend on it: everything per sequence is indexed by its slot.
@@ -340,6 +313,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.dbg_ts = e->dbg_ts;
   g.ln_trim = e->ln_trim;
   g.mt_ntw = (e->mt_tiles == 1 && rs.n_rows > 32) ? 2 : (e->mt_tiles == 2 || e->mt_tiles == 4) ? e->mt_tiles : 0;    // 1 = two tiles from 33 rows on
+  if (e->wide_gemm && e->wd_order >= 0) g.mt_ntw = e->wd_order;        // (measurement: request order of rows_gemm_wd_k)
   return g;
 }
 
@@ -507,17 +481,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
       a.fast = e->attn_fast;
-      if (e->apf_z > 0 && e->apf_scale > 0 && rs.n_rows == 1 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0) {
-        // one row: the launch leaves HBM mostly idle - extra workgroups pull the next two matrices' tiles into the L2 of
-        // the XCD that will read them (prefetch_role)
-        const int KW = e->dtype == VC_DTYPE_BF16 ? 32 : 16;
-        const int tile_b = (d / KW) * 64 * 16;                 // out-projection and FFN-up tiles: 16 channels x d
-        a.pf_z = e->apf_z;
-        a.pf[0] = PfSeg{(const char*)ly.Wo, e->p_o.n_tiles, tile_b, std::min(tile_b, e->apf_wo_kb * 1024), 1};
-        int w1_len = e->apf_w1_kb < 0 ? ((tile_b / 2 + 8191) & ~8191) : e->apf_w1_kb * 1024;
-        w1_len = ((w1_len * e->apf_scale / 4) + 8191) & ~8191;
-        a.pf[1] = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, w1_len), 1};
-      }
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {  // out-projection of the merged attention output -> split-K partial slabs
@@ -525,24 +488,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.Wp = ly.Wo; nt_bit(e, g, NT_O);
       g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
       g.part_out = e->parts;
-      const int f2_kb = e->gpf_f2_kb < 0 ? (d >= 2048 ? 16 : 32) : e->gpf_f2_kb;
-      if (e->gpf_blocks > 0 && f2_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr) {
-        // prefetch role: the head of every FFN down-projection tile of this layer, as the launch after next will read them
-        const int KT2 = 4 * d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16);
-        if (fd) {     // row_gemm_fr1_k: workgroup x reads 8-channel tile x
-          const int tile_b = KT2 * 4 * VC_TH_RES * 16;
-          g.pf = PfSeg{(const char*)ly.W28, d / VC_TH_RES, tile_b, std::min(tile_b, f2_kb * 1024), 1};
-        } else {      // slab form: workgroup (x, y) reads the y-th K slice of 16-channel tile x
-          const int ks = e->p_f2.ksplit, sub_b = KT2 * 64 * 16 / ks;
-          g.pf = PfSeg{(const char*)ly.W2, e->p_f2.n_tiles * ks, sub_b, std::min(sub_b, f2_kb * 1024 / ks), ks};
-        }
-        g.pf_blocks = e->gpf_blocks;
-      }
-      if (e->gpf_blocks > 0 && e->gpf_f1_kb > 0 && rs.n_rows == 1 && rs.n_active != nullptr) {
-        const int tile_b = (d / (e->dtype == VC_DTYPE_BF16 ? 32 : 16)) * 64 * 16;
-        g.pf2 = PfSeg{(const char*)ly.W1, e->p_f1.n_tiles, tile_b, std::min(tile_b, e->gpf_f1_kb * 1024), 1};
-        g.pf_blocks = e->gpf_blocks;
-      }
       HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_ATT, EPI_PART, e->p_o.ksplit, 1, s));
     }
     {  // h' = h + attn + bo ; a = relu(W1 LN2(h') + b1)                  
@@ -708,8 +653,6 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.n_parts = (l == 0) ? 0 : ks_f2;
       g.prev_bias = (l == 0) ? ly.bo : e->layers[l - 1].b2; g.has_prev_bias = (l == 0) ? 0 : 1;
       g.x_out = e->xn;
-      // (no piggyback prefetch on the LayerNorm launches of WIDE decode passes: measured at 32 rows with the tiles grouped as
-      // rows_gemm_mt_k reads them, PfSeg.sub = 4 - 1.428-1.437 -> 1.454 ms per step, profiles/r03j_lpf32_ab.log)
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
       g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.x_in = e->xn; g.x_ld = d; g.mt = mtv;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
@@ -902,12 +845,10 @@ int decode_step(vc_engine* e, const SampleArgs& sa, int B, int rps, bool grouped
 // sequence retires, and the host paces itself one graph behind the GPU with events, so a queued graph is
 // always waiting when the running one ends (measured before: ~8 us of idle GPU per graph launch and ~100 us
 // per blocking poll).  Steps replayed after the last sequence retired are no-ops (*n_active == 0).
-// apf_scale: the attention-launch prefetch fetches apf_scale / 4 of its configured length (decode_loop switches it per graph by context
-// length); refresh_opt_state() folds it into the key of the captured graphs
 void refresh_opt_state(vc_engine* e);
 
 int decode_loop(vc_engine* e, const SampleArgs& sa0, int B0, int rps, bool grouped, const vc_sample_cfg* sc,
-                int max_steps, int* steps_run, hipStream_t s, int pos0 = 0, bool precapture_only = false) {
+                int max_steps, int* steps_run, hipStream_t s, bool precapture_only = false) {
   const int G = std::max(1, e->steps_per_graph);
   const double t0 = now_ms();
   if (precapture_only) e->host_ms[1] = e->host_ms[2] = 0;
@@ -918,14 +859,8 @@ int decode_loop(vc_engine* e, const SampleArgs& sa0, int B0, int rps, bool group
   SampleArgs sa = sa0;
   const bool can_shrink = e->shrink && !grouped && rps == 1 && B0 > 1;
   auto width_for = [](int live) { int p = 1; while (p < live) p *= 2; return p; };
-  // One captured graph per (shape, option state).  The only thing that varies INSIDE a call is the prefetch length of the one-row
-  // attention launch: it is worth most while the context is short (the launch's own K/V traffic grows with the position and the
-  // window it leaves shrinks), so the host - which knows how many steps it has launched - picks full / half / none per graph of G
-  // steps from the position the graph starts at (option "attn_pf_cut" = first position of the half, of the none range).
-  auto exec_for = [&](int scale, hipGraphExec_t* out) -> int {
-    const int keep = e->apf_scale;
-    e->apf_scale = scale;
-    refresh_opt_state(e);
+  // One captured graph per (rows per step, option state), kept for the life of the engine.
+  auto exec_for = [&](hipGraphExec_t* out) -> int {
     const auto key = std::make_pair(std::make_tuple(B, rps, grouped ? 1 : 0), e->opt_state);
     auto it = e->graphs.find(key);
     int rc = VC_OK;
@@ -951,32 +886,17 @@ int decode_loop(vc_engine* e, const SampleArgs& sa0, int B0, int rps, bool group
       }
       if (graph) (void)hipGraphDestroy(graph);
     }
-    e->apf_scale = keep;
-    refresh_opt_state(e);
     return rc;
-  };
-  // (the role's own preconditions - forward_rows - are part of the rule: where it cannot apply every scale is the same step, one graph)
-  const bool one_row = B * rps == 1 && e->apf_z > 0 && e->H % 8 == 0 && e->p_o.n_tiles % 8 == 0 && e->p_f1.n_tiles % 8 == 0;
-  auto scale_at = [&](int pos) {
-    if (!one_row || e->apf_cut2 <= 0) return 4;
-    return (pos >= e->apf_cut2 || pos < e->apf_cut0) ? 0 : pos >= e->apf_cut1 ? 2 : 4;
   };
   if (precapture_only) {       // every graph this call can need, captured before the caller starts its decode timer
     if (!sc->use_graph) return VC_OK;
-    int last = -1, rc0 = VC_OK;
-    for (int k = 0; k < max_steps && rc0 == VC_OK; k += G) {
-      const int sc_k = scale_at(pos0 + k);
-      if (sc_k == last) continue;
-      last = sc_k;
-      hipGraphExec_t exec = nullptr;
-      rc0 = exec_for(sc_k, &exec);
-    }
+    hipGraphExec_t exec = nullptr;
+    int rc0 = exec_for(&exec);
     if (can_shrink)            // ... and the narrower widths a shrinking batch passes through
       for (int w = width_for(B0) / 2; w >= 1 && rc0 == VC_OK; w /= 2) {
         if (w >= B0) continue;
         B = w; sa = make_sample_args(e, w, rps);
-        hipGraphExec_t exec = nullptr;
-        rc0 = exec_for(4, &exec);
+        rc0 = exec_for(&exec);
       }
     return rc0;
   }
@@ -1004,18 +924,14 @@ int decode_loop(vc_engine* e, const SampleArgs& sa0, int B0, int rps, bool group
         }
       }
     }
-    const int scale = scale_at(pos0 + launched);
     if (sc->use_graph) {
       hipGraphExec_t exec = nullptr;
-      rc = exec_for(scale, &exec);
+      rc = exec_for(&exec);
       if (rc) break;
       hipError_t le = hipGraphLaunch(exec, s);
       if (le != hipSuccess) rc = fail(e, VC_EHIP, "hipGraphLaunch failed: %s", hipGetErrorString(le));
     } else {
-      const int keep = e->apf_scale;
-      e->apf_scale = scale;
       for (int i = 0; i < G && rc == VC_OK; ++i) rc = decode_step(e, sa, B, rps, grouped, s);
-      e->apf_scale = keep;
     }
     if (rc) break;
     launched += G;
@@ -1077,15 +993,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   int v0 = 0, v1 = 0, v2 = 0;
   const int n = sscanf(value ? value : "", "%d,%d,%d", &v0, &v1, &v2);
   if (n < 1) return fail(e, VC_EINVAL, "option '%s': '%s' is not a number list", name.c_str(), value ? value : "(null)");
-  if (name == "attn_pf") {            // slices[,out-projection KB[,FFN-up KB]] of the one-row attention launch's prefetch role; 0 = off
-    e->apf_z = std::max(0, std::min(v0, 16));
-    if (n >= 2) e->apf_wo_kb = std::max(0, v1);
-    if (n >= 3) e->apf_w1_kb = v2;                       // < 0: half a tile
-  } else if (name == "attn_pf_cut") {   // p1,p2: half the prefetch from cached position p1 on, none from p2 on (one-row steps); 0 = never
-    e->apf_cut1 = std::max(0, v0);
-    e->apf_cut2 = n >= 2 ? std::max(e->apf_cut1, v1) : 0;
-    e->apf_cut0 = n >= 3 ? std::max(0, v2) : (e->apf_cut2 > 0 ? 128 : 0);
-  } else if (name == "graph_steps") { e->steps_per_graph = std::max(1, std::min(64, v0));
+  if (name == "graph_steps") { e->steps_per_graph = std::max(1, std::min(64, v0));
   } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
   } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
   } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
@@ -1099,10 +1007,6 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
       return fail(e, VC_ESTATE, "option '%s': this engine was created with VC_FINISHED_ROWS=0 and VC_FR_ONE=0 and holds no 8-channel weight images", name.c_str());
     if (name == "fr_one") e->fr_one = std::max(0, std::min(v0, 2));
     else e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
-  } else if (name == "gemm_pf") {
-    e->gpf_blocks = std::max(0, std::min(v0, 1024)) & ~7;
-    if (n >= 2) e->gpf_f2_kb = v1;                      // < 0: by width
-    e->gpf_f1_kb = n >= 3 ? std::max(0, v2) : 0;
   } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
   } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
   } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
@@ -1112,6 +1016,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->mt_tiles = v0;
   } else if (name == "wide_gemm") { e->wide_gemm = v0 ? 1 : 0;
   } else if (name == "shrink") { e->shrink = v0 ? 1 : 0;
+  } else if (name == "wd_order") { e->wd_order = std::max(0, std::min(v0, 5));
   } else if (name == "qkv16") {
     if (v0 && !e->layers.empty() && !e->layers[0].Wqkv16)
       return fail(e, VC_ESTATE, "option 'qkv16': this engine was created with VC_QKV16=0 and holds no 16-channel image of the QKV matrix");
@@ -1128,10 +1033,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "apf=%d,%d,%d,%d,%d,%d,%d|g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|gpf=%d,%d,%d|q16=%d,%d,%d,%d|sh=%d", e->apf_z, e->apf_wo_kb, e->apf_w1_kb, e->apf_scale, e->apf_cut1, e->apf_cut2, e->apf_cut0,
+  snprintf(buf, sizeof buf, "g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|q16=%d,%d,%d,%d|sh=%d,%d",
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->gpf_blocks, e->gpf_f2_kb, e->gpf_f1_kb, e->qkv16, e->wide_heads, e->mt_tiles, e->wide_gemm, e->shrink);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->qkv16, e->wide_heads, e->mt_tiles, e->wide_gemm, e->shrink, e->wd_order);
   e->opt_state = buf;
 }
 
@@ -1445,11 +1350,11 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   HIPCHK(e, hipStreamCreate(&e->own_stream));
   // ---- options: the VC_* environment variables preset them, vc_set_option changes them at run time
   for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), std::make_pair("VC_LN_SPLIT_ROWS", "ln_split_rows"),
-                         std::make_pair("VC_ATTN_PF", "attn_pf"), std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
+                         std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
-                         std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_ATTN_PF_CUT", "attn_pf_cut"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_GEMM_PF", "gemm_pf"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_MT_TILES", "mt_tiles"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_MT_TILES", "mt_tiles"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1548,13 +1453,11 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   // ---- first sample comes from the prefill logits, then the decode loop
   SampleArgs sa = make_sample_args(e, B, 1);
   int steps_run = 0;
-  int pos0 = 0;
-  for (const TtsJob& j : jobs) pos0 = std::max(pos0, j.Lx + j.T + 1);
   // (a first call of this shape / option state captures its decode graphs here, outside the decode timer)
-  if ((rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, nullptr, s, pos0, true))) return rc;
+  if ((rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, nullptr, s, true))) return rc;
   HIPCHK(e, vc_launch_sample(sa, grouped, s));
   HIPCHK(e, hipEventRecord(e->ev[1], s));
-  rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s, pos0);
+  rc = decode_loop(e, sa, B, 1, grouped, sc, max_steps, &steps_run, s);
   if (rc) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   if (e->cur_rows == B) {
@@ -1733,11 +1636,11 @@ extern "C" int vc_edit(vc_engine* e, const int64_t* x_dev, int Lx, const int64_t
   if (rc) return rc;
   const int rps = (M > 1) ? 3 : 1;
   SampleArgs sa = make_sample_args(e, 1, rps);
-  if ((rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, nullptr, s, Lx + col, true))) return rc;
+  if ((rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, nullptr, s, true))) return rc;
   HIPCHK(e, vc_launch_sample(sa, false, s));
   HIPCHK(e, hipEventRecord(e->ev[1], s));
   int steps_run = 0;
-  rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, &steps_run, s, Lx + col);
+  rc = decode_loop(e, sa, 1, rps, false, sc, max_steps, &steps_run, s);
   if (rc) return rc;
   HIPCHK(e, hipEventRecord(e->ev[2], s));
   HIPCHK(e, hipMemcpyAsync(e->h_st, e->st, sizeof(SeqState), hipMemcpyDeviceToHost, s));

@@ -141,10 +141,7 @@ hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStr
 // that wrote whole rows).  Every workgroup of a consumer launch used to pull h + 4 slabs = 40 KB out of L2 whatever n_parts said
 // (unconditional loads, unused slabs discarded by a select): 512 workgroups x 40 KB = 20 MB through the CUs' vector memory
 // pipes per launch, queued IN FRONT of the 25-33 MB weight burst (round 5: in-kernel stamps, profiles/r04b_kernel_stamps_*).
-// PF: the launch carries the prefetch role below (a second grid.z layer of workgroups).  A template parameter because the role's
-// inline asm, merely by being in the kernel, makes hipcc load `*a.n_active` (and a gathered row index) with VECTOR loads in the
-// GEMM path as well (seen in the ISA, round 5): only the form that hosts the role - the one-row out-projection - pays that.
-template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true, bool R2 = false, int NP = VC_MAX_KSPLIT, bool PF = false>
+template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true, bool R2 = false, int NP = VC_MAX_KSPLIT>
 __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
   static_assert(NTW == 1 || PRO == PRO_LNW, "two tiles per workgroup: finished-row consumers only");
@@ -155,24 +152,6 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
 
   VC_KTS_DECL();
   VC_KTS(0);
-  // Prefetch role (round 5, option "gemm_pf"; GemmArgs.pf / pf_blocks): a launch that leaves HBM idle - the one-row
-  // out-projection waits for the attention partials and streams 8.4 MB in 4.3 us; every launch of a d = 1024 model - is launched
-  // with a SECOND grid.z layer of workgroups that do none of its work: the first pf_blocks of them pull the head of a LATER launch's
-  // weight tiles into the L2 of the XCD whose workgroups will read them (vc_common.h vc_prefetch_tiles), the rest exit at once.
-  // The role is decided from blockIdx.z alone - a test against a kernel argument would put a scalar load, its wait and a branch in
-  // front of every other argument load of the GEMM path (seen in the ISA of the first build).  grid.x * grid.y is a multiple of
-  // 8, so a workgroup's XCD is its index within the layer & 7.  (The heads' second linears use grid.z for their groups: no role.)
-  static_assert(!PF || (NTW == 1 && !R2 && EPI != EPI_LOGITS), "prefetch role: one tile per workgroup, grid.z free");
-  if constexpr (PF) {
-    if (blockIdx.z != 0) {
-      const unsigned idx = blockIdx.x + gridDim.x * blockIdx.y;
-      if (idx < (unsigned)a.pf_blocks) {
-        const PfSeg segs[2] = {a.pf, a.pf2};
-        vc_prefetch_tiles(segs, 2, idx, 0u, (unsigned)a.pf_blocks);
-      }
-      return;
-    }
-  }
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wave = (NTW == 1) ? wv : (wv & 3);    // K quarter of the tile
@@ -1513,9 +1492,9 @@ size_t vc_gemm_lds_bytes(const GemmArgs& a, int dtype, int ksplit) {
   return (size_t)a.r_lds * xs + 4 * 64 * sizeof(f32x4) + VC_ROWS * 4 * 3 * sizeof(float);   // X rows, K-reduce area, LN statistics + row means
 }
 
-template <typename WT, int KTW, int PRO, int EPI, int NTW, bool NT, bool R2 = false, int NP = VC_MAX_KSPLIT, bool PF = false>
+template <typename WT, int KTW, int PRO, int EPI, int NTW, bool NT, bool R2 = false, int NP = VC_MAX_KSPLIT>
 static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW, NT, R2, NP, PF>;
+  auto kern = rows_gemm_k<WT, KTW, PRO, EPI, NTW, NT, R2, NP>;
   const size_t lds = vc_gemm_lds_bytes(a, dtype, ksplit) + (size_t)(NTW - 1) * 4 * 64 * sizeof(f32x4);
   if (lds > 64 * 1024) {
     static size_t granted[16] = {0};   // per instantiation and device
@@ -1541,10 +1520,7 @@ static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int gr
     }
   }
   ++vc_launch_counts[VC_LC_ROWS_GEMM];
-  // (prefetch role: extra workgroups behind the tiles; only where the tile -> XCD rule holds)
-  if (!PF || groups != 1 || b.pf_blocks <= 0 || (b.pf.len <= 0 && b.pf2.len <= 0) || (a.n_tiles * ksplit) % 8 != 0 || b.pf_blocks % 8 != 0) b.pf_blocks = 0;
-  b.pf_blocks = std::min(b.pf_blocks, a.n_tiles * ksplit);
-  hipLaunchKernelGGL(kern, dim3(a.n_tiles / NTW, ksplit, b.pf_blocks > 0 ? 2 : groups), dim3(256 * NTW), lds, s, b);
+  hipLaunchKernelGGL(kern, dim3(a.n_tiles / NTW, ksplit, groups), dim3(256 * NTW), lds, s, b);
   return hipGetLastError();
 }
 
@@ -1557,10 +1533,6 @@ static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int group
       if (a.n_parts == 0 && !a.has_prev_bias) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, 0>(a, dtype, ksplit, groups, s);
       if (a.n_parts <= 2) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, 2>(a, dtype, ksplit, groups, s);
     }
-  }
-  if constexpr (PRO == PRO_ATT && EPI == EPI_PART && NTW == 1) {
-    // the one-row out-projection may host the prefetch role (option gemm_pf): its own instantiation
-    if (a.pf_blocks > 0 && a.nt && groups == 1) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, VC_MAX_KSPLIT, true>(a, dtype, ksplit, groups, s);
   }
   if (a.nt) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true>(a, dtype, ksplit, groups, s);
   return launch_dec_nt<WT, KTW, PRO, EPI, NTW, false>(a, dtype, ksplit, groups, s);

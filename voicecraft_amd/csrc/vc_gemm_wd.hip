@@ -35,7 +35,9 @@ namespace {
 template <typename WT> struct WdChunk { static constexpr int X = 8; };     // X fragments of one row tile a wave keeps in flight
 template <> struct WdChunk<float> { static constexpr int X = 4; };         // (exact mode: twice the k-tiles per K, 4-float fragments)
 
-template <typename WT, int KPW, int RT, int EPI>
+// ORD: issue order of a chunk's requests (measured in process, tools/wd_probe.py): 0 = X (k-tile major) then W; 1 = X (row-tile major:
+// the 8 k-tiles of a row tile are 512 contiguous bytes per row) then W; 2 = per k-tile W then X; 3 = W then X (row-tile major)
+template <typename WT, int KPW, int RT, int EPI, int ORD = 0>
 __global__ __launch_bounds__(512) void rows_gemm_wd_k(const GemmArgs a) {
   using T = WTr<WT>;
   constexpr int NW = 8;                      // waves per workgroup = K shares
@@ -87,17 +89,56 @@ __global__ __launch_bounds__(512) void rows_gemm_wd_k(const GemmArgs a) {
 #pragma unroll
   for (int c0 = 0; c0 < KPW; c0 += CK) {
     uint4 xf[RT][CK], wf[2][CK];
-    // X first: L2 hits, and a wave's loads return in order - behind the weight burst they would wait for HBM
+#define VC_WD_LX(r_, j_) xf[r_][j_] = *reinterpret_cast<const uint4*>(xp[r_] + (size_t)(c0 + (j_)) * (T::KW * sizeof(WT)))
+#define VC_WD_LW(t_, j_) wf[t_][j_] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t_] + (size_t)(c0 + (j_)) * 64)))
+    if constexpr (ORD == 0) {
+      // X first: L2 hits, and a wave's loads return in order - behind the weight burst they would wait for HBM
 #pragma unroll
-    for (int j = 0; j < CK; ++j)
+      for (int j = 0; j < CK; ++j)
+#pragma unroll
+        for (int r = 0; r < RT; ++r) VC_WD_LX(r, j);
+#pragma unroll
+      for (int j = 0; j < CK; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) VC_WD_LW(t, j);
+    } else if constexpr (ORD == 1) {
 #pragma unroll
       for (int r = 0; r < RT; ++r)
-        xf[r][j] = *reinterpret_cast<const uint4*>(xp[r] + (size_t)(c0 + j) * (T::KW * sizeof(WT)));
 #pragma unroll
-    for (int j = 0; j < CK; ++j)
+        for (int j = 0; j < CK; ++j) VC_WD_LX(r, j);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        wf[t][j] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wp[t] + (size_t)(c0 + j) * 64)));
+      for (int j = 0; j < CK; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) VC_WD_LW(t, j);
+    } else if constexpr (ORD == 2) {
+#pragma unroll
+      for (int j = 0; j < CK; ++j) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) VC_WD_LW(t, j);
+#pragma unroll
+        for (int r = 0; r < RT; ++r) VC_WD_LX(r, j);
+      }
+    } else if constexpr (ORD == 3) {
+#pragma unroll
+      for (int j = 0; j < CK; ++j)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) VC_WD_LW(t, j);
+#pragma unroll
+      for (int r = 0; r < RT; ++r)
+#pragma unroll
+        for (int j = 0; j < CK; ++j) VC_WD_LX(r, j);
+    } else {        // timing probes, WRONG results by design: 4 = no X requests (the weight stream alone), 5 = no weight requests (X alone)
+#pragma unroll
+      for (int j = 0; j < CK; ++j) {
+#pragma unroll
+        for (int r = 0; r < RT; ++r) { if constexpr (ORD == 5) VC_WD_LX(r, j); else xf[r][j] = make_uint4(lane, j, r, 1u); }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) { if constexpr (ORD == 4) VC_WD_LW(t, j); else wf[t][j] = make_uint4(lane, j, t, 1u); }
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);      // (the requests leave in the order written)
+#undef VC_WD_LX
+#undef VC_WD_LW
     if (c0 == 0) {
       __builtin_amdgcn_sched_barrier(0);
       if (active == 0) return;               // a replayed decode step after the last sequence retired
@@ -126,9 +167,18 @@ __global__ __launch_bounds__(512) void rows_gemm_wd_k(const GemmArgs a) {
   }
 }
 
-template <typename WT, int KPW, int RT, int EPI>
+template <typename WT, int KPW, int RT, int EPI, int ORD = 0>
 hipError_t launch_wd(const GemmArgs& a, int ksplit, int groups, hipStream_t s) {
-  auto kern = rows_gemm_wd_k<WT, KPW, RT, EPI>;
+  if constexpr (ORD == 0 && sizeof(WT) == 2 && KPW >= 2) {       // measurement builds: the request order is selectable (GemmArgs.mt_ntw = 1..3)
+    if (a.mt_ntw == 1) return launch_wd<WT, KPW, RT, EPI, 1>(a, ksplit, groups, s);
+    if (a.mt_ntw == 2) return launch_wd<WT, KPW, RT, EPI, 2>(a, ksplit, groups, s);
+    if (a.mt_ntw == 3) return launch_wd<WT, KPW, RT, EPI, 3>(a, ksplit, groups, s);
+    if constexpr (KPW == 8 && (EPI == EPI_RELU || EPI == EPI_PART)) {
+      if (a.mt_ntw == 4) return launch_wd<WT, KPW, RT, EPI, 4>(a, ksplit, groups, s);
+      if (a.mt_ntw == 5) return launch_wd<WT, KPW, RT, EPI, 5>(a, ksplit, groups, s);
+    }
+  }
+  auto kern = rows_gemm_wd_k<WT, KPW, RT, EPI, ORD>;
   const size_t lds = (size_t)8 * 2 * RT * 64 * sizeof(f32x4);
   if (lds >= 64 * 1024) {
     static bool granted[16] = {false};       // per instantiation and device

@@ -441,17 +441,16 @@ class VoiceCraftEngine:
 
     # ------------------------------------------------------------------ measurement hooks
     def set_option(self, name: str, value) -> None:
-        """Run-time launch-shape option of the decode step (include/vc_engine.h vc_set_option), e.g. ("attn_pf", "0") or
-        ("attn_pf", "8,0,32").  Exact-mode tokens never depend on one; bf16 logits move by rounding where a form re-orders sums
+        """Run-time launch-shape option of the decode step (include/vc_engine.h vc_set_option), e.g. ("fr_one", "0") or
+        ("tile_attn", "2,768").  Exact-mode tokens never depend on one; bf16 logits move by rounding where a form re-orders sums
         (include/vc_engine.h).  bench.py --ab toggles one inside a process."""
         check(self.lib.vc_set_option(self._h, str(name).encode(), str(value).encode()), self._h, f"vc_set_option({name})")
 
     def options(self) -> str:
-        """The engine's option state as text, `key=v,v,...|key=...`: apf = attention-launch prefetch (slices, out-proj KB, FFN-up KB,
-        quarters in force, cuts p1, p2, p0), lpf = LayerNorm-launch prefetch (workgroups, QKV KB, FFN-up KB), g = steps per graph,
-        ls = ln_split_rows, ab = attention workgroups aimed at (several rows, one row), nt = (weight mask, K/V rows), fr = finished-row
-        form (max rows, consumer tiles, split rows), ta = prefill attention (kernel, min rows), r1 = one-row step (fr_one, ln_trim,
-        attn_fast).  bench.py turns it into a JSON object (`config.engine_options`)."""
+        """The engine's option state as text, `key=v,v,...|key=...`: g = steps per graph, ls = ln_split_rows, ab = attention workgroups
+        aimed at (several rows, one row), nt = (weight mask, K/V rows), fr = finished-row form (max rows, consumer tiles, split rows,
+        paired producer), ta = prefill attention (kernel, min rows), r1 = one-row step (fr_one, ln_trim, attn_fast, qkv_p8), q16 = many-row
+        steps (qkv16, wide_heads, mt_tiles, wide_gemm), sh = (shrink, wd_order).  bench.py turns it into a JSON object (`config.engine_options`)."""
         return bytes(self.debug_read("options", (256,), torch.uint8).tolist()).split(b"\0")[0].decode()
 
     def last_timing_ms(self):
