@@ -122,7 +122,7 @@ def in_situ(kernel, args):
 OPTION_STATE = {"graph_steps": ("g", (0,)),
                 "ln_split_rows": ("ls", (0,)), "attn_blocks": ("ab", (0,)), "attn_blocks1": ("ab", (1,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)),
                 "finished_rows": ("fr", (0,)), "lnw_tiles": ("fr", (1,)), "fr_split_rows": ("fr", (2,)), "fr_pair": ("fr", (3,)), "tile_attn": ("ta", (0, 1)),
-                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,)), "mt_tiles": ("q16", (2,)), "wide_gemm": ("q16", (3,)), "shrink": ("sh", (0,))}
+                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,)), "mt_tiles": ("q16", (2,)), "wide_gemm": ("q16", (3,)), "wd_stage": ("q16", (4,)), "shrink": ("sh", (0,))}
 
 
 def option_value(text, knob):
@@ -175,7 +175,7 @@ def options_object(text):
     names = {
              "g": ("graph_steps", None), "ls": ("ln_split_rows", None), "ab": ("attn_blocks", ["several_rows", "one_row"]),
              "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "lnw_tiles", "split_rows", "paired"]),
-             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "q16": ("many_rows", ["qkv16", "wide_heads", "mt_tiles", "wide_gemm"]), "sh": ("shrink", ["on", "wd_order"])}
+             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "q16": ("many_rows", ["qkv16", "wide_heads", "mt_tiles", "wide_gemm", "wd_stage"]), "sh": ("shrink", None)}
     out = {"text": text}
     try:
         for part in text.split("|"):

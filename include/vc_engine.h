@@ -108,8 +108,9 @@ const char* vc_version(void);
  *   "qkv16"        1 (default) = prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
  *                  the folded matrix instead of the one-row kernels' 12-channel tiles (VC_QKV16=0 at creation: not packed, stays off)
  *   "wide_heads"   1 (default) = decode steps of 17..64 rows run the prediction heads once on the wide-decode kernel instead of once per 16 rows
- *   "wide_gemm"    1 (default) = the linear layers of 17..64-row steps run on rows_gemm_wd_k (every row tile in flight, X straight from L2; widths
- *                  whose K does not split into 8 x {1, 2, 4, 8, 16} k-tiles, and 0, take the weight-stationary rows_gemm_mt_k of rounds 2-5)
+ *   "wide_gemm"    1 (default) = the linear layers of 17..64-row steps run on rows_gemm_wd_k / rows_gemm_wds_k (every row tile of the step in flight;
+ *                  widths whose K does not split into 8 x {1, 2, 4, 8, 16} k-tiles, and 0, take the weight-stationary rows_gemm_mt_k of rounds 2-5);
+ *                  "wd_stage" 1 (default) = that kernel takes X as whole cache lines through a wave-private LDS stage, 0 = MFMA fragments straight from L2
  *   "mt_tiles"     weight tiles per workgroup of THAT kernel: 2 (default), 4, 0 = by tile count (rounds 2-4), 1 = two from 33 rows on
  *   "shrink"       1 (default) = a multi-utterance call re-packs its live sequences onto the rows of a narrower step (next power of two) as the
  *                  others retire; 0 = the step keeps its starting width until the longest sequence ends (rounds 1-5)
@@ -117,7 +118,7 @@ const char* vc_version(void);
  * What an option may change: nothing in the exact fp32 mode's greedy tokens (tests/test_gpu_options.py, test_gpu_one_row.py); in bf16
  * mode the forms that re-order sums or round at another place ("finished_rows", "fr_split_rows", "attn_blocks*", "fr_one",
  * "attn_fast", "qkv16", "wide_heads", "wide_gemm", "mt_tiles") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can
- * differ between option states; the cache-policy / host-side options ("nt", "attn_nt", "ln_trim", "graph_steps", "shrink") change no value.
+ * differ between option states; the cache-policy / data-path / host-side options ("nt", "attn_nt", "ln_trim", "wd_stage", "graph_steps", "shrink") change no value.
  * (The prefetch roles of rounds 3-5 - "attn_pf", "attn_pf_cut", "gemm_pf" - left the tree in round 6: default-off, or inside the
  * spread on the driver's box)
  * The non-temporal mask "nt" has no bit for the finished-row producers (rows_gemm_fr_k, rows_gemm_fr2_k, row_gemm_fr1_k): they always

@@ -172,9 +172,9 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
             assert np.abs(lg[1] - lg[0])[live].max() < 0.25, float(np.abs(lg[1] - lg[0])[live].max())
 
 
-# launch forms of the linear layers of 17..64-row steps: rows_gemm_wd_k (round 6, the default), and the weight-stationary
+# launch forms of the linear layers of 17..64-row steps: rows_gemm_wd_k (round 6: X through its LDS stage - the default - or straight from L2), and the weight-stationary
 # rows_gemm_mt_k of rounds 2-5 with two / by-tile-count / two-from-33-rows / four weight tiles per workgroup
-WIDE_FORMS = [(("wide_gemm", 1),), (("wide_gemm", 0), ("mt_tiles", 2)), (("wide_gemm", 0), ("mt_tiles", 0)),
+WIDE_FORMS = [(("wide_gemm", 1), ("wd_stage", 1)), (("wide_gemm", 1), ("wd_stage", 0)), (("wide_gemm", 0), ("mt_tiles", 2)), (("wide_gemm", 0), ("mt_tiles", 0)),
               (("wide_gemm", 0), ("mt_tiles", 1)), (("wide_gemm", 0), ("mt_tiles", 4))]
 
 

@@ -114,31 +114,37 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
 
 
 def test_wide_decode_kernel_keeps_every_row_tile_in_flight(kern):
-    """rows_gemm_wd_k (round 6, 17..64-row steps): nothing is staged and nothing is waited for before everything is requested - at
-    d = 2048 / 64 rows a wave asks for its 32 X fragments (plain loads, L2) and then its 16 weight fragments (non-temporal, HBM) in one
-    batch, runs 64 MFMAs into 8 accumulators and meets the other waves at ONE barrier; 512 threads at <= 256 registers, no scratch."""
+    """rows_gemm_wd_k / rows_gemm_wds_k (round 6, 17..64-row steps): nothing is waited for before everything is requested - at d = 2048 /
+    64 rows a wave of the direct form asks for its 32 X fragments (plain loads, L2) and then its 16 weight fragments (non-temporal, HBM) in
+    one batch; the staged form asks for two chunks of whole-line X requests and the 16 weight fragments, parks X in its own LDS stage
+    (ds_write_b128) and reads the fragments back; both run 64 MFMAs into 8 accumulators and meet the other waves at ONE barrier; 512
+    threads at <= 256 registers, no scratch."""
     import re
-    sel = {n: v for n, v in kern.items() if "rows_gemm_wd_k<" in n}
-    assert len(sel) >= 80, len(sel)
-    for name, (body, scratch, vgpr) in sel.items():
-        m = re.search(r"rows_gemm_wd_k<(\w+), (\d+), (\d+), (\d+)(?:, (\d+))?>", name)
-        assert m, name
-        wt, kpw, rt = m.group(1), int(m.group(2)), int(m.group(3))
-        if m.group(5) and int(m.group(5)) >= 4:
-            continue            # (measurement builds: timing probes without one of the operand streams)
-        assert scratch == 0 and vgpr <= 256, (name, scratch, vgpr)
-        assert body.count("s_barrier") == 1, name
-        ck = min(kpw, 8 if wt == "bf16_t" else 4)
-        nt_loads = len(re.findall(r"global_load_dwordx4[^\n]* nt", body))
-        mf = body.count("v_mfma_f32_16x16x32_bf16") if wt == "bf16_t" else body.count("v_mfma_f32_16x16x4_f32") // 4
-        if kpw == ck:         # one chunk: straight-line code, every fragment counted once
-            assert nt_loads == 2 * kpw and mf == 2 * rt * kpw, (name, nt_loads, mf)
-    main = {n: v for n, v in sel.items() if "rows_gemm_wd_k<bf16_t, 8, 4, 2>" in n or "rows_gemm_wd_k<bf16_t, 8, 4, 2, 0>" in n}
+    direct = {n: v for n, v in kern.items() if "rows_gemm_wd_k<" in n}
+    staged = {n: v for n, v in kern.items() if "rows_gemm_wds_k<" in n}
+    assert len(direct) >= 80 and len(staged) >= 60, (len(direct), len(staged))
+    for sel, pat in ((direct, r"rows_gemm_wd_k<(\w+), (\d+), (\d+), (\d+)>"), (staged, r"rows_gemm_wds_k<(\w+), (\d+), (\d+), (\d+)>")):
+        for name, (body, scratch, vgpr) in sel.items():
+            m = re.search(pat, name)
+            assert m, name
+            wt, kpw, rt = m.group(1), int(m.group(2)), int(m.group(3))
+            assert scratch == 0 and vgpr <= 256, (name, scratch, vgpr)
+            assert body.count("s_barrier") == 1, name
+            nt_loads = len(re.findall(r"global_load_dwordx4[^\n]* nt", body))
+            mf = body.count("v_mfma_f32_16x16x32_bf16") if wt == "bf16_t" else body.count("v_mfma_f32_16x16x4_f32") // 4
+            if sel is staged or kpw <= (8 if wt == "bf16_t" else 4):         # straight-line code: every fragment counted once
+                assert nt_loads == 2 * kpw and mf == 2 * rt * kpw, (name, nt_loads, mf)
+    main = {n: v for n, v in direct.items() if "rows_gemm_wd_k<bf16_t, 8, 4, 2>" in n}
     assert main
-    for name, (body, _, vgpr) in main.items():      # FFN-up at d = 2048, 33..64 rows
+    for name, (body, _, vgpr) in main.items():      # FFN-up at d = 2048, 33..64 rows, direct form
         first_wait = body.index("s_waitcnt vmcnt")
         assert len(re.findall(r"global_load_dwordx4", body[:first_wait])) >= 48, name         # 32 X + 16 W (+ the bias) before the first wait
-        assert "ds_write_b128" in body and "ds_read_b128" in body and vgpr <= 256, (name, vgpr)
+    main = {n: v for n, v in staged.items() if "rows_gemm_wds_k<bf16_t, 8, 4, 2>" in n}
+    assert main
+    for name, (body, _, vgpr) in main.items():      # ... and the staged form: 2 chunks x 8 whole-line requests + 16 W ahead of the first wait
+        first_wait = body.index("s_waitcnt vmcnt")
+        assert len(re.findall(r"global_load_dwordx4", body[:first_wait])) >= 32, name
+        assert body.count("global_load_dwordx4") == 4 * 8 + 16 + 1 and body.count("ds_write_b128") >= 32 + 8 and vgpr <= 200, (name, vgpr)
 
 
 def test_the_non_temporal_hint_survives_in_every_decode_gemm(kern):

@@ -29,16 +29,16 @@ for rows in (32, 48, 64):
         r["delta_pct"] = round(100.0 * (r["wd"]["us"] / r["mt2"]["us"] - 1.0), 1)
         out[f"{which}@{rows}"] = r
     eng.set_option("wide_gemm", 1)
-    # request order inside rows_gemm_wd_k (measurement builds carry the four forms; option wd_order)
+    # X through the wave-private LDS stage (wd_stage = 1, the default) against fragments straight from L2 (0)
     for which in ("wd_ffn1", "wd_ffn2", "wd_qkv", "wd_oproj"):
         r = {}
-        for o in ((0, 1, 2, 3, 4, 5, 0) if which in ("wd_ffn1", "wd_ffn2") else (0, 1, 2, 3, 0)):      # 4 / 5: weight stream alone / X alone (timing only)
-            eng.set_option("wd_order", o)
+        for o in (1, 0, 1):
+            eng.set_option("wd_stage", o)
             eng.bench_kernel(which, n_rows=rows, iters=16)
             ms, by = min(eng.bench_kernel(which, n_rows=rows, iters=128), eng.bench_kernel(which, n_rows=rows, iters=128))
-            r.setdefault(f"order{o}", []).append(round(ms * 1e3, 2))
-        out[f"{which}@{rows} by request order"] = r
-    eng.set_option("wd_order", 0)
+            r.setdefault(f"stage{o}", []).append(round(ms * 1e3, 2))
+        out[f"{which}@{rows} staged / direct"] = r
+    eng.set_option("wd_stage", 1)
     for which in ("wd_ln", "wd_attn"):
         eng.bench_kernel(which, n_rows=rows, iters=16)
         ms, by = min(eng.bench_kernel(which, n_rows=rows, iters=128), eng.bench_kernel(which, n_rows=rows, iters=128))

@@ -210,6 +210,7 @@ struct GemmArgs {
   int r_lds;                // rows of X staged in LDS (<= VC_ROWS)
   int rows_cap;             // row stride of the split-K slabs: parts[s][rows_cap][N]
   int mt_ntw;               // wide decode pass (mt == 2): weight tiles per workgroup, 0 = by tile count (4 from 512 tiles on), 2 or 4 forced (option "mt_tiles")
+  int wd_stage;             // rows_gemm_wd_k launches: 1 = X through the wave-private LDS stage (rows_gemm_wds_k), 0 = fragments straight from L2 (option "wd_stage")
   int nt;                   // 1: stream the weights with non-temporal loads
   int mt;                   // 1: prefill pass (rows_gemm_blk_k): n_rows may reach VC_MAX_ROWS, plain prologue only; 2: wide decode pass
                             // (rows_gemm_mt_k); 3: PRO_LNW with two weight tiles per workgroup (rows_gemm_k<..., NTW = 2>)

@@ -139,7 +139,9 @@ struct vc_engine {
   // flight at once, X fragments straight from L2 into registers, one barrier per launch) instead of the weight-stationary
   // rows_gemm_mt_k, which walks the row tiles one after the other; 0 = the round-2..5 kernel (its "mt_tiles" then applies)
   int wide_gemm = 1;
-  int wd_order = 0;                     // measurement option "wd_order": request order inside rows_gemm_wd_k (vc_gemm_wd.hip ORD)
+  // option "wd_stage": 1 (default) = that kernel takes X as whole cache lines through a wave-private LDS stage (rows_gemm_wds_k: 64 rows FFN-up
+  // 13.5 -> 9.7 us, the 64-row step -9.5 % +- 0.01, 32 rows -2.7 %; profiles/r06c_*), 0 = MFMA fragments straight from L2 (16 half lines per request)
+  int wd_stage = 1;
   // option "shrink" (round 6): a multi-utterance call whose sequences retire at different steps re-packs the live ones onto the rows of a
   // narrower step (the next power of two >= the live count: 64 -> 32 -> 16 -> 8 -> 4 -> 2 -> 1) instead of keeping its launch form until
   // the longest sequence ends; 0 = the fixed width of rounds 1-5.  Results do not depend on it: everything per sequence is indexed by its slot.
@@ -313,7 +315,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.dbg_ts = e->dbg_ts;
   g.ln_trim = e->ln_trim;
   g.mt_ntw = (e->mt_tiles == 1 && rs.n_rows > 32) ? 2 : (e->mt_tiles == 2 || e->mt_tiles == 4) ? e->mt_tiles : 0;    // 1 = two tiles from 33 rows on
-  if (e->wide_gemm && e->wd_order >= 0) g.mt_ntw = e->wd_order;        // (measurement: request order of rows_gemm_wd_k)
+  g.wd_stage = e->wd_stage;
   return g;
 }
 
@@ -1016,7 +1018,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->mt_tiles = v0;
   } else if (name == "wide_gemm") { e->wide_gemm = v0 ? 1 : 0;
   } else if (name == "shrink") { e->shrink = v0 ? 1 : 0;
-  } else if (name == "wd_order") { e->wd_order = std::max(0, std::min(v0, 5));
+  } else if (name == "wd_stage") { e->wd_stage = v0 ? 1 : 0;
   } else if (name == "qkv16") {
     if (v0 && !e->layers.empty() && !e->layers[0].Wqkv16)
       return fail(e, VC_ESTATE, "option 'qkv16': this engine was created with VC_QKV16=0 and holds no 16-channel image of the QKV matrix");
@@ -1033,10 +1035,10 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|q16=%d,%d,%d,%d|sh=%d,%d",
+  snprintf(buf, sizeof buf, "g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|q16=%d,%d,%d,%d,%d|sh=%d",
            e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
            e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->qkv16, e->wide_heads, e->mt_tiles, e->wide_gemm, e->shrink, e->wd_order);
+           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->qkv16, e->wide_heads, e->mt_tiles, e->wide_gemm, e->wd_stage, e->shrink);
   e->opt_state = buf;
 }
 
@@ -1354,7 +1356,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_MT_TILES", "mt_tiles"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_MT_TILES", "mt_tiles"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";

@@ -450,7 +450,7 @@ class VoiceCraftEngine:
         """The engine's option state as text, `key=v,v,...|key=...`: g = steps per graph, ls = ln_split_rows, ab = attention workgroups
         aimed at (several rows, one row), nt = (weight mask, K/V rows), fr = finished-row form (max rows, consumer tiles, split rows,
         paired producer), ta = prefill attention (kernel, min rows), r1 = one-row step (fr_one, ln_trim, attn_fast, qkv_p8), q16 = many-row
-        steps (qkv16, wide_heads, mt_tiles, wide_gemm), sh = (shrink, wd_order).  bench.py turns it into a JSON object (`config.engine_options`)."""
+        steps (qkv16, wide_heads, mt_tiles, wide_gemm, wd_stage), sh = shrink.  bench.py turns it into a JSON object (`config.engine_options`)."""
         return bytes(self.debug_read("options", (256,), torch.uint8).tolist()).split(b"\0")[0].decode()
 
     def last_timing_ms(self):
