@@ -119,10 +119,9 @@ def in_situ(kernel, args):
 
 
 # option name -> (key of the option-state text, positions of its values there)
-OPTION_STATE = {"graph_steps": ("g", (0,)),
-                "ln_split_rows": ("ls", (0,)), "attn_blocks": ("ab", (0,)), "attn_blocks1": ("ab", (1,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)),
-                "finished_rows": ("fr", (0,)), "lnw_tiles": ("fr", (1,)), "fr_split_rows": ("fr", (2,)), "fr_pair": ("fr", (3,)), "tile_attn": ("ta", (0, 1)),
-                "fr_one": ("r1", (0,)), "ln_trim": ("r1", (1,)), "attn_fast": ("r1", (2,)), "qkv_p8": ("r1", (3,)), "qkv16": ("q16", (0,)), "wide_heads": ("q16", (1,)), "mt_tiles": ("q16", (2,)), "wide_gemm": ("q16", (3,)), "wd_stage": ("q16", (4,)), "shrink": ("sh", (0,))}
+OPTION_STATE = {"graph_steps": ("g", (0,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)), "finished_rows": ("fr", (0,)), "fr_pair": ("fr", (1,)),
+                "tile_attn": ("ta", (0, 1)), "fr_one": ("r1", (0,)), "attn_fast": ("r1", (1,)), "qkv_p8": ("r1", (2,)), "qkv16": ("q16", (0,)),
+                "wide_heads": ("q16", (1,)), "wide_gemm": ("q16", (2,)), "wd_stage": ("q16", (3,)), "shrink": ("sh", (0,))}
 
 
 def option_value(text, knob):
@@ -172,10 +171,9 @@ def sampler_block(wl, box):
 
 def options_object(text):
     """The engine's option state (a compact text, vc_debug_read "options") as a JSON object."""
-    names = {
-             "g": ("graph_steps", None), "ls": ("ln_split_rows", None), "ab": ("attn_blocks", ["several_rows", "one_row"]),
-             "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "lnw_tiles", "split_rows", "paired"]),
-             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "ln_trim", "attn_fast", "qkv_p8"]), "q16": ("many_rows", ["qkv16", "wide_heads", "mt_tiles", "wide_gemm", "wd_stage"]), "sh": ("shrink", None)}
+    names = {"g": ("graph_steps", None), "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "paired"]),
+             "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "attn_fast", "qkv_p8"]),
+             "q16": ("many_rows", ["qkv16", "wide_heads", "wide_gemm", "wd_stage"]), "sh": ("shrink", None)}
     out = {"text": text}
     try:
         for part in text.split("|"):
@@ -836,7 +834,7 @@ def main():
             # the other one-row forms of round 5 in `ab_more` (fewer pairs).  (The prefetch roles of rounds 3-5 left the tree in round 6.)
             ab = ("fr_one=0:1" if B == 1 else "finished_rows=0:16" if B <= 16 else "wide_gemm=0:1")
             if B == 1:
-                more = ["qkv_p8=0:1", "ln_trim=0:1"]
+                more = ["qkv_p8=0:1"]
         if n_gpus == 1 and ab and ab != "none":
             try:
                 out["ab"] = ab_block(eng, one_step, ab, max(3, args.ab_pairs))

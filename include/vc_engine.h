@@ -94,36 +94,36 @@ const char* vc_last_error(const vc_engine* e); /* e may be NULL: last vc_create 
 const char* vc_version(void);
 
 /* Run-time options of a finalized engine: launch-shape knobs of the decode step, the same ones the VC_* environment
- * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  name / value:
+ * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  Fifteen of them (round 6
+ * pruned the list: the prefetch roles and the knobs whose value every measurement had fixed are constants now).  name / value:
  *   "nt"           bit mask of the weight matrices streamed with the non-temporal hint (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down, 16 / 32
  *                  heads); "attn_nt" 0 / 1 / 2 = the decode attention's K/V loads never / always / from two rows per step
  *   "finished_rows" rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs (0 = off, max 16);
- *   "fr_one"       ONE-row steps: 1 (default) = the FFN down-projection finishes its row (no split-K slabs), 0 = off;  "ln_trim" 1 = the LayerNorm prologue requests only the slabs
- *                  a pass has;  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
- *   "lnw_tiles"    weight tiles per workgroup of that form's consumers (0 = by row count, 1, 2);  "fr_pair" 1 = its FFN down-projection
- *                  with two k-tiles per MFMA fragment at 2..8 rows;  "qkv_p8" 1 = the one-row QKV projection in the same paired form (2: 8 waves)
+ *                  "fr_pair" 1 = its FFN down-projection with two k-tiles per MFMA fragment at 2..8 rows
+ *   "fr_one"       ONE-row steps: 1 (default) = the FFN down-projection finishes its row (no split-K slabs), 0 = off;  "qkv_p8" 1 = the
+ *                  one-row QKV projection in the same paired form;  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
  *   "tile_attn"    "k[,min_rows]"  prefill attention kernel (1: 16 query rows per wave; 2: 64 per workgroup, P in registers - bf16,
- *                  head_dim 128, calls whose longest prompt has at least min_rows rows); "fr_split_rows" rows up to which that form's
- *                  attention stays split
- *   "qkv16"        1 (default) = prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
- *                  the folded matrix instead of the one-row kernels' 12-channel tiles (VC_QKV16=0 at creation: not packed, stays off)
+ *                  head_dim 128, calls whose longest prompt has at least min_rows rows)
+ *   "qkv16"        1 = prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of the folded matrix
+ *                  instead of the one-row kernels' 12-channel tiles.  The image is packed for engines with max_seqs > 16 (or VC_QKV16=1 at
+ *                  creation); without it the option stays 0 and wide steps fall back to the weight-stationary kernel
  *   "wide_heads"   1 (default) = decode steps of 17..64 rows run the prediction heads once on the wide-decode kernel instead of once per 16 rows
  *   "wide_gemm"    1 (default) = the linear layers of 17..64-row steps run on rows_gemm_wd_k / rows_gemm_wds_k (every row tile of the step in flight;
  *                  widths whose K does not split into 8 x {1, 2, 4, 8, 16} k-tiles, and 0, take the weight-stationary rows_gemm_mt_k of rounds 2-5);
  *                  "wd_stage" 1 (default) = that kernel takes X as whole cache lines through a wave-private LDS stage, 0 = MFMA fragments straight from L2
- *   "mt_tiles"     weight tiles per workgroup of THAT kernel: 2 (default), 4, 0 = by tile count (rounds 2-4), 1 = two from 33 rows on
  *   "shrink"       1 (default) = a multi-utterance call re-packs its live sequences onto the rows of a narrower step (next power of two) as the
  *                  others retire; 0 = the step keeps its starting width until the longest sequence ends (rounds 1-5)
- *   "graph_steps"  decode steps captured per hipGraph;  "ln_split_rows", "attn_blocks", "attn_blocks1", "prefill_rows"
+ *   "graph_steps"  decode steps captured per hipGraph;  "prefill_rows"  rows per prefill pass (16: decode kernels only)
  * What an option may change: nothing in the exact fp32 mode's greedy tokens (tests/test_gpu_options.py, test_gpu_one_row.py); in bf16
- * mode the forms that re-order sums or round at another place ("finished_rows", "fr_split_rows", "attn_blocks*", "fr_one",
- * "attn_fast", "qkv16", "wide_heads", "wide_gemm", "mt_tiles") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can
- * differ between option states; the cache-policy / data-path / host-side options ("nt", "attn_nt", "ln_trim", "wd_stage", "graph_steps", "shrink") change no value.
- * (The prefetch roles of rounds 3-5 - "attn_pf", "attn_pf_cut", "gemm_pf" - left the tree in round 6: default-off, or inside the
- * spread on the driver's box)
- * The non-temporal mask "nt" has no bit for the finished-row producers (rows_gemm_fr_k, rows_gemm_fr2_k, row_gemm_fr1_k): they always
- * stream with the hint.  Captured decode graphs are kept per option state, so an in-process A/B (bench.py --ab) pays for capture once
- * per state.  Unknown names / malformed values: VC_EINVAL. */
+ * mode the forms that re-order sums or round at another place ("finished_rows", "fr_pair", "fr_one", "qkv_p8", "attn_fast", "qkv16",
+ * "wide_heads", "wide_gemm") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can differ between option
+ * states; the cache-policy / data-path / host-side options ("nt", "attn_nt", "wd_stage", "graph_steps", "shrink") change no value.
+ * The non-temporal mask "nt" has no bit for the finished-row producers (rows_gemm_fr_k, rows_gemm_fr2_k, row_gemm_fr1_k) and the
+ * wide-decode kernels: they always stream with the hint.  Captured decode graphs are kept per option state and step width, so an
+ * in-process A/B (bench.py --ab) pays for capture once per state.  Unknown names / malformed values: VC_EINVAL.
+ * (Left the tree in round 6: the prefetch roles "attn_pf", "attn_pf_cut", "gemm_pf" - default-off, or inside the spread on the driver's
+ * box -, and the knobs "ln_trim", "lnw_tiles", "fr_split_rows", "attn_blocks", "attn_blocks1", "ln_split_rows", "mt_tiles", whose measured
+ * best value is a constant now) */
 int vc_set_option(vc_engine* e, const char* name, const char* value);
 
 /* ---- weights: replaces get_model()/load_state_dict (inference_tts_scale.py:107-125).

@@ -47,9 +47,8 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256, use_graph=False)
     L = a.num_decoder_layers
     got = {}
-    for mode in ("on", "on1", "unpaired", "off"):   # on: two weight tiles per consumer workgroup (the default); on1: one; unpaired: round 4's FFN-down producer
+    for mode in ("on", "unpaired", "off"):   # on: the default; unpaired: round 4's FFN-down producer; off: split-K slabs + LayerNorm launches
         eng.set_option("finished_rows", 0 if mode == "off" else 16)
-        eng.set_option("lnw_tiles", 1 if mode == "on1" else 2)
         eng.set_option("fr_pair", 0 if mode == "unpaired" else 1)
         assert ("|fr=0," if mode == "off" else "|fr=16,") in eng.options()
         c0 = eng.launch_counts()
@@ -73,7 +72,6 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
         assert worst <= 2e-2, (mode, worst)
         got[mode] = lg
     assert np.abs(got["on"] - got["off"])[np.abs(got["off"]) < 1e3].max() < 0.25      # two roundings of the same numbers
-    assert np.array_equal(got["on"], got["on1"])               # one or two tiles per workgroup: the same sums in the same order
     assert np.abs(got["on"] - got["unpaired"])[np.abs(got["off"]) < 1e3].max() < 0.25    # paired / unpaired producer: another order of the same sums
 
 
@@ -106,8 +104,8 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
     x, xl, y = synth.random_prompt(a, 6, 21, seed=11)
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=2, max_positions=256)
     base = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
-    for name, value in [("attn_nt", "1"), ("attn_nt", "0"), ("nt", "28"), ("nt", "0"), ("nt", "63"), ("graph_steps", "3"), ("attn_blocks1", "64"),
-                        ("ln_split_rows", "2"), ("graph_steps", "8"), ("shrink", "0"), ("wide_gemm", "0")]:
+    for name, value in [("attn_nt", "1"), ("attn_nt", "0"), ("nt", "28"), ("nt", "0"), ("nt", "63"), ("graph_steps", "3"), ("graph_steps", "8"),
+                        ("shrink", "0"), ("wide_gemm", "0"), ("wd_stage", "0"), ("tile_attn", "1")]:
         eng.set_option(name, value)
         got = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
         assert np.array_equal(got, base), (name, value)
@@ -117,11 +115,13 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
         eng.set_option("graph_steps", "many")
     with pytest.raises(AssertionError):
         eng.set_option("attn_pf", "8")          # the prefetch roles of rounds 3-5 are gone
+    with pytest.raises(AssertionError):
+        eng.set_option("mt_tiles", "4")         # ... and the knobs whose measured best value became a constant
 
 
 @pytest.mark.parametrize("preset,B", [("tiny", 1), ("tiny_h16", 1), ("tiny128", 20)])
 def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
-    """Options `qkv16`, `wide_heads` (both default on) and `mt_tiles`.  `qkv16`: prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
+    """Options `qkv16` and `wide_heads`.  `qkv16`: prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of
     the LayerNorm-folded matrix instead of the 12-channel tiles of the one-row kernels.  The same dot products on other MFMA lanes:
     fp32 tokens equal the oracle's in both states (one sequence: the prompt pass; 20 sequences: 20-row decode steps as well; the wide-decode
     kernel itself at d = 2048: tests/test_gpu_scale.py, 32 rows), bf16
@@ -133,14 +133,20 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
     prompts = [synth.random_prompt(a, 4 + (u % 5), 17 + 3 * (u % 7), seed=500 + u) for u in range(B)]
     _, want_res = _oracle_traces(a, sd, prompts)
     for dtype in ("fp32", "bf16"):
-        eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype=dtype, max_seqs=B, max_positions=256)
+        # (the 16-channel image is packed for engines that can take wide steps - max_seqs > 16 - or on request: VC_QKV16=1 at creation)
+        import os
+        os.environ["VC_QKV16"] = "1"
+        try:
+            eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype=dtype, max_seqs=B, max_positions=256)
+        finally:
+            os.environ.pop("VC_QKV16", None)
         res = {}
-        # (wide_heads: 17..64-row steps run the heads once on the wide-decode kernel, not per 16 rows; mt_tiles: that kernel's weight tiles
-        # per workgroup - 2, the default, or by tile count as through round 4)
-        for q16, wh, mt in ((1, 1, 2), (0, 0, 0), (1, 0, 2), (1, 1, 0)):
+        # (wide_heads: 17..64-row steps run the heads once on the wide-decode kernel, not per 16 rows; wide_gemm 0: the weight-stationary
+        # kernel of rounds 2-5)
+        for q16, wh, mt in ((1, 1, 1), (0, 0, 0), (1, 0, 1), (1, 1, 0)):
             eng.set_option("qkv16", q16)
             eng.set_option("wide_heads", wh)
-            eng.set_option("mt_tiles", mt)
+            eng.set_option("wide_gemm", mt)
             assert f"|q16={q16},{wh},{mt}," in eng.options()
             c0 = eng.launch_counts()
             if B == 1:
@@ -158,7 +164,7 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
                 assert (c["mt2"] + c["mt4"] + c["wd"] > 0) if wh else (c["rows_gemm"] > 0), (wh, c)
             res[(q16, wh, mt)] = got
         if dtype == "bf16" and B > 1:
-            same = sum(int(np.array_equal(g1, g0)) for g1, g0 in zip(res[(1, 1, 2)], res[(0, 0, 0)]))
+            same = sum(int(np.array_equal(g1, g0)) for g1, g0 in zip(res[(1, 1, 1)], res[(0, 0, 0)]))
             assert same >= (B * 3) // 4, (same, B)
         if dtype == "bf16" and B == 1:
             # one sequence: only the PROMPT pass reads the image (block GEMM, EPI_QKV16).  A value check instead of a token count
@@ -173,9 +179,8 @@ def test_qkv16_image_of_prefill_and_wide_decode_passes(preset, B):
 
 
 # launch forms of the linear layers of 17..64-row steps: rows_gemm_wd_k (round 6: X through its LDS stage - the default - or straight from L2), and the weight-stationary
-# rows_gemm_mt_k of rounds 2-5 with two / by-tile-count / two-from-33-rows / four weight tiles per workgroup
-WIDE_FORMS = [(("wide_gemm", 1), ("wd_stage", 1)), (("wide_gemm", 1), ("wd_stage", 0)), (("wide_gemm", 0), ("mt_tiles", 2)), (("wide_gemm", 0), ("mt_tiles", 0)),
-              (("wide_gemm", 0), ("mt_tiles", 1)), (("wide_gemm", 0), ("mt_tiles", 4))]
+# rows_gemm_mt_k of rounds 2-5 (two weight tiles per workgroup)
+WIDE_FORMS = [(("wide_gemm", 1), ("wd_stage", 1)), (("wide_gemm", 1), ("wd_stage", 0)), (("wide_gemm", 0),)]
 
 
 def _free_running_multi(eng, prompts):

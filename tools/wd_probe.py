@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """The linear layers of a WIDE decode step (17..64 rows), isolated: rows_gemm_wd_k (option wide_gemm = 1, round 6) against the
-weight-stationary rows_gemm_mt_k of rounds 2-5 (wide_gemm = 0; its mt_tiles = 2), per matrix and row count, with the algorithmic
+weight-stationary rows_gemm_mt_k of rounds 2-5 (wide_gemm = 0), per matrix and row count, with the algorithmic
 bytes per launch and the fraction of the 8 TB/s HBM peak; plus the step's LayerNorm launch and its attention launch.
   python tools/wd_probe.py [preset] > profiles/r06_wd_probe.log"""
 import json
@@ -20,7 +20,7 @@ out = {"preset": preset}
 for rows in (32, 48, 64):
     for which in ("wd_ffn1", "wd_ffn2", "wd_qkv", "wd_oproj"):
         r = {}
-        for name, opts in (("wd", {"wide_gemm": 1}), ("mt2", {"wide_gemm": 0, "mt_tiles": 2})):
+        for name, opts in (("wd", {"wide_gemm": 1}), ("mt2", {"wide_gemm": 0})):
             for k, v in opts.items():
                 eng.set_option(k, v)
             eng.bench_kernel(which, n_rows=rows, iters=16)

@@ -209,7 +209,6 @@ struct GemmArgs {
   int nchunk;               // k-chunks per block; a chunk = 4 waves * KTW tiles
   int r_lds;                // rows of X staged in LDS (<= VC_ROWS)
   int rows_cap;             // row stride of the split-K slabs: parts[s][rows_cap][N]
-  int mt_ntw;               // wide decode pass (mt == 2): weight tiles per workgroup, 0 = by tile count (4 from 512 tiles on), 2 or 4 forced (option "mt_tiles")
   int wd_stage;             // rows_gemm_wd_k launches: 1 = X through the wave-private LDS stage (rows_gemm_wds_k), 0 = fragments straight from L2 (option "wd_stage")
   int nt;                   // 1: stream the weights with non-temporal loads
   int mt;                   // 1: prefill pass (rows_gemm_blk_k): n_rows may reach VC_MAX_ROWS, plain prologue only; 2: wide decode pass
@@ -229,7 +228,6 @@ struct GemmArgs {
   int n_parts;
   const float* prev_bias;   // always a readable [d] vector; added only when has_prev_bias
   int has_prev_bias;
-  int ln_trim;              // 1: the LayerNorm prologue requests only as many slabs as n_parts needs (0 / 2 / 4; rows_gemm_k NP)
   const float* wg;          // LN prologue: [group][N] row sums of the folded weights (W . gamma), see vc_gemm.hip
   const int* gather_rows;   // optional indirection on h_in/parts rows (logit rows for the heads)
   int d;                    // row width of h / parts

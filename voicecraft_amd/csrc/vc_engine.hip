@@ -100,20 +100,18 @@ struct vc_engine {
   // (in-process A/Bs, profiles/r04d_bench_*attn_nt*: one row +0.3 % +- 0.09 - there the launch is latency-bound and carries the prefetch
   // role -, 8 rows -4.8 % +- 0.05, 32 rows -6.5 % +- 0.05: several caches stream 58-230 MB per layer through L2 otherwise)
   int attn_nt = 2;
-  int ln_split_rows = 3;                // VC_LN_SPLIT_ROWS: passes with at least this many rows run LayerNorm as its own launch
+  static constexpr int ln_split_rows = 3;      // slab-form passes with at least this many rows run LayerNorm as its own launch (was an option through round 5)
   // finished-row form of decode passes of 2..fr_rows rows (forward_rows_fr): 0 = off.  VC_FINISHED_ROWS / option "finished_rows"
   int fr_rows = VC_ROWS;
-  // weight tiles per workgroup of the finished-row consumers (QKV, FFN-up); option "lnw_tiles": 1, 2, or 0 = by row count - two
-  // from 5 rows up (in-process A/Bs, profiles/r04b_bench_batch*.json.log: 8 rows -3.4 % +- 0.1 with two, 4 rows +0.5 % +- 0.05:
-  // there half of the 8 waves have no row to fold)
-  int lnw_tiles = 0;
+  // (weight tiles per workgroup of the finished-row consumers (QKV, FFN-up): two from 5 rows up - in-process A/Bs of round 4,
+  // profiles/r04b_bench_batch*.json.log: 8 rows -3.4 % +- 0.1 with two, 4 rows +0.5 % +- 0.05 - lnw_two(); an option through round 5)
   // option "tile_attn": prefill attention kernel - 1 = tile_attn_k (16 query rows per wave, keys split over the waves), 2 =
   // tile_attn64_k (64 query rows per workgroup, transposed score product, P in registers; bf16 / head_dim 128 only, prompts are then
   // laid out on 64-row boundaries)
   // Default 2 when the call's longest prompt has at least 768 rows ("tile_attn" = "k[,min_rows]"): measured on one layer of giga830M (profiles/r04o_attn64_probe.log)
   // 512 / 800 / 2048 causal rows: 14.3 / 24.6 / 86.7 us (first kernel) against 15.5 / 21.0 / 52.5 us (second).
   int tile_attn = 2, tile_attn_min_rows = 768;
-  int fr_split_rows = VC_FR_MAX_ROWS;   // option "fr_split_rows": passes of more rows run the attention unsplit (it normalises itself, plain out-projection prologue)
+  static constexpr int fr_split_rows = VC_FR_MAX_ROWS;   // finished-row passes of more rows run the attention unsplit (it normalises itself, plain out-projection prologue; unsplit from 5 rows measured +1.7..+4.5 %, r04j)
   // option "fr_one" (round 5): ONE-row steps - the FFN down-projection finishes its row (row_gemm_fr1_k: 8-channel tiles over the whole K,
   // two k-tiles per MFMA fragment, residual + bias added) instead of leaving 4 split-K slabs, so the next layer's QKV projection (and
   // heads-1) reads one 8 KB row instead of h + bias + 4 slabs = 40 KB in each of its 512 workgroups; 0 = off
@@ -126,18 +124,15 @@ struct vc_engine {
   int qkv_p8 = 1;
   // option "qkv16" (round 5): prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of the
   // folded matrix (every A lane of every MFMA a weight) instead of the 12-channel tiles one-row steps were tuned on; + 6 d^2 bytes per
-  // layer in bf16 (0.4 GB at giga830M).  VC_QKV16=0 at creation: not packed, the option stays off.
+  // layer in bf16 (0.4 GB at giga830M).  Packed for engines that can take wide steps (max_seqs > 16) or with VC_QKV16=1 at creation;
+  // otherwise the option stays off and prefill passes read the 12-channel tiles.
   int qkv16 = 1;
   // option "wide_heads" (round 5): decode steps of 17..64 rows run the prediction heads once on the weight-stationary kernel of those
   // steps (one LayerNorm launch + two rows_gemm_mt_k launches) instead of once per 16 rows on the rows-GEMM
   int wide_heads = 1;
-  // option "mt_tiles": weight tiles per workgroup of the wide-decode kernel (17..64-row steps): 2 (default since the end of round 5: twice the
-  // workgroups of 512 threads - every CU busy - measured -2.6 % per step at 32 rows and -3.0 % at 64, profiles/r05t_mt_tiles_ab.log; 4 tiles
-  // everywhere +4.2 %), 0 = by tile count (4 from 512 tiles on: the rule of rounds 2-4), 1 = two tiles from 33 rows on, 4 forced
-  int mt_tiles = 2;
   // option "wide_gemm" (round 6): the linear layers of 17..64-row steps on rows_gemm_wd_k (vc_gemm_wd.hip: every row tile of the step in
   // flight at once, X fragments straight from L2 into registers, one barrier per launch) instead of the weight-stationary
-  // rows_gemm_mt_k, which walks the row tiles one after the other; 0 = the round-2..5 kernel (its "mt_tiles" then applies)
+  // rows_gemm_mt_k, which walks the row tiles one after the other; 0 = that kernel (two weight tiles per workgroup)
   int wide_gemm = 1;
   // option "wd_stage": 1 (default) = that kernel takes X as whole cache lines through a wave-private LDS stage (rows_gemm_wds_k: 64 rows FFN-up
   // 13.5 -> 9.7 us, the 64-row step -9.5 % +- 0.01, 32 rows -2.7 %; profiles/r06c_*), 0 = MFMA fragments straight from L2 (16 half lines per request)
@@ -148,13 +143,10 @@ struct vc_engine {
   int shrink = 1;
   int cur_rows = 0;                     // rows per step the last decode loop ended on (tts_run reads the states back accordingly)
   int h_parts = 0;                      // split-K slabs the last pass left pending on hB (what the heads' LayerNorm has to sum)
-  // option "ln_trim": the LayerNorm prologue of slab-form passes requests only the slabs the pass has (0 behind a finished row / at
-  // layer 0, 2 behind the out-projection, 4 behind the slab-form FFN down-projection) instead of always 4
-  int ln_trim = 1;
   // option "attn_fast": decode attention with the wave's maximum taken before any exponential (no online rescaling inside a wave) and,
   // in bf16 mode, hardware exp2 (v_exp_f32) instead of expf
   int attn_fast = 1;
-  int attn_blocks_multi = 512, attn_blocks_one = 256;   // VC_ATTN_BLOCKS / VC_ATTN_BLOCKS1: attention workgroups aimed at (several rows / one row)
+  static constexpr int attn_blocks_multi = 512, attn_blocks_one = 256;   // attention workgroups aimed at (several rows / one row); 256 -> 64 at one row measured +1.1..+1.8 % (r05f)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
   float ms[3]{0, 0, 0};
@@ -313,8 +305,6 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7;            // head_dim is 32, 64 or 128 (vc_create)
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
-  g.ln_trim = e->ln_trim;
-  g.mt_ntw = (e->mt_tiles == 1 && rs.n_rows > 32) ? 2 : (e->mt_tiles == 2 || e->mt_tiles == 4) ? e->mt_tiles : 0;    // 1 = two tiles from 33 rows on
   g.wd_stage = e->wd_stage;
   return g;
 }
@@ -348,7 +338,7 @@ int fr_max_rows(const vc_engine* e) {
   while (r >= 2 && vc_gemm_fr_form(r, e->d, 4 * e->d, e->dtype, PRO_PLAIN, 1) == 0) --r;
   return r >= 2 ? r : 0;
 }
-bool lnw_two(const vc_engine* e, int rows) { return e->lnw_tiles == 2 || (e->lnw_tiles == 0 && rows >= 5) || rows > VC_FR_MAX_ROWS; }
+bool lnw_two(const vc_engine*, int rows) { return rows >= 5; }
 // splits of the decode attention in the finished-row form: the out-projection merges rows x splits <= 16 partials per thread in
 // one batch of loads; from 9 rows up the attention is unsplit (rows x heads >= 144 workgroups) and normalises itself
 int fr_nsplit(vc_engine* e, int rows) {
@@ -460,7 +450,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       if (fd && e->qkv_p8 && ly.Wqkv8 && !split_ln) {
         // the row entering the layer is finished (layer 0: the sampler's dec_h row): 8-channel tiles, two k-tiles per fragment
         g.Wp = ly.Wqkv8;
-        g.mt = e->qkv_p8 == 2 ? 8 : 0;
         HIPCHK(e, vc_launch_gemm_fr1(g, e->dtype, PRO_LN, EPI_QKV, s));
       } else if (split_ln) {   // several rows: LayerNorm once per row, then the plain-prologue GEMM
         g.x_out = e->xn;
@@ -996,32 +985,23 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   const int n = sscanf(value ? value : "", "%d,%d,%d", &v0, &v1, &v2);
   if (n < 1) return fail(e, VC_EINVAL, "option '%s': '%s' is not a number list", name.c_str(), value ? value : "(null)");
   if (name == "graph_steps") { e->steps_per_graph = std::max(1, std::min(64, v0));
-  } else if (name == "ln_split_rows") { e->ln_split_rows = std::max(2, v0);
-  } else if (name == "attn_blocks") { e->attn_blocks_multi = std::max(1, v0);
-  } else if (name == "attn_blocks1") { e->attn_blocks_one = std::max(1, v0);
   } else if (name == "tile_attn") {
     e->tile_attn = v0 == 2 ? 2 : 1;
     if (n >= 2) e->tile_attn_min_rows = std::max(64, v1);
-  } else if (name == "fr_split_rows") { e->fr_split_rows = std::max(1, std::min(v0, VC_FR_MAX_ROWS));
-  } else if (name == "lnw_tiles") { e->lnw_tiles = std::max(0, std::min(v0, 2));
   } else if (name == "finished_rows" || name == "fr_one") {
     if (v0 > 0 && !e->layers.empty() && !e->layers[0].W28)
       return fail(e, VC_ESTATE, "option '%s': this engine was created with VC_FINISHED_ROWS=0 and VC_FR_ONE=0 and holds no 8-channel weight images", name.c_str());
     if (name == "fr_one") e->fr_one = std::max(0, std::min(v0, 2));
     else e->fr_rows = std::max(0, std::min(v0, VC_ROWS));
   } else if (name == "fr_pair") { e->fr_pair = v0 ? 1 : 0;
-  } else if (name == "qkv_p8") { e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: eight waves per workgroup instead of four
-  } else if (name == "ln_trim") { e->ln_trim = v0 ? 1 : 0;
+  } else if (name == "qkv_p8") { e->qkv_p8 = v0 ? 1 : 0;
   } else if (name == "wide_heads") { e->wide_heads = v0 ? 1 : 0;
-  } else if (name == "mt_tiles") {
-    if (v0 != 0 && v0 != 1 && v0 != 2 && v0 != 4) return fail(e, VC_EINVAL, "option 'mt_tiles': 0 (by tile count), 1 (two tiles from 33 rows on), 2 or 4");
-    e->mt_tiles = v0;
   } else if (name == "wide_gemm") { e->wide_gemm = v0 ? 1 : 0;
   } else if (name == "shrink") { e->shrink = v0 ? 1 : 0;
   } else if (name == "wd_stage") { e->wd_stage = v0 ? 1 : 0;
   } else if (name == "qkv16") {
     if (v0 && !e->layers.empty() && !e->layers[0].Wqkv16)
-      return fail(e, VC_ESTATE, "option 'qkv16': this engine was created with VC_QKV16=0 and holds no 16-channel image of the QKV matrix");
+      return fail(e, VC_ESTATE, "option 'qkv16': this engine holds no 16-channel image of the QKV matrix (packed for max_seqs > 16, or with VC_QKV16=1 at creation)");
     e->qkv16 = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
@@ -1035,10 +1015,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "g=%d|ls=%d|ab=%d,%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d,%d|q16=%d,%d,%d,%d,%d|sh=%d",
-           e->steps_per_graph, e->ln_split_rows, e->attn_blocks_multi,
-           e->attn_blocks_one, e->nt_decode, e->attn_nt, e->fr_rows, e->lnw_tiles, e->fr_split_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->ln_trim, e->attn_fast, e->qkv_p8, e->qkv16, e->wide_heads, e->mt_tiles, e->wide_gemm, e->wd_stage, e->shrink);
+  snprintf(buf, sizeof buf, "g=%d|nt=%d,%d|fr=%d,%d|ta=%d,%d|r1=%d,%d,%d|q16=%d,%d,%d,%d|sh=%d",
+           e->steps_per_graph, e->nt_decode, e->attn_nt, e->fr_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
+           e->fr_one, e->attn_fast, e->qkv_p8, e->qkv16, e->wide_heads, e->wide_gemm, e->wd_stage, e->shrink);
   e->opt_state = buf;
 }
 
@@ -1208,8 +1187,11 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   const char* env_fr = getenv("VC_FINISHED_ROWS");
   const char* env_f1 = getenv("VC_FR_ONE");
   const bool want_fr8 = !(env_fr && atoi(env_fr) == 0 && env_f1 && atoi(env_f1) == 0);
+  // the 16-channel image of the QKV matrix serves wide decode steps (17..64 rows) and prefill passes: packed for engines that can
+  // take such steps (max_seqs > 16) or on request (VC_QKV16=1); a narrower engine runs its prefill on the 12-channel tiles (-0.4 GB)
   const char* env_q16 = getenv("VC_QKV16");
-  const bool want_qkv16 = !(env_q16 && atoi(env_q16) == 0);
+  const bool want_qkv16 = env_q16 ? atoi(env_q16) != 0 : e->B_max > VC_ROWS;
+  if (!want_qkv16) e->qkv16 = 0;
   e->layers.resize(L);
   for (int l = 0; l < L; ++l) {
     const std::string pre = "decoder.layers." + std::to_string(l) + ".";
@@ -1351,12 +1333,12 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   // a blocking stream: implicitly ordered after work the caller queued on the null stream
   HIPCHK(e, hipStreamCreate(&e->own_stream));
   // ---- options: the VC_* environment variables preset them, vc_set_option changes them at run time
-  for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), std::make_pair("VC_LN_SPLIT_ROWS", "ln_split_rows"),
+  for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), 
                          std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
-                         std::make_pair("VC_ATTN_BLOCKS", "attn_blocks"), std::make_pair("VC_ATTN_BLOCKS1", "attn_blocks1"),
+                         
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
-                         std::make_pair("VC_LNW_TILES", "lnw_tiles"), std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_MT_TILES", "mt_tiles"), std::make_pair("VC_LN_TRIM", "ln_trim"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_TILE_ATTN", "tile_attn"),
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -1971,7 +1953,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
     Layer& ly = e->layers[hot ? 0 : i % e->L];   // _hot: the same 8-34 MB every launch (cache-resident)
     const std::string& w = w2;
     const bool split_ln = n_rows >= e->ln_split_rows;   // the engine then normalises in ln_rows_k and takes the plain prologue
-    if (wide) {      // one linear layer of a 17..64-row step, in the form prefill_rows launches it there (options wide_gemm / mt_tiles / qkv16)
+    if (wide) {      // one linear layer of a 17..64-row step, in the form prefill_rows launches it there (options wide_gemm / wd_stage / qkv16)
       const bool wd = use_wd(e, n_rows);
       RowSrc rw = rs;
       rw.n_active = e->one; rw.nsplit = 1;

@@ -1078,7 +1078,7 @@ int vc_gemm_fr1_ok(int N, int K, int dtype, int nw) {
 hipError_t vc_launch_gemm_fr1(const GemmArgs& a0, int dtype, int pro, int epi, hipStream_t s) {
   const bool qkv = pro == PRO_LN && epi == EPI_QKV;
   if (!qkv && !(pro == PRO_PLAIN && epi == EPI_RES)) return hipErrorInvalidValue;
-  const int nw = (qkv && a0.mt != 8) ? 4 : VC_FR_WAVES;        // (GemmArgs.mt == 8: the QKV form with eight waves - the comparison arm of option qkv_p8 = 2)
+  const int nw = qkv ? 4 : VC_FR_WAVES;        // (the QKV form with eight waves measured +1.9 % per step, profiles/r05*: four stay)
   if (!vc_gemm_fr1_ok(a0.N, a0.K, dtype, nw) || a0.n_rows != 1) return hipErrorInvalidValue;
   GemmArgs a = a0;
   const int KW = dtype == VC_DTYPE_BF16 ? 32 : 16;
@@ -1088,7 +1088,6 @@ hipError_t vc_launch_gemm_fr1(const GemmArgs& a0, int dtype, int pro, int epi, h
   int cap = 1;
   while (cap < npw) cap <<= 1;
 #define VC_FR1_CASE(P_) case P_:                                                                                        \
-    if (qkv && nw == 8) return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, 8, PRO_LN, EPI_QKV>(a, s) : launch_fr1_n<float, P_, 8, PRO_LN, EPI_QKV>(a, s);   \
     if (qkv) return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, 4, PRO_LN, EPI_QKV>(a, s) : launch_fr1_n<float, P_, 4, PRO_LN, EPI_QKV>(a, s);   \
     return (dtype == VC_DTYPE_BF16) ? launch_fr1_n<bf16_t, P_, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s) : launch_fr1_n<float, P_, VC_FR_WAVES, PRO_PLAIN, EPI_RES>(a, s);
   switch (cap) {
@@ -1527,9 +1526,9 @@ static hipError_t launch_dec_nt(const GemmArgs& a, int dtype, int ksplit, int gr
 template <typename WT, int KTW, int PRO, int EPI, int NTW = 1>
 static hipError_t launch_dec(const GemmArgs& a, int dtype, int ksplit, int groups, hipStream_t s) {
   if constexpr (PRO == PRO_LN && NTW == 1) {
-    // slabs the LayerNorm prologue requests per row: as many as the pass really has (GemmArgs.ln_trim; the trimmed forms exist
-    // with the non-temporal weight stream only - the comparison arm nt = 0 keeps the four-slab form)
-    if (a.ln_trim && a.nt) {
+    // slabs the LayerNorm prologue requests per row: as many as the pass really has (round 5, -1.7..-2.8 % per one-row step; the
+    // trimmed forms exist with the non-temporal weight stream only - the comparison arm nt = 0 keeps the four-slab form)
+    if (a.nt) {
       if (a.n_parts == 0 && !a.has_prev_bias) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, 0>(a, dtype, ksplit, groups, s);
       if (a.n_parts <= 2) return launch_dec_nt<WT, KTW, PRO, EPI, NTW, true, false, 2>(a, dtype, ksplit, groups, s);
     }
@@ -1571,8 +1570,8 @@ static hipError_t launch_mt(const GemmArgs& a, int dtype, int ksplit, int groups
   if constexpr (PRO == PRO_LN) {
     return hipErrorInvalidValue;       // multi-tile passes take their LayerNorm from ln_rows_k
   } else {
-    // 4 weight tiles per workgroup when that still leaves >= 128 workgroups, else 2
-    if (a.mt_ntw == 4 || (a.mt_ntw == 0 && (long)a.n_tiles * ksplit * groups >= 512)) return launch_mt_n<WT, KTW, PRO, EPI, 4>(a, dtype, ksplit, groups, s);
+    // two weight tiles per workgroup: twice the workgroups of the four-tile form of rounds 2-4 - every CU busy (-2.6 % / -3.0 % per
+    // step at 32 / 64 rows, profiles/r05t_mt_tiles_ab.log; the four-tile form left the tree in round 6)
     return launch_mt_n<WT, KTW, PRO, EPI, 2>(a, dtype, ksplit, groups, s);
   }
 }
