@@ -245,7 +245,8 @@ int vc_debug_plan(const vc_model_cfg* cfg, int compute_dtype, int rows, int32_t 
 /* Copies a named internal device buffer to host memory. */
 int vc_debug_read(vc_engine* e, const char* name, void* host_dst, int64_t nbytes);
 /* Timing of the last vc_tts/vc_edit call, measured with HIP events on `stream`:
- * ms[0] = prompt build + prefill, ms[1] = decode loop, ms[2] = whole call. */
+ * ms[0] = prompt build + prefill, ms[1] = decode loop, ms[2] = their sum.  The FIRST call of a shape / option state captures and
+ * instantiates its decode graphs before either timer starts (host time, in vc_debug_read "host_ms" [1] / [2]): neither figure holds it. */
 int vc_last_timing(const vc_engine* e, float ms[3]);
 /* Average duration in ms of ONE kernel of the decode step - `which` = "qkv" | "attn" | "oproj" | "ffn1" (the FFN up-projection: since
  * round 5 the longest launch of a one-row layer, the kernel bench.py's roofline object quotes) | "ffn2", "<name>_hot" (the same layer
