@@ -94,7 +94,7 @@ const char* vc_last_error(const vc_engine* e); /* e may be NULL: last vc_create 
 const char* vc_version(void);
 
 /* Run-time options of a finalized engine: launch-shape knobs of the decode step, the same ones the VC_* environment
- * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  Sixteen of them (round 6
+ * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  Fifteen of them (round 6
  * pruned the list: the prefetch roles and the knobs whose value every measurement had fixed are constants now).  name / value:
  *   "nt"           bit mask of the weight matrices streamed with the non-temporal hint (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down, 16 / 32
  *                  heads); "attn_nt" 0 / 1 / 2 = the decode attention's K/V loads never / always / from two rows per step
@@ -102,8 +102,6 @@ const char* vc_version(void);
  *                  "fr_pair" 1 = its FFN down-projection with two k-tiles per MFMA fragment at 2..8 rows
  *   "fr_one"       ONE-row steps: 1 (default) = the FFN down-projection finishes its row (no split-K slabs), 0 = off;  "qkv_p8" 1 = the
  *                  one-row QKV projection in the same paired form;  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
- *   "attn_pipe"    rows up to which the decode attention of a several-row step walks its cached positions software-pipelined (the next batch of
- *                  K/V rows is requested while the current one is multiplied): 16 (default; 1 means the same), 0 = never; the same values in the same order
  *   "tile_attn"    "k[,min_rows]"  prefill attention kernel (1: 16 query rows per wave; 2: 64 per workgroup, P in registers - bf16,
  *                  head_dim 128, calls whose longest prompt has at least min_rows rows)
  *   "qkv16"        1 = prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of the folded matrix
@@ -119,7 +117,7 @@ const char* vc_version(void);
  * What an option may change: nothing in the exact fp32 mode's greedy tokens (tests/test_gpu_options.py, test_gpu_one_row.py); in bf16
  * mode the forms that re-order sums or round at another place ("finished_rows", "fr_pair", "fr_one", "qkv_p8", "attn_fast", "qkv16",
  * "wide_heads", "wide_gemm") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can differ between option
- * states; the cache-policy / data-path / host-side options ("nt", "attn_nt", "attn_pipe", "wd_stage", "graph_steps", "shrink") change no value.
+ * states; the cache-policy / data-path / host-side options ("nt", "attn_nt", "wd_stage", "graph_steps", "shrink") change no value.
  * The non-temporal mask "nt" has no bit for the finished-row producers (rows_gemm_fr_k, rows_gemm_fr2_k, row_gemm_fr1_k) and the
  * wide-decode kernels: they always stream with the hint.  Captured decode graphs are kept per option state and step width, so an
  * in-process A/B (bench.py --ab) pays for capture once per state.  Unknown names / malformed values: VC_EINVAL.

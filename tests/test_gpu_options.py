@@ -47,10 +47,9 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256, use_graph=False)
     L = a.num_decoder_layers
     got = {}
-    for mode in ("on", "nopipe", "unpaired", "off"):   # on: the default; nopipe: the decode attention without its software pipeline; unpaired: round 4's FFN-down producer; off: split-K slabs + LayerNorm launches
+    for mode in ("on", "unpaired", "off"):   # on: the default; unpaired: round 4's FFN-down producer; off: split-K slabs + LayerNorm launches
         eng.set_option("finished_rows", 0 if mode == "off" else 16)
         eng.set_option("fr_pair", 0 if mode == "unpaired" else 1)
-        eng.set_option("attn_pipe", 0 if mode == "nopipe" else 1)
         assert ("|fr=0," if mode == "off" else "|fr=16,") in eng.options()
         c0 = eng.launch_counts()
         outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3,
@@ -73,7 +72,6 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
         assert worst <= 2e-2, (mode, worst)
         got[mode] = lg
     assert np.abs(got["on"] - got["off"])[np.abs(got["off"]) < 1e3].max() < 0.25      # two roundings of the same numbers
-    assert np.array_equal(got["on"], got["nopipe"])            # the pipelined walk multiplies the same batches in the same order
     assert np.abs(got["on"] - got["unpaired"])[np.abs(got["off"]) < 1e3].max() < 0.25    # paired / unpaired producer: another order of the same sums
 
 

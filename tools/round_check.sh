@@ -27,6 +27,6 @@ python tools/pmc_to_json.py $O/${TAG}_fetch_pmc.txt $O/pmc_traffic.json > /dev/n
 if [ "${SHORT:-0}" = "1" ]; then exit 0; fi      # SHORT=1: suite + smoke + bench + the two profiles only
 echo "== in-kernel stamps"; timeout 200 python tools/kernel_ts.py giga830M 1 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_kernel_stamps_giga830M.log
 echo "== giga330M"; timeout 300 python tools/ab_sweep.py --preset giga330M fr_one=0:1 qkv_p8=0:1 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_330M.log
-echo "== 8 rows"; timeout 300 python tools/ab_sweep.py --batch 8 fr_pair=0:1 finished_rows=0:16 attn_pipe=0:16 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_b8.log
+echo "== 8 rows"; timeout 300 python tools/ab_sweep.py --batch 8 fr_pair=0:1 finished_rows=0:16 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_ab_b8.log
 echo "== wide steps"; timeout 300 python tools/wd_probe.py 2>&1 | grep -v amdgpu.ids | tee $O/${TAG}_wd_probe.log
 bash tools/prof_decode.sh ${TAG}_b8 --batch 8 --no-codec --ab none; head -12 $O/${TAG}_b8_rocprof_kernel_stats.txt

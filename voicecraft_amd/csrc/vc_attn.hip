@@ -42,12 +42,7 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 // maximum: no rescaling per visit (one per batch of 4), and the position groups of a wave merge by plain additions (no
 // exponentials, no multiplies).  In bf16 mode the exponentials are hardware exp2 (v_exp_f32, q pre-scaled by log2 e; the exported
 // maximum is converted back to natural units for the out-projection's merge); the exact fp32 mode keeps expf.
-// PIPE (round 6; several-row steps): the walk over a workgroup's positions is software-pipelined - the K/V rows of the batch AFTER the one
-// being multiplied are already requested (two register sets, the loop unrolled by two) - instead of request -> wait -> multiply per
-// batch.  A one-row step gives every workgroup a single batch (884 positions / 8 splits < 128 per batch) and keeps the plain form; a
-// workgroup of an 8-row step walks 4 batches, of a 16-row step 7, and with one or two workgroups per CU nothing else covers the round
-// trips.  Same values in the same order.
-template <typename WT, bool NT, bool FAST, bool PIPE>
+template <typename WT, bool NT, bool FAST>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
   constexpr int EPL = WTr<WT>::EPL;
   constexpr int NW = VC_ATT_WAVES;
@@ -106,28 +101,25 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
     }
     uint4 ku[4], vu[4];
     int pp[4];
-    uint4 ku2[4], vu2[4];                    // PIPE: the second register set
-    int pp2[4];
     // (the general form - refills of long chunks, calls with a shared text prefix - computes its per-lane 64-bit bases where it is
     // used: hoisted in front of the first batch they would sit in front of the lean path too)
-#define VC_KV_LOADS_TO(pb_, KU_, VU_, PP_)                                   \
+#define VC_KV_LOADS(pb_)                                                     \
     const long own = (long)seq * a.cache_seq_stride;      /* positions below `share` live in sequence 0's cache */ \
     const long base = own + (long)h * a.S_max * hd + li * EPL;               \
     const WT* kb = reinterpret_cast<const WT*>(a.kcache) + base;             \
     const WT* vb = reinterpret_cast<const WT*>(a.vcache) + base;             \
     _Pragma("unroll") for (int it = 0; it < 4; ++it) {                       \
-      PP_[it] = (pb_) + (it * NW + wave) * PPW + sub;                        \
-      const long pc = max(min(PP_[it], p1 - 1), 0);                          \
+      pp[it] = (pb_) + (it * NW + wave) * PPW + sub;                         \
+      const long pc = max(min(pp[it], p1 - 1), 0);                           \
       const long po = pc * hd - ((pc < share) ? own : 0);                    \
       if constexpr (NT) {                                                    \
-        KU_[it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + po))); \
-        VU_[it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + po))); \
+        ku[it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(kb + po))); \
+        vu[it] = __builtin_bit_cast(uint4, __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(vb + po))); \
       } else {                                                               \
-        KU_[it] = *reinterpret_cast<const uint4*>(kb + po);                  \
-        VU_[it] = *reinterpret_cast<const uint4*>(vb + po);                  \
+        ku[it] = *reinterpret_cast<const uint4*>(kb + po);                   \
+        vu[it] = *reinterpret_cast<const uint4*>(vb + po);                   \
       }                                                                      \
     }
-#define VC_KV_LOADS(pb_) VC_KV_LOADS_TO(pb_, ku, vu, pp)
     // The FIRST batch - the one every launch waits for - from a wave-uniform base and one 32-bit offset per lane when no prefix is
     // shared (every call but the sentence-chained ones): scalar-base addressing, no 64-bit vector arithmetic, no select per visit.
     // (In-kernel stamps of the first round-5 build: 2 956 clk from "position known" to "loads issued" - the address code in front of
@@ -162,134 +154,63 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
       q[4 * j + 2] = qv[j].z * qs; q[4 * j + 3] = qv[j].w * qs;
     }
     VC_KTS(3);
-    if constexpr (!PIPE) {      // (the form of rounds 1-5, untouched: one-row steps and wide steps run it)
-      for (int pb = p0;;) {
-        if constexpr (FAST) {
-          float sc[4];
-  #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            float kf[EPL];
-            unpack16<WT>(ku[it], kf);
-            float t = 0.f;
-  #pragma unroll
-            for (int j = 0; j < EPL; ++j) t += q[j] * kf[j];
-            if (LPR == 4) t = quad_sum(t);
-            else if (LPR == 8) t = half_row_sum(t);
-            else { t = row_sum(t); if (LPR == 32) t += __shfl_xor(t, 16, 64); }
-            sc[it] = (pp[it] < p1) ? t : -INFINITY;
-          }
-          const float mn = fmaxf(m, wave_max(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]))));    // wave-uniform
-          if (mn > -INFINITY) {
-            const float corr = ex(m - mn);             // m = -inf before the first valid position -> 0
-            float pw[4];
-  #pragma unroll
-            for (int it = 0; it < 4; ++it) pw[it] = ex(sc[it] - mn);    // -inf (beyond the chunk) -> 0
-            l = l * corr + ((pw[0] + pw[1]) + (pw[2] + pw[3]));
-            float vf[4][EPL];
-  #pragma unroll
-            for (int it = 0; it < 4; ++it) unpack16<WT>(vu[it], vf[it]);
-  #pragma unroll
-            for (int j = 0; j < EPL; ++j)
-              o[j] = o[j] * corr + ((pw[0] * vf[0][j] + pw[1] * vf[1][j]) + (pw[2] * vf[2][j] + pw[3] * vf[3][j]));
-            m = mn;
-          }
-        } else {
-  #pragma unroll
+    for (int pb = p0;;) {
+      if constexpr (FAST) {
+        float sc[4];
+#pragma unroll
         for (int it = 0; it < 4; ++it) {
-          float kf[EPL], vf[EPL];
+          float kf[EPL];
           unpack16<WT>(ku[it], kf);
-          unpack16<WT>(vu[it], vf);
-          float sc = 0.f;
-  #pragma unroll
-          for (int j = 0; j < EPL; ++j) sc += q[j] * kf[j];
-          if (LPR == 4) sc = quad_sum(sc);
-          else if (LPR == 8) sc = half_row_sum(sc);
-          else { sc = row_sum(sc); if (LPR == 32) sc += __shfl_xor(sc, 16, 64); }
-          if (pp[it] < p1) {
-            const float mn = fmaxf(m, sc);
-            const float corr = expf(m - mn);     // m = -inf on the first visit -> 0
-            const float pe = expf(sc - mn);
-            l = l * corr + pe;
-  #pragma unroll
-            for (int j = 0; j < EPL; ++j) o[j] = o[j] * corr + pe * vf[j];
-            m = mn;
-          }
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) t += q[j] * kf[j];
+          if (LPR == 4) t = quad_sum(t);
+          else if (LPR == 8) t = half_row_sum(t);
+          else { t = row_sum(t); if (LPR == 32) t += __shfl_xor(t, 16, 64); }
+          sc[it] = (pp[it] < p1) ? t : -INFINITY;
         }
+        const float mn = fmaxf(m, wave_max(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]))));    // wave-uniform
+        if (mn > -INFINITY) {
+          const float corr = ex(m - mn);             // m = -inf before the first valid position -> 0
+          float pw[4];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) pw[it] = ex(sc[it] - mn);    // -inf (beyond the chunk) -> 0
+          l = l * corr + ((pw[0] + pw[1]) + (pw[2] + pw[3]));
+          float vf[4][EPL];
+#pragma unroll
+          for (int it = 0; it < 4; ++it) unpack16<WT>(vu[it], vf[it]);
+#pragma unroll
+          for (int j = 0; j < EPL; ++j)
+            o[j] = o[j] * corr + ((pw[0] * vf[0][j] + pw[1] * vf[1][j]) + (pw[2] * vf[2][j] + pw[3] * vf[3][j]));
+          m = mn;
         }
-        pb += step;
-        if (pb >= p1) break;
-        { VC_KV_LOADS(pb) }
+      } else {
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        float kf[EPL], vf[EPL];
+        unpack16<WT>(ku[it], kf);
+        unpack16<WT>(vu[it], vf);
+        float sc = 0.f;
+#pragma unroll
+        for (int j = 0; j < EPL; ++j) sc += q[j] * kf[j];
+        if (LPR == 4) sc = quad_sum(sc);
+        else if (LPR == 8) sc = half_row_sum(sc);
+        else { sc = row_sum(sc); if (LPR == 32) sc += __shfl_xor(sc, 16, 64); }
+        if (pp[it] < p1) {
+          const float mn = fmaxf(m, sc);
+          const float corr = expf(m - mn);     // m = -inf on the first visit -> 0
+          const float pe = expf(sc - mn);
+          l = l * corr + pe;
+#pragma unroll
+          for (int j = 0; j < EPL; ++j) o[j] = o[j] * corr + pe * vf[j];
+          m = mn;
+        }
       }
-    } else {
-      // one batch of 4 x 8 x PPW positions: scores, running maximum, weighted V
-      auto att_batch = [&](const uint4 (&KU_)[4], const uint4 (&VU_)[4], const int (&PP_)[4]) __attribute__((always_inline)) {
-        if constexpr (FAST) {
-          float sc[4];
-  #pragma unroll
-          for (int it = 0; it < 4; ++it) {
-            float kf[EPL];
-            unpack16<WT>(KU_[it], kf);
-            float t = 0.f;
-  #pragma unroll
-            for (int j = 0; j < EPL; ++j) t += q[j] * kf[j];
-            if (LPR == 4) t = quad_sum(t);
-            else if (LPR == 8) t = half_row_sum(t);
-            else { t = row_sum(t); if (LPR == 32) t += __shfl_xor(t, 16, 64); }
-            sc[it] = (PP_[it] < p1) ? t : -INFINITY;
-          }
-          const float mn = fmaxf(m, wave_max(fmaxf(fmaxf(sc[0], sc[1]), fmaxf(sc[2], sc[3]))));    // wave-uniform
-          if (mn > -INFINITY) {
-            const float corr = ex(m - mn);             // m = -inf before the first valid position -> 0
-            float pw[4];
-  #pragma unroll
-            for (int it = 0; it < 4; ++it) pw[it] = ex(sc[it] - mn);    // -inf (beyond the chunk) -> 0
-            l = l * corr + ((pw[0] + pw[1]) + (pw[2] + pw[3]));
-            float vf[4][EPL];
-  #pragma unroll
-            for (int it = 0; it < 4; ++it) unpack16<WT>(VU_[it], vf[it]);
-  #pragma unroll
-            for (int j = 0; j < EPL; ++j)
-              o[j] = o[j] * corr + ((pw[0] * vf[0][j] + pw[1] * vf[1][j]) + (pw[2] * vf[2][j] + pw[3] * vf[3][j]));
-            m = mn;
-          }
-        } else {
-  #pragma unroll
-        for (int it = 0; it < 4; ++it) {
-          float kf[EPL], vf[EPL];
-          unpack16<WT>(KU_[it], kf);
-          unpack16<WT>(VU_[it], vf);
-          float sc = 0.f;
-  #pragma unroll
-          for (int j = 0; j < EPL; ++j) sc += q[j] * kf[j];
-          if (LPR == 4) sc = quad_sum(sc);
-          else if (LPR == 8) sc = half_row_sum(sc);
-          else { sc = row_sum(sc); if (LPR == 32) sc += __shfl_xor(sc, 16, 64); }
-          if (PP_[it] < p1) {
-            const float mn = fmaxf(m, sc);
-            const float corr = expf(m - mn);     // m = -inf on the first visit -> 0
-            const float pe = expf(sc - mn);
-            l = l * corr + pe;
-  #pragma unroll
-            for (int j = 0; j < EPL; ++j) o[j] = o[j] * corr + pe * vf[j];
-            m = mn;
-          }
-        }
-        }
-      };
-      // two register sets: while one batch is multiplied the next one's rows are on their way
-      if (p0 + step < p1) { VC_KV_LOADS_TO(p0 + step, ku2, vu2, pp2) }
-      for (int pb = p0;;) {
-        att_batch(ku, vu, pp);
-        pb += step;
-        if (pb >= p1) break;
-        if (pb + step < p1) { VC_KV_LOADS(pb + step) }
-        att_batch(ku2, vu2, pp2);
-        pb += step;
-        if (pb >= p1) break;
-        if (pb + step < p1) { VC_KV_LOADS_TO(pb + step, ku2, vu2, pp2) }
       }
+      pb += step;
+      if (pb >= p1) break;
+      { VC_KV_LOADS(pb) }
     }
-#undef VC_KV_LOADS_TO
 #undef VC_KV_LOADS
     VC_KTS(4);
   }
@@ -352,8 +273,7 @@ hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_
   ++vc_launch_counts[VC_LC_ROWS_ATTN];
   AttnArgs b = a;
   b.inv_nsplit = nextafterf(1.0f / (float)a.nsplit, 2.0f);
-#define VC_ATTN_GO(WT_, NT_, F_) { if (a.pipe) hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b); \
-                                   else hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_, false>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b); }
+#define VC_ATTN_GO(WT_, NT_, F_) hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b);
   if (dtype == VC_DTYPE_BF16) {
     if (a.fast) { if (a.nt) VC_ATTN_GO(bf16_t, true, true) else VC_ATTN_GO(bf16_t, false, true) }
     else { if (a.nt) VC_ATTN_GO(bf16_t, true, false) else VC_ATTN_GO(bf16_t, false, false) }

@@ -277,7 +277,6 @@ struct AttnArgs {
   long long* dbg_ts;        // diagnostic builds only
   int nt;                   // rows_attn_k: K/V rows requested with the non-temporal hint
   int fast;                 // rows_attn_k: 1 = the round-5 form (wave maximum before any exponential; bf16 mode: hardware exp2)
-  int pipe;                 // rows_attn_k: 1 = the software-pipelined walk (two register sets; several-row steps)
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence

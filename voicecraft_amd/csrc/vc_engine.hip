@@ -146,10 +146,6 @@ struct vc_engine {
   // option "attn_fast": decode attention with the wave's maximum taken before any exponential (no online rescaling inside a wave) and,
   // in bf16 mode, hardware exp2 (v_exp_f32) instead of expf
   int attn_fast = 1;
-  // option "attn_pipe" (round 6): the decode attention of 2..16-row steps walks its positions software-pipelined (the next batch of K/V rows
-  // requested while the current one is multiplied: rows_attn_k<..., PIPE>); one-row steps have a single batch per workgroup, wide steps
-  // (17..64 rows) put four workgroups on a CU and keep the lighter form (148 instead of 77-84 registers)
-  int attn_pipe = VC_ROWS;              // rows up to which the pipelined form is taken (0 = never)
   static constexpr int attn_blocks_multi = 512, attn_blocks_one = 256;   // attention workgroups aimed at (several rows / one row); 256 -> 64 at one row measured +1.1..+1.8 % (r05f)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
@@ -382,7 +378,6 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
       a.fast = e->attn_fast;
-      a.pipe = (a.n_rows >= 2 && a.n_rows <= e->attn_pipe) ? 1 : 0;
       if (rs.nsplit == 1) a.x_out = e->xn;        // unsplit (9..16 rows): the workgroup saw every position and normalises itself
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -477,7 +472,6 @@ int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
       a.fast = e->attn_fast;
-      a.pipe = (a.n_rows >= 2 && a.n_rows <= e->attn_pipe) ? 1 : 0;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
     {  // out-projection of the merged attention output -> split-K partial slabs
@@ -670,7 +664,6 @@ int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.n_active = rs.n_active ? rs.n_active : e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len;
       a.nt = rs.n_active != nullptr ? attn_nt_for(e, rs.n_rows) : 0;      // wide decode passes stream their K/V once, prefill passes re-read it
       a.fast = e->attn_fast;
-      a.pipe = (a.n_rows >= 2 && a.n_rows <= e->attn_pipe) ? 1 : 0;
       if (rs.nsplit == 1) a.x_out = e->xn;    // xn is free between the QKV GEMM and the FFN LayerNorm
       if (rs.tiled == 2 && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn64(a, s));
       else if (rs.tiled && rs.nsplit == 1) HIPCHK(e, vc_launch_tile_attn(a, e->dtype, s));
@@ -1014,7 +1007,6 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
       return fail(e, VC_ESTATE, "option 'qkv16': this engine holds no 16-channel image of the QKV matrix (packed for max_seqs > 16, or with VC_QKV16=1 at creation)");
     e->qkv16 = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
-  } else if (name == "attn_pipe") { e->attn_pipe = v0 == 1 ? VC_ROWS : std::max(0, std::min(v0, VC_MAX_SEQS));      // 1 = the default (16 rows)
   } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
@@ -1026,9 +1018,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "g=%d|nt=%d,%d|fr=%d,%d|ta=%d,%d|r1=%d,%d,%d|ap=%d|q16=%d,%d,%d,%d|sh=%d",
+  snprintf(buf, sizeof buf, "g=%d|nt=%d,%d|fr=%d,%d|ta=%d,%d|r1=%d,%d,%d|q16=%d,%d,%d,%d|sh=%d",
            e->steps_per_graph, e->nt_decode, e->attn_nt, e->fr_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
-           e->fr_one, e->attn_fast, e->qkv_p8, e->attn_pipe, e->qkv16, e->wide_heads, e->wide_gemm, e->wd_stage, e->shrink);
+           e->fr_one, e->attn_fast, e->qkv_p8, e->qkv16, e->wide_heads, e->wide_gemm, e->wd_stage, e->shrink);
   e->opt_state = buf;
 }
 
@@ -1352,7 +1344,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_ATTN_FAST", "attn_fast"), std::make_pair("VC_ATTN_PIPE", "attn_pipe")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -2017,7 +2009,6 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
         a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
         a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = attn_nt_for(e, n_rows); a.x_out = e->xn;
         a.fast = e->attn_fast;
-        a.pipe = (a.n_rows >= 2 && a.n_rows <= e->attn_pipe) ? 1 : 0;
         HIPCHK(e, vc_launch_attn(a, e->dtype, n_rows, s));
       } else {
         return fail(e, VC_EINVAL, "unknown kernel '%s'", which);
@@ -2087,7 +2078,6 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = attn_nt_for(e, rs.n_rows);
       a.fast = e->attn_fast;
-      a.pipe = (a.n_rows >= 2 && a.n_rows <= e->attn_pipe) ? 1 : 0;
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "pf_ffn1") {      // the prefill pass's FFN up-projection on the MFMA block GEMM (X = xn, n_rows rows)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
