@@ -47,9 +47,10 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256, use_graph=False)
     L = a.num_decoder_layers
     got = {}
-    for mode in ("on", "unpaired", "off"):   # on: the default; unpaired: round 4's FFN-down producer; off: split-K slabs + LayerNorm launches
+    for mode in ("on", "p32", "unpaired", "off"):   # on: the default; p32: fp32 attention partials (rounds 4-5); unpaired: round 4's FFN-down producer; off: split-K slabs + LayerNorm launches
         eng.set_option("finished_rows", 0 if mode == "off" else 16)
         eng.set_option("fr_pair", 0 if mode == "unpaired" else 1)
+        eng.set_option("att_p16", 0 if mode == "p32" else 1)
         assert ("|fr=0," if mode == "off" else "|fr=16,") in eng.options()
         c0 = eng.launch_counts()
         outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3,
@@ -72,6 +73,9 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
         assert worst <= 2e-2, (mode, worst)
         got[mode] = lg
     assert np.abs(got["on"] - got["off"])[np.abs(got["off"]) < 1e3].max() < 0.25      # two roundings of the same numbers
+    assert np.abs(got["on"] - got["p32"])[np.abs(got["off"]) < 1e3].max() < 0.25      # bf16 / fp32 attention partials (the same up to 8 rows; identical beyond: unsplit)
+    if B > 8:
+        assert np.array_equal(got["on"], got["p32"])
     assert np.abs(got["on"] - got["unpaired"])[np.abs(got["off"]) < 1e3].max() < 0.25    # paired / unpaired producer: another order of the same sums
 
 

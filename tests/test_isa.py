@@ -79,7 +79,7 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
         assert body.count("v_mfma_f32_16x16x32_bf16") >= 2 and " nt" in body, name     # non-temporal weight stream
     # finished-row form (2..16-row decode steps): the FFN down-projection streams a wave's whole share (32 fragments) in ONE burst
     # of non-temporal loads, 512 threads at <= 256 registers; the consumers with two tiles per workgroup are 512-thread kernels
-    for name, (body, _, vgpr) in pick(kern, "rows_gemm_fr_k<bf16_t, 32, 1, 1>").items():
+    for name, (body, _, vgpr) in pick(kern, "rows_gemm_fr_k<bf16_t, 32, 1, 1, false>").items():
         assert body.count("global_load_dwordx4") >= 32 + 16 and body.count(" nt") >= 32 and body.count("v_mfma_f32_16x16x32_bf16") == 32, name
         assert vgpr <= 256, (name, vgpr)
     for name, (body, _, vgpr) in pick(kern, "rows_gemm_fr2_k<bf16_t, 16>").items():      # 9..16 rows: both halves' fragments up front

@@ -42,8 +42,13 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 // maximum: no rescaling per visit (one per batch of 4), and the position groups of a wave merge by plain additions (no
 // exponentials, no multiplies).  In bf16 mode the exponentials are hardware exp2 (v_exp_f32, q pre-scaled by log2 e; the exported
 // maximum is converted back to natural units for the out-projection's merge); the exact fp32 mode keeps expf.
-template <typename WT, bool NT, bool FAST>
+// P16 (round 6; bf16 mode, split passes of 2..8 rows): the un-normalised partial acc[hd] leaves as bf16 instead of fp32 - the
+// finished-row out-projection re-reads every head's partials in each of its 256 workgroups (rows x heads x splits x hd values: 131 KB
+// per workgroup at 8 rows, four times its weights), and those bytes go through the CU's vector-memory path like any others; the merged
+// row is rounded to bf16 for the MFMA anyway.  (max, sum) stay fp32.
+template <typename WT, bool NT, bool FAST, bool P16 = false>
 __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs a) {
+  static_assert(!P16 || sizeof(WT) == 2, "bf16 partials: bf16 mode only");
   constexpr int EPL = WTr<WT>::EPL;
   constexpr int NW = VC_ATT_WAVES;
   constexpr bool X2 = sizeof(WT) == 2;        // FAST: base-2 exponentials in bf16 mode
@@ -260,7 +265,8 @@ __global__ __launch_bounds__(64 * VC_ATT_WAVES) void rows_attn_k(const AttnArgs 
       WTr<WT>::st(reinterpret_cast<WT*>(a.x_out) + (long)r * a.d + h * hd + tid, (L > 0.f) ? O / L : 0.f);
     } else {
       const long pi = ((long)(r * a.H + h) * a.nsplit + sp);
-      a.att_o[pi * hd + tid] = O;
+      if constexpr (P16) reinterpret_cast<uint16_t*>(a.att_o)[pi * hd + tid] = f32_to_bf16(O);
+      else a.att_o[pi * hd + tid] = O;
       if (tid == 0) { a.att_ml[pi * 2] = M; a.att_ml[pi * 2 + 1] = L; }
     }
   }
@@ -274,6 +280,13 @@ hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_
   AttnArgs b = a;
   b.inv_nsplit = nextafterf(1.0f / (float)a.nsplit, 2.0f);
 #define VC_ATTN_GO(WT_, NT_, F_) hipLaunchKernelGGL((rows_attn_k<WT_, NT_, F_>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b);
+  if (dtype == VC_DTYPE_BF16 && a.part16 && !a.x_out) {      // bf16 partials (finished-row passes of 2..8 rows whose attention is split)
+    if (a.fast) { if (a.nt) hipLaunchKernelGGL((rows_attn_k<bf16_t, true, true, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b);
+                  else hipLaunchKernelGGL((rows_attn_k<bf16_t, false, true, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b); }
+    else { if (a.nt) hipLaunchKernelGGL((rows_attn_k<bf16_t, true, false, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b);
+           else hipLaunchKernelGGL((rows_attn_k<bf16_t, false, false, true>), grid, dim3(64 * VC_ATT_WAVES), 0, s, b); }
+    return hipGetLastError();
+  }
   if (dtype == VC_DTYPE_BF16) {
     if (a.fast) { if (a.nt) VC_ATTN_GO(bf16_t, true, true) else VC_ATTN_GO(bf16_t, false, true) }
     else { if (a.nt) VC_ATTN_GO(bf16_t, true, false) else VC_ATTN_GO(bf16_t, false, false) }

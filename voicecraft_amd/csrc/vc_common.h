@@ -237,7 +237,8 @@ struct GemmArgs {
   int x_group_stride;
   int x_upr_shift;          // log2 of the 16-byte units per X row slice when that is a power of two, else -1 (set by the launcher)
   // prologue ATT: X = combine of attention split partials
-  const float* att_o;       // [VC_ROWS][H][nsplit][hd]
+  const float* att_o;       // [VC_ROWS][H][nsplit][hd] (fp32; bf16 when att_p16)
+  int att_p16;              // rows_gemm_fr_k<PRO_ATT>, bf16 mode: the partials are bf16 (AttnArgs.part16 of the attention launch in front)
   const float* att_ml;      // [VC_ROWS][H][nsplit][2]
   int nsplit, H, hd;
   int hd_shift;             // log2(hd): head_dim is a power of two (vc_create), so head / element of a channel are a shift and a mask
@@ -277,6 +278,7 @@ struct AttnArgs {
   long long* dbg_ts;        // diagnostic builds only
   int nt;                   // rows_attn_k: K/V rows requested with the non-temporal hint
   int fast;                 // rows_attn_k: 1 = the round-5 form (wave maximum before any exponential; bf16 mode: hardware exp2)
+  int part16;               // rows_attn_k (bf16 mode, split passes): 1 = the partial acc[hd] is written as bf16 (read by rows_gemm_fr_k<.., P16>)
 };
 
 struct Segment {            // one run of columns of the rearranged audio sequence

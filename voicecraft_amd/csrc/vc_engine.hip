@@ -146,6 +146,9 @@ struct vc_engine {
   // option "attn_fast": decode attention with the wave's maximum taken before any exponential (no online rescaling inside a wave) and,
   // in bf16 mode, hardware exp2 (v_exp_f32) instead of expf
   int attn_fast = 1;
+  // option "att_p16" (round 6; bf16 mode): finished-row passes of 2..8 rows hand the attention's split partials to the out-projection as
+  // bf16 (131 -> 66 KB per out-projection workgroup at 8 rows; the merged row is rounded to bf16 for the MFMA anyway)
+  int att_p16 = 1;
   static constexpr int attn_blocks_multi = 512, attn_blocks_one = 256;   // attention workgroups aimed at (several rows / one row); 256 -> 64 at one row measured +1.1..+1.8 % (r05f)
   int prefill_rows_per_pass = VC_MAX_ROWS;   // VC_PREFILL_ROWS=16 falls back to the decode kernels for the prompt
   hipEvent_t ev[3]{};
@@ -378,6 +381,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       a.att_o = e->att_o; a.att_ml = e->att_ml; a.share_len = e->share_len;
       a.nt = (rs.n_active != nullptr || rs.nt) ? attn_nt_for(e, rs.n_rows) : 0;
       a.fast = e->attn_fast;
+      a.part16 = (e->att_p16 && e->dtype == VC_DTYPE_BF16 && rs.nsplit > 1) ? 1 : 0;
       if (rs.nsplit == 1) a.x_out = e->xn;        // unsplit (9..16 rows): the workgroup saw every position and normalises itself
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     }
@@ -390,6 +394,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
         HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
       } else {
         g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = rs.nsplit;
+        g.att_p16 = (e->att_p16 && e->dtype == VC_DTYPE_BF16) ? 1 : 0;
         HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s));
       }
     }
@@ -1007,6 +1012,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
       return fail(e, VC_ESTATE, "option 'qkv16': this engine holds no 16-channel image of the QKV matrix (packed for max_seqs > 16, or with VC_QKV16=1 at creation)");
     e->qkv16 = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
+  } else if (name == "att_p16") { e->att_p16 = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
@@ -1018,8 +1024,8 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "g=%d|nt=%d,%d|fr=%d,%d|ta=%d,%d|r1=%d,%d,%d|q16=%d,%d,%d,%d|sh=%d",
-           e->steps_per_graph, e->nt_decode, e->attn_nt, e->fr_rows, e->fr_pair, e->tile_attn, e->tile_attn_min_rows,
+  snprintf(buf, sizeof buf, "g=%d|nt=%d,%d|fr=%d,%d,%d|ta=%d,%d|r1=%d,%d,%d|q16=%d,%d,%d,%d|sh=%d",
+           e->steps_per_graph, e->nt_decode, e->attn_nt, e->fr_rows, e->fr_pair, e->att_p16, e->tile_attn, e->tile_attn_min_rows,
            e->fr_one, e->attn_fast, e->qkv_p8, e->qkv16, e->wide_heads, e->wide_gemm, e->wd_stage, e->shrink);
   e->opt_state = buf;
 }
@@ -1344,7 +1350,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_ATTN_FAST", "attn_fast")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_ATTN_FAST", "attn_fast"), std::make_pair("VC_ATT_P16", "att_p16")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -2036,7 +2042,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
         GemmArgs g = base_args(e, rs, e->p_o, d, d);
         g.Wp = ly.Wo8; g.bias = ly.bo; g.h_in = e->hB; g.h_out = e->hA;
         if (fr_nsplit(e, n_rows) == 1) { g.x_in = e->xn; g.x_ld = d; HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s)); }
-        else { g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = fr_nsplit(e, n_rows); HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s)); }
+        else { g.att_o = e->att_o; g.att_ml = e->att_ml; g.nsplit = fr_nsplit(e, n_rows); g.att_p16 = (e->att_p16 && e->dtype == VC_DTYPE_BF16) ? 1 : 0; HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_ATT, s)); }
       }
       return VC_OK;
     }
@@ -2078,6 +2084,7 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
       a.row_seq = rs.row_seq; a.row_pos = rs.row_pos; a.n_rows = rs.n_rows; a.att_o = e->att_o; a.att_ml = e->att_ml;
       a.n_active = e->one; a.dbg_ts = e->dbg_ts; a.share_len = e->share_len; a.nt = attn_nt_for(e, rs.n_rows);
       a.fast = e->attn_fast;
+      a.part16 = (e->att_p16 && e->dtype == VC_DTYPE_BF16 && n_rows >= 2 && n_rows <= fr_max_rows(e) && rs.nsplit > 1) ? 1 : 0;    // as forward_rows_fr launches it
       HIPCHK(e, vc_launch_attn(a, e->dtype, rs.n_rows, s));
     } else if (w == "pf_ffn1") {      // the prefill pass's FFN up-projection on the MFMA block GEMM (X = xn, n_rows rows)
       GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);

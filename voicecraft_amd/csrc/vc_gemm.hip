@@ -536,8 +536,9 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
 // PRO_PLAIN: X = activations (FFN down); PRO_ATT: X = merge of the attention's split partials of ALL heads (out-projection;
 // NS = partials per item the loads are unrolled for, rows x NS <= 16 so that one batch of loads covers every item).
 // Bounded by rows x K x sizeof(WT) <= 128 KB of LDS: 8 rows in bf16, 4 in the exact fp32 mode.
-template <typename WT, int KTW, int PRO, int NS>
+template <typename WT, int KTW, int PRO, int NS, bool P16 = false>
 __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr_k(const GemmArgs a) {
+  static_assert(!P16 || (PRO == PRO_ATT && sizeof(WT) == 2), "bf16 attention partials: the merging out-projection in bf16 mode");
   using T = WTr<WT>;
   constexpr int NW = VC_FR_WAVES, NTHR = 64 * NW, TH = VC_TH_RES, SPT = 4 * TH;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -601,6 +602,63 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr_k(const GemmArg
     VC_FRX_STORE(12, x12) VC_FRX_STORE(13, x13) VC_FRX_STORE(14, x14) VC_FRX_STORE(15, x15)
 #undef VC_FRX_LOAD
 #undef VC_FRX_STORE
+  } else if constexpr (P16) {   // PRO_ATT on bf16 partials (round 6): item = (row, EIGHT columns of one head) - one 16-byte load per partial - NI items per thread
+    constexpr int NI = 8 / NS;
+    const int q8 = K >> 3;
+    const int n_items = n_rows * q8;              // <= NI * NTHR (rows x NS <= 16, K <= 2048: host contract)
+    const int qsh = a.att_q4_shift - 1;           // log2(K / 8) when K / 4 is a power of two, else < 0
+    float2 ml[NI][NS];
+    uint4 os[NI][NS];
+    int ir[NI], ic[NI];
+    bool on[NI];
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib) {
+      const int idx = ib * NTHR + tid;
+      on[ib] = idx < n_items;
+      const int i_ = on[ib] ? idx : 0;
+      ir[ib] = (a.att_q4_shift >= 1) ? (i_ >> qsh) : (i_ / q8);
+      ic[ib] = (i_ - ir[ib] * q8) * 8;
+      const int h_ = ic[ib] >> a.hd_shift, e_ = ic[ib] & (a.hd - 1);
+      const float2* mp = reinterpret_cast<const float2*>(a.att_ml) + (long)(ir[ib] * a.H + h_) * a.nsplit;
+      const uint16_t* op = reinterpret_cast<const uint16_t*>(a.att_o) + ((long)(ir[ib] * a.H + h_) * a.nsplit) * a.hd + e_;
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        const int se = (sp < a.nsplit) ? sp : 0;
+        ml[ib][sp] = mp[se];
+        os[ib][sp] = *reinterpret_cast<const uint4*>(op + (long)se * a.hd);
+      }
+    }
+    VC_FR_WEIGHTS(0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (active == 0) return;
+#pragma unroll
+    for (int ib = 0; ib < NI; ++ib) {
+      float M = -INFINITY;
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        ml[ib][sp].x = (sp < a.nsplit) ? ml[ib][sp].x : -INFINITY;
+        M = fmaxf(M, ml[ib][sp].x);
+      }
+      float L = 0.f;
+      float o[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+#pragma unroll
+      for (int sp = 0; sp < NS; ++sp) {
+        const float w = (ml[ib][sp].x == -INFINITY) ? 0.f : expf(ml[ib][sp].x - M);
+        L += w * ml[ib][sp].y;
+        const uint4 u = os[ib][sp];
+        o[0] += w * __uint_as_float(u.x << 16); o[1] += w * __uint_as_float(u.x & 0xffff0000u);
+        o[2] += w * __uint_as_float(u.y << 16); o[3] += w * __uint_as_float(u.y & 0xffff0000u);
+        o[4] += w * __uint_as_float(u.z << 16); o[5] += w * __uint_as_float(u.z & 0xffff0000u);
+        o[6] += w * __uint_as_float(u.w << 16); o[7] += w * __uint_as_float(u.w & 0xffff0000u);
+      }
+      const float inv = (L > 0.f) ? 1.0f / L : 0.f;
+      uint4 pk;
+      pk.x = pack_bf16x2(o[0] * inv, o[1] * inv); pk.y = pack_bf16x2(o[2] * inv, o[3] * inv);
+      pk.z = pack_bf16x2(o[4] * inv, o[5] * inv); pk.w = pack_bf16x2(o[6] * inv, o[7] * inv);
+      if (on[ib]) *reinterpret_cast<uint4*>(reinterpret_cast<WT*>(xl + (size_t)ir[ib] * xs) + ic[ib]) = pk;
+    }
   } else {   // PRO_ATT: item = (row, 4 columns of one head) with a.nsplit <= NS partials of (max, sum, acc[4]); NI items per thread
     constexpr int NI = 16 / NS;
     const int q4 = K >> 2;
@@ -790,9 +848,9 @@ static hipError_t launch_fr2(const GemmArgs& a, size_t lds, hipStream_t s) {
   return hipGetLastError();
 }
 
-template <typename WT, int KTW, int PRO, int NS>
+template <typename WT, int KTW, int PRO, int NS, bool P16 = false>
 static hipError_t launch_fr_n(const GemmArgs& a, size_t lds, hipStream_t s) {
-  auto kern = rows_gemm_fr_k<WT, KTW, PRO, NS>;
+  auto kern = rows_gemm_fr_k<WT, KTW, PRO, NS, P16>;
   if (lds > 64 * 1024) {
     static size_t granted[16] = {0};   // per instantiation and device
     int dev = 0;
@@ -812,6 +870,13 @@ static hipError_t launch_fr_ktw(const GemmArgs& a, int pro, size_t lds, hipStrea
   if (pro == PRO_PLAIN) return launch_fr_n<WT, KTW, PRO_PLAIN, 1>(a, lds, s);
   if constexpr (KTW <= 16) {           // the out-projection: K = d <= 2048
     if (pro == PRO_ATT) {
+      if constexpr (sizeof(WT) == 2) {     // bf16 mode: the attention launch in front may have left bf16 partials (GemmArgs.att_p16)
+        if (a.att_p16) {
+          if (a.nsplit > 4) return launch_fr_n<WT, KTW, PRO_ATT, 8, true>(a, lds, s);
+          if (a.nsplit > 2) return launch_fr_n<WT, KTW, PRO_ATT, 4, true>(a, lds, s);
+          return launch_fr_n<WT, KTW, PRO_ATT, 2, true>(a, lds, s);
+        }
+      }
       if (a.nsplit > 4) return launch_fr_n<WT, KTW, PRO_ATT, 8>(a, lds, s);
       if (a.nsplit > 2) return launch_fr_n<WT, KTW, PRO_ATT, 4>(a, lds, s);
       return launch_fr_n<WT, KTW, PRO_ATT, 2>(a, lds, s);
