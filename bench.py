@@ -119,7 +119,7 @@ def in_situ(kernel, args):
 
 
 # option name -> (key of the option-state text, positions of its values there)
-OPTION_STATE = {"graph_steps": ("g", (0,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)), "finished_rows": ("fr", (0,)), "fr_pair": ("fr", (1,)), "att_p16": ("fr", (2,)),
+OPTION_STATE = {"graph_steps": ("g", (0,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)), "finished_rows": ("fr", (0,)), "fr_pair": ("fr", (1,)), "att_p16": ("fr", (2,)), "hq": ("fr", (3,)),
                 "tile_attn": ("ta", (0, 1)), "fr_one": ("r1", (0,)), "attn_fast": ("r1", (1,)), "qkv_p8": ("r1", (2,)), "qkv16": ("q16", (0,)),
                 "wide_heads": ("q16", (1,)), "wide_gemm": ("q16", (2,)), "wd_stage": ("q16", (3,)), "shrink": ("sh", (0,))}
 
@@ -171,7 +171,7 @@ def sampler_block(wl, box):
 
 def options_object(text):
     """The engine's option state (a compact text, vc_debug_read "options") as a JSON object."""
-    names = {"g": ("graph_steps", None), "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "paired", "bf16_partials"]),
+    names = {"g": ("graph_steps", None), "nt": ("nt", ["weights_mask", "attn_kv"]), "fr": ("finished_rows", ["max_rows", "paired", "bf16_partials", "centred_copy"]),
              "ta": ("tile_attn", ["kernel", "min_rows"]), "r1": ("one_row", ["fr_one", "attn_fast", "qkv_p8"]),
              "q16": ("many_rows", ["qkv16", "wide_heads", "wide_gemm", "wd_stage"]), "sh": ("shrink", None)}
     out = {"text": text}

@@ -189,7 +189,10 @@ struct SeqState {
 };
 
 // ---------------------------------------------------------------- kernel argument blocks
-enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2, PRO_LNW = 3 };      // PRO_LNW: LayerNorm fold of 2..8 FINISHED rows, one wave per row
+enum { PRO_LN = 0, PRO_PLAIN = 1, PRO_ATT = 2, PRO_LNW = 3, PRO_LNQ = 4 };      // PRO_LNW: LayerNorm fold of 2..8 FINISHED rows, one wave per row;
+// PRO_LNQ (round 6): the same fold on the producers' CENTRED COPY of those rows in the compute dtype (GemmArgs.x_in = q = WT(h - c), c = row_mu[row]:
+// the LayerNorm fold is exact for ANY centring constant, so the producer centres on the previous LayerNorm's mean of the row and the consumer
+// reads half the bytes - no fp32 row, no conversion)
 enum { EPI_QKV = 0, EPI_PART = 1, EPI_RELU = 2, EPI_GELU = 3, EPI_LOGITS = 4, EPI_RES = 5, EPI_QKV16 = 6 };   // EPI_RES: h_out = h_in + bias + W x (whole rows)
 // EPI_QKV16: the QKV epilogue over the 16-channel image of the matrix (prefill and wide-decode passes, round 5): the 12-channel tiles of
 // EPI_QKV leave a quarter of every MFMA's A lanes idle, which costs a many-row pass a quarter of its QKV launch
@@ -230,6 +233,9 @@ struct GemmArgs {
   int has_prev_bias;
   const float* wg;          // LN prologue: [group][N] row sums of the folded weights (W . gamma), see vc_gemm.hip
   const int* gather_rows;   // optional indirection on h_in/parts rows (logit rows for the heads)
+  const float* row_mu;      // never null.  Finished-row producers: the constant the centred copy hq_out is centred on; PRO_LNQ consumers: the same constant
+  float* row_mu_out;        // PRO_LNW / PRO_LNQ consumers: the row's mean (for the next producer's centred copy), written by the launch's first workgroup; may be null
+  void* hq_out;             // finished-row producers: WT [rows][d] = h_out - row_mu[row] in the compute dtype (null = not written)
   int d;                    // row width of h / parts
   // prologue PLAIN: X = x_in[r][grp*x_group_stride + k]
   const void* x_in;

@@ -146,6 +146,15 @@ struct vc_engine {
   // option "attn_fast": decode attention with the wave's maximum taken before any exponential (no online rescaling inside a wave) and,
   // in bf16 mode, hardware exp2 (v_exp_f32) instead of expf
   int attn_fast = 1;
+  // option "hq" (round 6): the finished-row producers of 2..16-row steps also write their rows CENTRED and in the compute dtype (hqA / hqB =
+  // WT(h - c), c = the row's mean as the previous LayerNorm found it: row_mu ping-pong), and the LayerNorm-folding consumers read that copy
+  // (PRO_LNQ: half the bytes of the fp32 row in bf16 mode, no conversion) - the fold is exact for any centring constant
+  int hq = 1;
+  void *hqA = nullptr, *hqB = nullptr;  // centred copies of hA / hB, WT [VC_ROWS][d]
+  float* row_mu[2] = {nullptr, nullptr};       // [VC_ROWS] each: ping-pong of the rows' means
+  float* mu_zero = nullptr;             // [VC_ROWS] zeros: GemmArgs.row_mu of every launch that centres nothing
+  int mu_cur = 0;                       // which row_mu buffer holds the means of the rows in hB (run_heads16 reads it behind forward_rows_fr)
+  bool hq_h = false;                    // hqB holds the centred copy of the finished rows in hB
   // option "att_p16" (round 6; bf16 mode): finished-row passes of 2..8 rows hand the attention's split partials to the out-projection as
   // bf16 (131 -> 66 KB per out-projection workgroup at 8 rows; the merged row is rounded to bf16 for the MFMA anyway)
   int att_p16 = 1;
@@ -308,6 +317,7 @@ GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdi
   g.hd_shift = e->hd == 32 ? 5 : e->hd == 64 ? 6 : 7;            // head_dim is 32, 64 or 128 (vc_create)
   g.cache_seq_stride = (long)e->H * e->S_max * e->hd;
   g.dbg_ts = e->dbg_ts;
+  g.row_mu = e->mu_zero;
   g.wd_stage = e->wd_stage;
   return g;
 }
@@ -358,6 +368,10 @@ int fr_nsplit(vc_engine* e, int rows) {
 // add residual + bias in their epilogue (rows_gemm_fr_k).  Leaves the finished rows in hB.
 int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
+  // option "hq": the producers leave a centred copy of their rows in the compute dtype and the consumers fold THAT (PRO_LNQ).  `cur` names
+  // the row_mu buffer with the latest means: a consumer reads its producer's constant there and leaves the row's new mean in the other one.
+  const bool hq = e->hq != 0;
+  int cur = 0;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
     const float* h_res = (l == 0) ? rs.h_in : e->hB;      // residual entering the layer
@@ -367,7 +381,14 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.h_in = h_res;
       g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
       g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
+      if (hq) g.row_mu_out = e->row_mu[cur ^ 1];
+      if (hq && l > 0) {       // the previous layer's FFN down-projection left hqB = WT(hB - row_mu[cur])
+        g.x_in = e->hqB; g.x_ld = d; g.row_mu = e->row_mu[cur];
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNQ, EPI_QKV, 1, 1, s));
+      } else {
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
+      }
+      cur ^= 1;
     }
     {
       AttnArgs a;
@@ -389,6 +410,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       GemmArgs g = base_args(e, rs, e->p_o, d, d);
       g.Wp = ly.Wo8; g.bias = ly.bo;
       g.h_in = h_res; g.h_out = e->hA;
+      if (hq) { g.hq_out = e->hqA; g.row_mu = e->row_mu[cur]; }      // centred on the mean the QKV consumer found for h
       if (rs.nsplit == 1) {
         g.x_in = e->xn; g.x_ld = d;
         HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
@@ -404,17 +426,26 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       g.h_in = e->hA;
       g.out = e->act; g.out_ld = 4 * d;
       g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
+      if (hq) {
+        g.x_in = e->hqA; g.x_ld = d; g.row_mu = e->row_mu[cur]; g.row_mu_out = e->row_mu[cur ^ 1];
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNQ, EPI_RELU, 1, 1, s));
+        cur ^= 1;
+      } else {
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
+      }
     }
     {  // h'' = h' + b2 + W2 a
       GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
       g.Wp = ly.W28; g.bias = ly.b2;
       g.x_in = e->act; g.x_ld = 4 * d;
       g.h_in = e->hA; g.h_out = e->hB;
+      if (hq) { g.hq_out = e->hqB; g.row_mu = e->row_mu[cur]; }      // centred on the mean the FFN-up consumer found for h'
       if (e->fr_pair && vc_gemm_frp_ok(rs.n_rows, d, 4 * d, e->dtype)) HIPCHK(e, vc_launch_gemm_frp(g, e->dtype, s));      // 2..8 rows: two k-tiles per fragment
       else HIPCHK(e, vc_launch_gemm_fr(g, e->dtype, PRO_PLAIN, s));
     }
   }
+  e->hq_h = hq;
+  e->mu_cur = cur;
   return VC_OK;
 }
 
@@ -422,6 +453,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
 int forward_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
   e->finished_rows_h = false;
+  e->hq_h = false;
   if (rs.n_rows >= 2 && rs.n_rows <= fr_max_rows(e)) {
     RowSrc fr = rs;
     fr.nsplit = fr_nsplit(e, rs.n_rows);
@@ -534,7 +566,12 @@ int run_heads16(vc_engine* e, const int* gather, int n, int in_row0, int out_row
     g.wg = e->wg_h1; g.gather_rows = gather;
     g.out = (char*)e->hh + (size_t)out_row0 * e->K * e->P * e->esz; g.out_ld = e->K * e->P;
     if (e->finished_rows_h && !gather && n >= 2 && n <= VC_FR_MAX_ROWS) {     // finished rows: LayerNorm fold per wave, no extra launch
-      HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_GELU, 1, 1, s));
+      if (e->hq_h && in_row0 == 0) {      // ... on the last FFN down-projection's centred copy
+        g.x_in = e->hqB; g.x_ld = e->d; g.row_mu = e->row_mu[e->mu_cur];
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNQ, EPI_GELU, 1, 1, s));
+      } else {
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_GELU, 1, 1, s));
+      }
     } else if (!gather && n >= e->ln_split_rows) {
       g.x_out = e->xn;
       HIPCHK(e, vc_launch_ln_rows(g, e->dtype, s));
@@ -635,6 +672,7 @@ bool use_wd(const vc_engine* e, int rows) {
 int prefill_rows(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
   e->finished_rows_h = false;           // this pass leaves h + split-K slabs
+  e->hq_h = false;
   // prefill passes run on the block GEMM (mt = 1); decode passes of 17..64 rows (n_active set) are still weight
   // streams: they take the weight-stationary multi-tile kernel (mt = 2), which reads every weight once at the decode rate
   const int mtv = (rs.n_active != nullptr && rs.n_rows <= VC_MAX_SEQS && !getenv("VC_WIDE_BLK")) ? 2 : 1;
@@ -1013,6 +1051,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
     e->qkv16 = v0 ? 1 : 0;
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "att_p16") { e->att_p16 = v0 ? 1 : 0;
+  } else if (name == "hq") { e->hq = v0 ? 1 : 0;
   } else if (name == "nt") { e->nt_decode = v0 & 63;
   } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
@@ -1024,8 +1063,8 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
 
 void refresh_opt_state(vc_engine* e) {
   char buf[256];
-  snprintf(buf, sizeof buf, "g=%d|nt=%d,%d|fr=%d,%d,%d|ta=%d,%d|r1=%d,%d,%d|q16=%d,%d,%d,%d|sh=%d",
-           e->steps_per_graph, e->nt_decode, e->attn_nt, e->fr_rows, e->fr_pair, e->att_p16, e->tile_attn, e->tile_attn_min_rows,
+  snprintf(buf, sizeof buf, "g=%d|nt=%d,%d|fr=%d,%d,%d,%d|ta=%d,%d|r1=%d,%d,%d|q16=%d,%d,%d,%d|sh=%d",
+           e->steps_per_graph, e->nt_decode, e->attn_nt, e->fr_rows, e->fr_pair, e->att_p16, e->hq, e->tile_attn, e->tile_attn_min_rows,
            e->fr_one, e->attn_fast, e->qkv_p8, e->qkv16, e->wide_heads, e->wide_gemm, e->wd_stage, e->shrink);
   e->opt_state = buf;
 }
@@ -1319,6 +1358,19 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   if ((rc = dalloc(e, &e->logit_row, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->st, (size_t)e->NS))) return rc;
   if ((rc = dalloc(e, &e->st_fin, (size_t)e->NS))) return rc;
+  {
+    char* t2;
+    if ((rc = dalloc(e, &t2, (size_t)VC_ROWS * d * e->esz))) return rc;
+    e->hqA = t2;
+    if ((rc = dalloc(e, &t2, (size_t)VC_ROWS * d * e->esz))) return rc;
+    e->hqB = t2;
+    if ((rc = dalloc(e, &e->row_mu[0], (size_t)VC_ROWS))) return rc;
+    if ((rc = dalloc(e, &e->row_mu[1], (size_t)VC_ROWS))) return rc;
+    if ((rc = dalloc(e, &e->mu_zero, (size_t)VC_ROWS))) return rc;
+    HIPCHK(e, hipMemset(e->row_mu[0], 0, VC_ROWS * 4));
+    HIPCHK(e, hipMemset(e->row_mu[1], 0, VC_ROWS * 4));
+    HIPCHK(e, hipMemset(e->mu_zero, 0, VC_ROWS * 4));
+  }
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
@@ -1350,7 +1402,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
                          
                          std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
                          std::make_pair("VC_TILE_ATTN", "tile_attn"),
-                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_ATTN_FAST", "attn_fast"), std::make_pair("VC_ATT_P16", "att_p16")})
+                         std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_ATTN_FAST", "attn_fast"), std::make_pair("VC_ATT_P16", "att_p16"), std::make_pair("VC_HQ", "hq")})
     if (const char* v = getenv(kv.first)) {
       // (VC_NT was a boolean through round 3 - 1 = on, the default; it is a per-matrix bit mask now: the legacy "1" keeps meaning "on")
       if (std::string(kv.first) == "VC_NT" && std::string(v) == "1") v = "63";
@@ -2027,12 +2079,14 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
         GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
         g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.wg = ly.wg_1; g.h_in = e->hA; g.out = e->act; g.out_ld = 4 * d;
         g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_RELU, 1, 1, s));
+        if (e->hq) { g.x_in = e->hqA; g.x_ld = d; g.row_mu = e->row_mu[0]; g.row_mu_out = e->row_mu[1]; }     // the form forward_rows_fr launches
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, e->hq ? PRO_LNQ : PRO_LNW, EPI_RELU, 1, 1, s));
       } else if (w == "qkv") {
         GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
         g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.wg = ly.wg_qkv; g.h_in = e->hB; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
         g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
+        if (e->hq) { g.x_in = e->hqB; g.x_ld = d; g.row_mu = e->row_mu[0]; g.row_mu_out = e->row_mu[1]; }
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, e->hq ? PRO_LNQ : PRO_LNW, EPI_QKV, 1, 1, s));
       } else if (w == "ffn2") {
         GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
         g.Wp = ly.W28; g.bias = ly.b2; g.x_in = e->act; g.x_ld = 4 * d; g.h_in = e->hA; g.h_out = e->hB;

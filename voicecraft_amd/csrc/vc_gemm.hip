@@ -144,7 +144,8 @@ hipError_t vc_launch_cast(const float* src, void* dst, long n, int dtype, hipStr
 template <typename WT, int KTW, int PRO, int EPI, int NTW = 1, bool NT = true, bool R2 = false, int NP = VC_MAX_KSPLIT>
 __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   using T = WTr<WT>;
-  static_assert(NTW == 1 || PRO == PRO_LNW, "two tiles per workgroup: finished-row consumers only");
+  constexpr bool LNW = PRO == PRO_LNW || PRO == PRO_LNQ;       // finished-row consumers (fp32 rows / the producers' centred copy)
+  static_assert(NTW == 1 || LNW, "two tiles per workgroup: finished-row consumers only");
   static_assert(NP == VC_MAX_KSPLIT || PRO == PRO_LN, "slab count: LayerNorm prologue of slab-form passes only");
   static_assert(NP == 0 || NP == 2 || NP == VC_MAX_KSPLIT, "slabs requested per row");
   static_assert(!R2 || NTW == 2, "two rows per wave: the two-tile form");
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
   int epos, eseq;
   epi_preload<WT, EPI>(a, (m < n_rows) ? m : 0, n, grp, eb, epos, eseq);
   float4 ewg = make_float4(0.f, 0.f, 0.f, 0.f);
-  if constexpr (PRO == PRO_LN || PRO == PRO_LNW) ewg = wg_preload<WT, EPI>(a, n, grp);
+  if constexpr (PRO == PRO_LN || LNW) ewg = wg_preload<WT, EPI>(a, n, grp);
 
   const uint4* wbase = a.Wp + (long)grp * a.w_group_stride + ((long)nt * a.KT + kt0 + wave * KTW) * SPT;   // wave-uniform
   uint4 wf[KTW];
@@ -342,11 +343,69 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
       if (lane == 0) {      /* the epilogue sums four per-wave pairs: this row has one */          \
         *reinterpret_cast<float4*>(stat + (r) * 8) = make_float4(s1_, s2_, 0.f, 0.f);            \
         *reinterpret_cast<float4*>(stat + (r) * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);        \
+        if (a.row_mu_out && blockIdx.x == 0 && grp == 0) a.row_mu_out[r] = mu_;      /* the next producer centres its copy of the row on it */ \
       }                                                                                          \
     }
     VC_LNW_ROW(xa, rowA);
     if constexpr (TWO_ROWS) { VC_LNW_ROW(xb, rowB); }
 #undef VC_LNW_ROW
+  } else if constexpr (PRO == PRO_LNQ) {
+    // The same fold on the producer's centred copy q = WT(h - c) of the finished rows (c = a.row_mu[row], the mean the PREVIOUS LayerNorm of
+    // the row found): W LN(h) = rstd (W' q - mean(q) rowsum(W')) + cb holds for any c, and |mean(q)| stays far below sigma because one
+    // residual update moves a row's mean by little - the rounding of q keeps its mantissa for the signal, as with the exact mean.  A wave
+    // copies its row(s) from HBM / L2 to LDS as they are (16 bytes per lane and request: HALF the bytes of the fp32 rows in bf16 mode, no
+    // conversion) and sums the values and their squares on the way.
+    const int d = a.d;
+    constexpr int E16 = 16 / (int)sizeof(WT);                   // elements per 16-byte unit
+    const int npl = (d * (int)sizeof(WT)) >> 10;                // units per lane and row: d sizeof(WT) / 16 / 64 = 1..8
+    const int rowA = (NTW == 1) ? wave : wv;
+    const int rowB = (NTW == 1) ? wave + 4 : wv + 8;
+    constexpr bool TWO_ROWS = (NTW == 1) || R2;
+    const char* qA = reinterpret_cast<const char*>(a.x_in) + (long)min(rowA, n_rows - 1) * d * (long)sizeof(WT);
+    const char* qB = reinterpret_cast<const char*>(a.x_in) + (long)min(rowB, n_rows - 1) * d * (long)sizeof(WT);
+    const float cA = a.row_mu[min(rowA, n_rows - 1)], cB = a.row_mu[min(rowB, n_rows - 1)];
+    uint4 xa[8], xb[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int u = (min(j, npl - 1) * 64 + lane) * 16;
+      xa[j] = *reinterpret_cast<const uint4*>(qA + u);
+      if constexpr (TWO_ROWS) xb[j] = *reinterpret_cast<const uint4*>(qB + u);
+    }
+    VC_ISSUE_WEIGHTS(0);
+    VC_BURST_OUT();
+#define VC_LNQ_ROW(X, r, c_)                                                                     \
+    if ((r) < n_rows) {                                                                          \
+      char* xr_ = xl + (size_t)(r) * xs;                                                         \
+      float s1_ = 0.f, s2_ = 0.f;                                                                \
+      _Pragma("unroll") for (int j = 0; j < 8; ++j)                                              \
+        if (j < npl) {                                                                           \
+          *reinterpret_cast<uint4*>(xr_ + (j * 64 + lane) * 16) = X[j];                          \
+          float f_[E16];                                                                         \
+          if constexpr (sizeof(WT) == 2) {                                                       \
+            f_[0] = __uint_as_float(X[j].x << 16); f_[1] = __uint_as_float(X[j].x & 0xffff0000u); \
+            f_[2] = __uint_as_float(X[j].y << 16); f_[3] = __uint_as_float(X[j].y & 0xffff0000u); \
+            f_[4] = __uint_as_float(X[j].z << 16); f_[5] = __uint_as_float(X[j].z & 0xffff0000u); \
+            f_[6] = __uint_as_float(X[j].w << 16); f_[7] = __uint_as_float(X[j].w & 0xffff0000u); \
+          } else {                                                                               \
+            f_[0] = __uint_as_float(X[j].x); f_[1] = __uint_as_float(X[j].y);                    \
+            f_[2] = __uint_as_float(X[j].z); f_[3] = __uint_as_float(X[j].w);                    \
+          }                                                                                      \
+          _Pragma("unroll") for (int e_ = 0; e_ < E16; e_ += 4) {                                \
+            s1_ += (f_[e_] + f_[e_ + 1]) + (f_[e_ + 2] + f_[e_ + 3]);                            \
+            s2_ += (f_[e_] * f_[e_] + f_[e_ + 1] * f_[e_ + 1]) + (f_[e_ + 2] * f_[e_ + 2] + f_[e_ + 3] * f_[e_ + 3]); \
+          }                                                                                      \
+        }                                                                                        \
+      s1_ = wave_sum(s1_);                                                                       \
+      s2_ = wave_sum(s2_);                                                                       \
+      if (lane == 0) {                                                                           \
+        *reinterpret_cast<float4*>(stat + (r) * 8) = make_float4(s1_, s2_, 0.f, 0.f);            \
+        *reinterpret_cast<float4*>(stat + (r) * 8 + 4) = make_float4(0.f, 0.f, 0.f, 0.f);        \
+        if (a.row_mu_out && blockIdx.x == 0 && grp == 0) a.row_mu_out[r] = (c_) + s1_ * (1.0f / (float)d);   \
+      }                                                                                          \
+    }
+    VC_LNQ_ROW(xa, rowA, cA);
+    if constexpr (TWO_ROWS) { VC_LNQ_ROW(xb, rowB, cB); }
+#undef VC_LNQ_ROW
   } else if constexpr (PRO == PRO_PLAIN) {
     // X rows copied as 16-byte units, flat index = row * upr + unit.  The first NB*256 units are
     // requested ahead of the weight burst (clamped, unconditional), the rest behind it.
@@ -509,7 +568,7 @@ __global__ __launch_bounds__(256 * NTW) void rows_gemm_k(const GemmArgs a) {
       const f32x4 a1 = red[64 + lane], a2 = red[128 + lane], a3 = red[192 + lane];
       acc = (acc + a1) + (a2 + a3);
     }
-    if constexpr (PRO == PRO_LN || PRO == PRO_LNW) {   // LayerNorm fold on the centred row xc: y = rstd * (W'xc - mean(xc) * rowsum(W')) [+ cb in the epilogue]
+    if constexpr (PRO == PRO_LN || LNW) {   // LayerNorm fold on the centred row xc: y = rstd * (W'xc - mean(xc) * rowsum(W')) [+ cb in the epilogue]
       const float4 sa = *reinterpret_cast<const float4*>(stat + m * 8), sb = *reinterpret_cast<const float4*>(stat + m * 8 + 4);
       const float inv_d = 1.0f / (float)a.d;
       const float mean = ((sa.x + sa.z) + (sb.x + sb.z)) * inv_d;
@@ -558,6 +617,7 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr_k(const GemmArg
   // epilogue operands first (a wave's loads return in order): the residual and the bias of the lane's four channels
   const float4 eres = *reinterpret_cast<const float4*>(a.h_in + (long)((m < n_rows) ? m : 0) * a.d + n);
   const float4 eb = *reinterpret_cast<const float4*>(a.bias + n);
+  const float cmu = a.row_mu[(m < n_rows) ? m : 0];                      // centring constant of the row's copy in the compute dtype (hq_out)
   const uint4* wbase = a.Wp + ((long)nt * a.KT + wave * KTW) * SPT;      // wave-uniform
   uint4 wf[KTW];
 #define VC_FR_WEIGHTS(c_)                                                                        \
@@ -730,6 +790,7 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr_k(const GemmArg
     for (int w = 1; w < NW; ++w) acc += red[w * 64 + lane];
     const f32x4 o = {eres.x + eb.x + acc[0], eres.y + eb.y + acc[1], eres.z + eb.z + acc[2], eres.w + eb.w + acc[3]};
     store4(a.h_out + (long)m * a.d + n, o);
+    if (a.hq_out) { const f32x4 q = {o[0] - cmu, o[1] - cmu, o[2] - cmu, o[3] - cmu}; store4(reinterpret_cast<WT*>(a.hq_out) + (long)m * a.d + n, q); }
   }
 }
 
@@ -758,6 +819,7 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr2_k(const GemmAr
   const int wslot = kg * TH + min(m, TH - 1);
   const float4 eres = *reinterpret_cast<const float4*>(a.h_in + (long)((m < n_rows) ? m : 0) * a.d + n);
   const float4 eb = *reinterpret_cast<const float4*>(a.bias + n);
+  const float cmu = a.row_mu[(m < n_rows) ? m : 0];
   const uint4* wbase = a.Wp + ((long)nt * a.KT + wave * KTW) * SPT;      // wave-uniform; the second half is NW * KTW k-tiles further
   uint4 wfa[KTW], wfb[KTW];
   const int upr = Kh * (int)sizeof(WT) / 16;       // 16-byte units per row and half; rows x upr <= 16 x 512 (host contract)
@@ -830,6 +892,7 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_fr2_k(const GemmAr
     for (int w = 1; w < NW; ++w) acc += red[w * 64 + lane];
     const f32x4 o = {eres.x + eb.x + acc[0], eres.y + eb.y + acc[1], eres.z + eb.z + acc[2], eres.w + eb.w + acc[3]};
     store4(a.h_out + (long)m * a.d + n, o);
+    if (a.hq_out) { const f32x4 q = {o[0] - cmu, o[1] - cmu, o[2] - cmu, o[3] - cmu}; store4(reinterpret_cast<WT*>(a.hq_out) + (long)m * a.d + n, q); }
   }
 }
 template <typename WT, int KTW>
@@ -1191,6 +1254,7 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_frp_k(const GemmAr
   const int nfin = nt * TH + 4 * (tid & 1);
   const float4 eres = *reinterpret_cast<const float4*>(a.h_in + (long)frow * a.d + nfin);
   const float4 eb = *reinterpret_cast<const float4*>(a.bias + nfin);
+  const float cmu = a.row_mu[frow];
   // X rows as 16-byte units, flat index = row * upr + unit; RMAX * NPW / 8 units per thread
   constexpr int NXU = RMAX * ((NPW * 8 + 63) / 64);
   const int ush = a.x_upr_shift;                    // log2(units per row)
@@ -1248,6 +1312,7 @@ __global__ __launch_bounds__(64 * VC_FR_WAVES) void rows_gemm_frp_k(const GemmAr
     for (int w = 0; w < NW; ++w) sum += red[(w * RMAX + r) * 4 + half] + red[(w * RMAX + r) * 4 + half + 2];
     const f32x4 o = {eres.x + eb.x + sum[0], eres.y + eb.y + sum[1], eres.z + eb.z + sum[2], eres.w + eb.w + sum[3]};
     store4(a.h_out + (long)r * a.d + nfin, o);
+    if (a.hq_out) { const f32x4 q = {o[0] - cmu, o[1] - cmu, o[2] - cmu, o[3] - cmu}; store4(reinterpret_cast<WT*>(a.hq_out) + (long)r * a.d + nfin, q); }
   }
 }
 template <typename WT, int NPW, int RMAX>
@@ -1653,6 +1718,23 @@ static hipError_t launch_ktw(const GemmArgs& a, int dtype, int pro, int epi, int
   if (pro == PRO_LN && epi == EPI_QKV) return launch_one<WT, KTW, PRO_LN, EPI_QKV>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LN && epi == EPI_RELU) return launch_one<WT, KTW, PRO_LN, EPI_RELU>(a, dtype, ksplit, groups, s);
   if (pro == PRO_LN && epi == EPI_GELU) return launch_one<WT, KTW, PRO_LN, EPI_GELU>(a, dtype, ksplit, groups, s);
+  if (pro == PRO_LNQ) {      // finished-row consumers on the producers' centred copy (round 6): the same three shapes as PRO_LNW below
+    if (a.mt == 4 && a.n_tiles % 2 == 0 && groups == 1) {
+      if (epi == EPI_QKV) return a.nt ? launch_dec_nt<WT, KTW, PRO_LNQ, EPI_QKV, 2, true, true>(a, dtype, ksplit, groups, s)
+                                      : launch_dec_nt<WT, KTW, PRO_LNQ, EPI_QKV, 2, false, true>(a, dtype, ksplit, groups, s);
+      if (epi == EPI_RELU) return a.nt ? launch_dec_nt<WT, KTW, PRO_LNQ, EPI_RELU, 2, true, true>(a, dtype, ksplit, groups, s)
+                                       : launch_dec_nt<WT, KTW, PRO_LNQ, EPI_RELU, 2, false, true>(a, dtype, ksplit, groups, s);
+    }
+    if (a.n_rows > VC_FR_MAX_ROWS) return hipErrorInvalidValue;
+    if (a.mt == 3 && a.n_tiles % 2 == 0 && groups == 1) {
+      if (epi == EPI_QKV) return launch_dec<WT, KTW, PRO_LNQ, EPI_QKV, 2>(a, dtype, ksplit, groups, s);
+      if (epi == EPI_RELU) return launch_dec<WT, KTW, PRO_LNQ, EPI_RELU, 2>(a, dtype, ksplit, groups, s);
+    }
+    if (epi == EPI_QKV) return launch_dec<WT, KTW, PRO_LNQ, EPI_QKV>(a, dtype, ksplit, groups, s);
+    if (epi == EPI_RELU) return launch_dec<WT, KTW, PRO_LNQ, EPI_RELU>(a, dtype, ksplit, groups, s);
+    if (epi == EPI_GELU) return launch_dec<WT, KTW, PRO_LNQ, EPI_GELU>(a, dtype, ksplit, groups, s);
+    return hipErrorInvalidValue;
+  }
   if (pro == PRO_LNW && a.mt == 4 && a.n_tiles % 2 == 0 && groups == 1) {     // ... and two rows per wave (9..16 finished rows)
     if (epi == EPI_QKV) return a.nt ? launch_dec_nt<WT, KTW, PRO_LNW, EPI_QKV, 2, true, true>(a, dtype, ksplit, groups, s)
                                     : launch_dec_nt<WT, KTW, PRO_LNW, EPI_QKV, 2, false, true>(a, dtype, ksplit, groups, s);
