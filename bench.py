@@ -515,6 +515,14 @@ def configs_block(args, dev, sd830):
                     ab = {k: ab[k] for k in ("knob", "A", "B", "A_ms_median", "B_ms_median", "median_delta_pct", "spread_pct")}
                 except Exception as e:      # reporting only
                     ab = {"error": str(e)}
+            elif 2 <= wl.B <= 16:      # the two byte-halving forms of round 6, each against its off state, in process (3 pairs)
+                ab = []
+                for spec in ("att_p16=0:1", "hq=0:1"):
+                    try:
+                        r = ab_block(wl.eng, lambda seed: wl.call(seed), spec, 3)
+                        ab.append({k: r[k] for k in ("knob", "A", "B", "A_ms_median", "B_ms_median", "median_delta_pct", "spread_pct")})
+                    except Exception as e:      # reporting only
+                        ab.append({"knob": spec, "error": str(e)})
             out[key] = {"config": what, "workload": wl.label(not args.no_graph), "value": round(tok / wall, 1), "unit": "codec-tokens/s",
                         "calls": n_calls, "ms_per_call": round(wall / n_calls * 1e3, 2), "prefill_ms": round(pre / n_calls, 2),
                         "decode_ms_per_step": round(dstep, 4), "rtf": round(wall / (tok / wl.K / 50.0), 4),

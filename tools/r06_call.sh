@@ -1,7 +1,8 @@
 set -u
 export TMPDIR=/tmp
 O=gpurun_out
-echo "== att_p16 A/B"
-for B in 8 4 2 6; do timeout 300 python tools/ab_sweep.py --batch $B att_p16=0:1 2>&1 | grep -v amdgpu.ids | tee -a $O/r06f_ab_att_p16.log; done
-echo "== tests"; timeout 1200 python -m pytest tests/test_gpu_options.py tests/test_gpu_scale.py -m gpu -q -x -k "finished_row or c5_share or eight_utter or options_do_not" 2>&1 | tail -8 | tee $O/r06f_pytest.log
-echo "== 8 rows traced"; bash tools/prof_decode.sh r06f_b8 --batch 8 --no-codec --ab none --no-configs; head -10 $O/r06f_b8_rocprof_kernel_stats.txt
+echo "== tests"; timeout 1800 python -m pytest tests/test_gpu_options.py tests/test_gpu_scale.py tests/test_gpu_model.py tests/test_gpu_one_row.py -m gpu -q 2>&1 | tail -25 | tee $O/r06h_pytest.log
+echo "== att_p16 one-row A/B"
+timeout 300 python tools/ab_sweep.py att_p16=1:2 2>&1 | grep -v amdgpu.ids | tee -a $O/r06h_ab_p16.log
+timeout 300 python tools/ab_sweep.py --preset giga330M att_p16=1:2 2>&1 | grep -v amdgpu.ids | tee -a $O/r06h_ab_p16.log
+timeout 300 python tools/ab_sweep.py --batch 3 att_p16=1:2 hq=0:1 2>&1 | grep -v amdgpu.ids | tee -a $O/r06h_ab_p16.log

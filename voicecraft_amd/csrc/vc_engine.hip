@@ -304,6 +304,13 @@ struct RowSrc {
   int tiled;        // 1: every 16-row tile holds consecutive positions of ONE sequence (prefill_batch): MFMA attention
 };
 
+// The consumers of 2..16 finished rows fold the producers' centred copy of the rows (PRO_LNQ) when a row of it is whole 1 KB requests of a
+// wave (64 lanes x 16 bytes: d a multiple of 512 in bf16, of 256 in fp32); other widths keep the fp32 rows (PRO_LNW).
+bool hq_on(const vc_engine* e) {
+  const int bytes = e->d * (e->dtype == VC_DTYPE_BF16 ? 2 : 4);
+  return e->hq != 0 && bytes % 1024 == 0 && bytes <= 8192;
+}
+
 GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdim) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
@@ -370,7 +377,7 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
   const int d = e->d;
   // option "hq": the producers leave a centred copy of their rows in the compute dtype and the consumers fold THAT (PRO_LNQ).  `cur` names
   // the row_mu buffer with the latest means: a consumer reads its producer's constant there and leaves the row's new mean in the other one.
-  const bool hq = e->hq != 0;
+  const bool hq = hq_on(e);
   int cur = 0;
   for (int l = 0; l < e->L; ++l) {
     Layer& ly = e->layers[l];
@@ -2079,14 +2086,14 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
         GemmArgs g = base_args(e, rs, e->p_f1, 4 * d, d);
         g.Wp = ly.W1; nt_bit(e, g, NT_F1); g.bias = ly.b1; g.wg = ly.wg_1; g.h_in = e->hA; g.out = e->act; g.out_ld = 4 * d;
         g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
-        if (e->hq) { g.x_in = e->hqA; g.x_ld = d; g.row_mu = e->row_mu[0]; g.row_mu_out = e->row_mu[1]; }     // the form forward_rows_fr launches
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, e->hq ? PRO_LNQ : PRO_LNW, EPI_RELU, 1, 1, s));
+        if (hq_on(e)) { g.x_in = e->hqA; g.x_ld = d; g.row_mu = e->row_mu[0]; g.row_mu_out = e->row_mu[1]; }     // the form forward_rows_fr launches
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, hq_on(e) ? PRO_LNQ : PRO_LNW, EPI_RELU, 1, 1, s));
       } else if (w == "qkv") {
         GemmArgs g = base_args(e, rs, e->p_qkv, 3 * d, d);
         g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.wg = ly.wg_qkv; g.h_in = e->hB; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
         g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
-        if (e->hq) { g.x_in = e->hqB; g.x_ld = d; g.row_mu = e->row_mu[0]; g.row_mu_out = e->row_mu[1]; }
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, e->hq ? PRO_LNQ : PRO_LNW, EPI_QKV, 1, 1, s));
+        if (hq_on(e)) { g.x_in = e->hqB; g.x_ld = d; g.row_mu = e->row_mu[0]; g.row_mu_out = e->row_mu[1]; }
+        HIPCHK(e, vc_launch_gemm(g, e->dtype, hq_on(e) ? PRO_LNQ : PRO_LNW, EPI_QKV, 1, 1, s));
       } else if (w == "ffn2") {
         GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
         g.Wp = ly.W28; g.bias = ly.b2; g.x_in = e->act; g.x_ld = 4 * d; g.h_in = e->hA; g.h_out = e->hB;
