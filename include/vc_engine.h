@@ -106,7 +106,8 @@ const char* vc_version(void);
  *                  found, and the LayerNorm-folding consumers read that copy instead of the fp32 rows (widths whose row of the copy is whole
  *                  1 KB requests: d a multiple of 512 in bf16, of 256 in fp32; others keep the fp32 rows)
  *   "fr_one"       ONE-row steps: 1 (default) = the FFN down-projection finishes its row (no split-K slabs), 0 = off;  "qkv_p8" 1 = the
- *                  one-row QKV projection in the same paired form;  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
+ *                  one-row QKV projection in the same paired form, 2 (default) = also the QKV projection of 2..8 finished rows behind the
+ *                  centred copy ("hq"; rows_gemm_qp_k: up to 6 rows at d >= 2048, where 8 rows measured slower);  "attn_fast" 1 = decode attention without per-visit rescaling (bf16: hardware exp2)
  *   "tile_attn"    "k[,min_rows]"  prefill attention kernel (1: 16 query rows per wave; 2: 64 per workgroup, P in registers - bf16,
  *                  head_dim 128, calls whose longest prompt has at least min_rows rows)
  *   "qkv16"        1 = prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of the folded matrix

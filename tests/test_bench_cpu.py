@@ -48,10 +48,10 @@ def test_option_state_text_round_trips_through_the_bench_helpers():
     takes it (what an in-process A/B restores afterwards)."""
     sys.path.insert(0, ROOT)
     import bench
-    t = "g=8|nt=63,2|fr=16,1,1,1|ta=2,768|r1=1,1,1|q16=1,1,1,1|sh=1"
+    t = "g=8|nt=63,2|fr=16,1,1,1|ta=2,768|r1=1,1,2|q16=1,1,1,1|sh=1"
     o = bench.options_object(t)
     assert o["text"] == t and o["graph_steps"] == 8 and o["tile_attn"] == {"kernel": 2, "min_rows": 768}
-    assert o["one_row"] == {"fr_one": 1, "attn_fast": 1, "qkv_p8": 1} and o["nt"] == {"weights_mask": 63, "attn_kv": 2}
+    assert o["one_row"] == {"fr_one": 1, "attn_fast": 1, "qkv_p8": 2} and o["nt"] == {"weights_mask": 63, "attn_kv": 2}
     assert o["many_rows"] == {"qkv16": 1, "wide_heads": 1, "wide_gemm": 1, "wd_stage": 1} and o["shrink"] == 1 and o["finished_rows"] == {"max_rows": 16, "paired": 1, "bf16_partials": 1, "centred_copy": 1}
     assert bench.option_value(t, "tile_attn") == "2,768" and bench.option_value(t, "wide_gemm") == "1" and bench.option_value(t, "shrink") == "1"
     assert bench.option_value(t, "fr_one") == "1" and bench.option_value(t, "attn_nt") == "2" and bench.option_value(t, "no_such") is None

@@ -47,16 +47,23 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256, use_graph=False)
     L = a.num_decoder_layers
     got = {}
-    for mode in ("on", "p32", "nohq", "unpaired", "off"):   # on: the default; p32: fp32 attention partials (rounds 4-5); nohq: the consumers fold the fp32 rows (no centred copy); unpaired: round 4's FFN-down producer; off: split-K slabs + LayerNorm launches
+    qp_can = (a.d_model * 2) % 1024 == 0       # the centred copy (and the paired QKV consumer behind it) needs rows of whole 1 KB requests
+    for mode in ("on", "p32", "nohq", "qkv12", "unpaired", "off"):   # on: the default; p32: fp32 attention partials (rounds 4-5); nohq: the consumers fold the fp32 rows (no centred copy); qkv12: the QKV projection of 2..8 rows on the 12-channel tiles; unpaired: round 4's FFN-down producer; off: split-K slabs + LayerNorm launches
         eng.set_option("finished_rows", 0 if mode == "off" else 16)
         eng.set_option("fr_pair", 0 if mode == "unpaired" else 1)
         eng.set_option("att_p16", 0 if mode == "p32" else 1)
         eng.set_option("hq", 0 if mode == "nohq" else 1)
+        eng.set_option("qkv_p8", 1 if mode == "qkv12" else 2)
         assert ("|fr=0," if mode == "off" else "|fr=16,") in eng.options()
         c0 = eng.launch_counts()
         outs, lg = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3,
                                            _forced=forced, _logit_steps=n)
         c = _delta(eng.launch_counts(), c0)
+        # the paired QKV consumer (round 6): layers 1.. of every step of 2..8 rows, only behind the centred copy
+        if mode in ("on", "p32", "unpaired") and qp_can and B <= 8:
+            assert c["rows_gemm_qp"] >= (L - 1) * (n - 1), c
+        elif mode in ("nohq", "qkv12", "off") or not qp_can:
+            assert c["rows_gemm_qp"] == 0, (mode, c)
         if mode == "unpaired":
             assert c["rows_gemm_frp"] == 0 and c["rows_gemm_fr"] >= 2 * L * (n - 1), c
         elif mode != "off":
@@ -77,6 +84,7 @@ def test_finished_row_form_bf16_per_sequence_logits(preset, B):
     assert np.abs(got["on"] - got["p32"])[np.abs(got["off"]) < 1e3].max() < 0.25      # bf16 / fp32 attention partials (steps of up to 8 rows: wider batches get there as they shrink)
     assert np.abs(got["on"] - got["nohq"])[np.abs(got["off"]) < 1e3].max() < 0.25     # rows centred on the previous mean / on their own: two roundings of the same numbers
     assert np.abs(got["on"] - got["unpaired"])[np.abs(got["off"]) < 1e3].max() < 0.25    # paired / unpaired producer: another order of the same sums
+    assert np.abs(got["on"] - got["qkv12"])[np.abs(got["off"]) < 1e3].max() < 0.25     # the QKV projection on 8- / 12-channel tiles: another order of the same sums
 
 
 @pytest.mark.parametrize("preset,B", [("tiny_h16", 2), ("tiny_h16", 4), ("tiny128", 3), ("tiny_h16", 11), ("tiny128", 16)])
@@ -92,14 +100,19 @@ def test_finished_row_form_fp32_tokens_equal_the_oracle(preset, B):
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=B, max_positions=256)
     orc = VoiceCraftOracle(a, sd)
     want = [orc.inference_tts(xx, xl, yy, top_k=1, stop_repetition=3)[0].numpy() for (xx, xl, yy) in prompts]
-    for hq in (1, 0):        # the consumers fold the producers' centred copy of the rows (round 6) / the fp32 rows
+    for hq, p8 in ((1, 2), (1, 1), (0, 2)):        # the consumers fold the producers' centred copy of the rows (round 6: the QKV projection of 2..8 rows on 8- / 12-channel tiles) / the fp32 rows
         eng.set_option("hq", hq)
+        eng.set_option("qkv_p8", p8)
         c0 = eng.launch_counts()
         outs = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=1, stop_repetition=3)
         c = _delta(eng.launch_counts(), c0)
         assert c["rows_gemm_fr"] + c["rows_gemm_frp"] > 0, c
+        if hq == 1 and p8 == 2:
+            assert B > 8 or c["rows_gemm_qp"] > 0, c       # (wider batches get to 2..8 rows only as they shrink)
+        else:
+            assert c["rows_gemm_qp"] == 0, (hq, p8, c)
         for w, (res, gen) in zip(want, outs):
-            assert np.array_equal(res.cpu().numpy(), w), hq
+            assert np.array_equal(res.cpu().numpy(), w), (hq, p8)
 
 
 def test_options_do_not_change_tokens_and_bad_options_are_refused():

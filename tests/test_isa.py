@@ -97,6 +97,13 @@ def test_kernels_are_built_around_the_intended_instructions(kern):
     for name, (body, _, vgpr) in pick(kern, "rows_gemm_frp_k<bf16_t, 16, 8>").items():
         assert len(re.findall(r"global_load_dwordx4[^\n]* nt", body)) == 16 and body.count("v_mfma_f32_16x16x32_bf16") == 16, name
         assert vgpr <= 256, (name, vgpr)
+    # ... and the QKV projection of 2..8 finished rows in the same paired form (round 6): three 8-channel tiles per workgroup, 4 pairs per
+    # wave and tile at d = 2048 - 12 full-KB weight requests (non-temporal) behind the 4 requests of the wave's row, 12 MFMAs, no scratch
+    qp = pick(kern, "rows_gemm_qp_k<bf16_t, 4, 8>")
+    assert qp
+    for name, (body, _, vgpr) in qp.items():
+        assert len(re.findall(r"global_load_dwordx4[^\n]* nt", body)) == 12 and body.count("v_mfma_f32_16x16x32_bf16") == 12, name
+        assert "scratch_" not in body and vgpr <= 128, (name, vgpr)
     # the GEMM path reads `*a.n_active` with a SCALAR load (round 5: an inline-asm prefetch role in the same kernel had turned it into a
     # vector load; the roles left the tree in round 6)
     for prefix in ("rows_gemm_k<bf16_t, 16, 0, 2, 1, true, false, 2>", "rows_gemm_k<bf16_t, 8, 2, 1, 1, true, false, 4>"):

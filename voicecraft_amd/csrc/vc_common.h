@@ -392,12 +392,14 @@ hipError_t vc_launch_gemm_fr1(const GemmArgs& a, int dtype, int pro, int epi, hi
 int vc_gemm_fr1_ok(int N, int K, int dtype, int nw);
 hipError_t vc_launch_gemm_frp(const GemmArgs& a, int dtype, hipStream_t s);           // paired finished-row producer of 2..8-row passes (rows_gemm_frp_k)
 int vc_gemm_frp_ok(int rows, int N, int K, int dtype);
+hipError_t vc_launch_gemm_qp(const GemmArgs& a, int dtype, hipStream_t s);            // paired QKV consumer of 2..8 finished rows (rows_gemm_qp_k)
+int vc_gemm_qp_ok(int rows, int N, int K, int dtype);
 extern int vc_blk_dbg_mask;   // vc_gemm.hip: diagnostic mask of the prefill block GEMM, 0 in production
 // Launch census (process-wide, host side): which kernel FORM each launcher picked.  Read through
 // vc_debug_read("launch_counts") by the parity tests, which assert that the form a benchmarked shape runs on is the one
 // they compared with the oracle.
 enum { VC_LC_ROWS_GEMM = 0, VC_LC_MT2 = 1, VC_LC_MT4 = 2, VC_LC_BLK64 = 3, VC_LC_BLK128_SBS = 4, VC_LC_BLK128_2X2 = 5,
-       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_ROWS_GEMM_FRP = 15, VC_LC_WD = 16, VC_LC_N = 17 };
+       VC_LC_BLK64_OCC2 = 6, VC_LC_LN_ROWS = 7, VC_LC_ROWS_ATTN = 8, VC_LC_TILE_ATTN = 9, VC_LC_ROWS_GEMM_FR = 10, VC_LC_BIG256 = 11, VC_LC_BIG128 = 12, VC_LC_ROW_GEMM_FR1 = 13, VC_LC_TILE_ATTN64 = 14, VC_LC_ROWS_GEMM_FRP = 15, VC_LC_WD = 16, VC_LC_ROWS_GEMM_QP = 17, VC_LC_N = 18 };
 extern long long vc_launch_counts[VC_LC_N];
 hipError_t vc_launch_ln_rows(const GemmArgs& a, int dtype, hipStream_t s);
 hipError_t vc_launch_attn(const AttnArgs& a, int dtype, int rows_cap, hipStream_t s);

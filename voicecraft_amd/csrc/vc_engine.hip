@@ -120,8 +120,9 @@ struct vc_engine {
   // of half-filled 8-channel fragments (rows_gemm_fr_k)
   int fr_pair = 1;
   // option "qkv_p8" (round 5): one-row steps behind a finished row (fr_one) run the QKV projection on 8-channel tiles with two k-tiles
-  // per MFMA fragment (row_gemm_fr1_k<PRO_LN, EPI_QKV>: every lane's 16 bytes are weights) instead of 12-channel tiles
-  int qkv_p8 = 1;
+  // per MFMA fragment (row_gemm_fr1_k<PRO_LN, EPI_QKV>: every lane's 16 bytes are weights) instead of 12-channel tiles; 2 (round 6): steps of
+  // 2..8 finished rows too, behind the producers' centred copy (rows_gemm_qp_k)
+  int qkv_p8 = 2;
   // option "qkv16" (round 5): prefill passes and wide decode passes (17..64 rows) run the QKV projection on a 16-channel image of the
   // folded matrix (every A lane of every MFMA a weight) instead of the 12-channel tiles one-row steps were tuned on; + 6 d^2 bytes per
   // layer in bf16 (0.4 GB at giga830M).  Packed for engines that can take wide steps (max_seqs > 16) or with VC_QKV16=1 at creation;
@@ -311,6 +312,14 @@ bool hq_on(const vc_engine* e) {
   return e->hq != 0 && bytes % 1024 == 0 && bytes <= 8192;
 }
 
+// Option "qkv_p8" = 2: behind a centred copy, the QKV projection of 2..8 finished rows runs on the 8-channel image with two k-tiles per
+// fragment (rows_gemm_qp_k: every lane of every weight request a weight) instead of the 12-channel tiles of rows_gemm_k.
+// Measured (profiles/r06i_ab_qp.log, per step): giga830M 2 / 4 / 6 / 8 rows -2.0 / -1.1 / -0.3 / +0.5 %, giga330M 8 rows -1.3 %: at d >= 2048 the form
+// stops at 6 rows (the 8-row launch itself: 7.42 us against 7.33 us of the 12-channel tiles).
+bool qp_on(const vc_engine* e, const Layer& ly, int rows) {
+  return e->qkv_p8 >= 2 && hq_on(e) && ly.Wqkv8 != nullptr && rows <= (e->d >= 2048 ? 6 : 8) && vc_gemm_qp_ok(rows, 3 * e->d, e->d, e->dtype) != 0;
+}
+
 GemmArgs base_args(vc_engine* e, const RowSrc& rs, const Plan& p, int N, int Kdim) {
   GemmArgs g;
   memset(&g, 0, sizeof g);
@@ -391,7 +400,8 @@ int forward_rows_fr(vc_engine* e, const RowSrc& rs, hipStream_t s) {
       if (hq) g.row_mu_out = e->row_mu[cur ^ 1];
       if (hq && l > 0) {       // the previous layer's FFN down-projection left hqB = WT(hB - row_mu[cur])
         g.x_in = e->hqB; g.x_ld = d; g.row_mu = e->row_mu[cur];
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNQ, EPI_QKV, 1, 1, s));
+        if (qp_on(e, ly, rs.n_rows)) { g.Wp = ly.Wqkv8; HIPCHK(e, vc_launch_gemm_qp(g, e->dtype, s)); }
+        else HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNQ, EPI_QKV, 1, 1, s));
       } else {
         HIPCHK(e, vc_launch_gemm(g, e->dtype, PRO_LNW, EPI_QKV, 1, 1, s));
       }
@@ -1047,7 +1057,7 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "qkv_p8") {
     if (v0 && !e->layers.empty() && !e->layers[0].Wqkv8 && vc_gemm_fr1_ok(3 * e->d, e->d, e->dtype, 4))
       return fail(e, VC_ESTATE, "option 'qkv_p8': this engine was created with VC_QKV_P8=0 or VC_FR_ONE=0 and holds no 8-channel image of the QKV matrix");
-    e->qkv_p8 = v0 ? 1 : 0;
+    e->qkv_p8 = std::max(0, std::min(v0, 2));      // 2: steps of 2..8 finished rows as well (rows_gemm_qp_k)
   } else if (name == "wide_heads") { e->wide_heads = v0 ? 1 : 0;
   } else if (name == "wide_gemm") { e->wide_gemm = v0 ? 1 : 0;
   } else if (name == "shrink") { e->shrink = v0 ? 1 : 0;
@@ -2093,7 +2103,8 @@ extern "C" int vc_bench_kernel(vc_engine* e, const char* which, int n_rows, int 
         g.Wp = ly.Wqkv; nt_bit(e, g, NT_QKV); g.bias = ly.bqkv; g.wg = ly.wg_qkv; g.h_in = e->hB; g.q_out = e->q; g.kcache = ly.kc; g.vcache = ly.vc;
         g.mt = rs.n_rows > VC_FR_MAX_ROWS ? 4 : lnw_two(e, rs.n_rows) ? 3 : 0;
         if (hq_on(e)) { g.x_in = e->hqB; g.x_ld = d; g.row_mu = e->row_mu[0]; g.row_mu_out = e->row_mu[1]; }
-        HIPCHK(e, vc_launch_gemm(g, e->dtype, hq_on(e) ? PRO_LNQ : PRO_LNW, EPI_QKV, 1, 1, s));
+        if (qp_on(e, ly, n_rows)) { g.Wp = ly.Wqkv8; HIPCHK(e, vc_launch_gemm_qp(g, e->dtype, s)); }
+        else HIPCHK(e, vc_launch_gemm(g, e->dtype, hq_on(e) ? PRO_LNQ : PRO_LNW, EPI_QKV, 1, 1, s));
       } else if (w == "ffn2") {
         GemmArgs g = base_args(e, rs, e->p_f2, d, 4 * d);
         g.Wp = ly.W28; g.bias = ly.b2; g.x_in = e->act; g.x_ld = 4 * d; g.h_in = e->hA; g.h_out = e->hB;

@@ -465,7 +465,7 @@ class VoiceCraftEngine:
         return ms.value, nbytes.value
 
     LAUNCH_FORMS = ("rows_gemm", "mt2", "mt4", "blk64", "blk128_sbs", "blk128_2x2", "blk64_occ2", "ln_rows", "rows_attn",
-                    "tile_attn", "rows_gemm_fr", "big256", "big128", "row_gemm_fr1", "tile_attn64", "rows_gemm_frp", "wd")
+                    "tile_attn", "rows_gemm_fr", "big256", "big128", "row_gemm_fr1", "tile_attn64", "rows_gemm_frp", "wd", "rows_gemm_qp")
 
     def launch_counts(self) -> dict:
         """Process-wide census of the kernel FORMS launched so far (vc_common.h VC_LC_*): the parity tests take the
