@@ -509,15 +509,16 @@ def configs_block(args, dev, sd830):
             dstep = dec / max(1, steps)
             sb = step_alg_bytes(wl.a, args.dtype, max(wl.B, wl.best_of), wl.s_mean())
             ab = None
+            rows = max(wl.B, wl.best_of)
             if wl.B > 16:      # the wide-decode kernels of round 6 against the weight-stationary kernel of rounds 2-5, in process (3 pairs)
                 try:
                     ab = ab_block(wl.eng, lambda seed: wl.call(seed), "wide_gemm=0:1", 3)
                     ab = {k: ab[k] for k in ("knob", "A", "B", "A_ms_median", "B_ms_median", "median_delta_pct", "spread_pct")}
                 except Exception as e:      # reporting only
                     ab = {"error": str(e)}
-            elif 2 <= wl.B <= 16:      # the two byte-halving forms of round 6, each against its off state, in process (3 pairs)
+            elif 2 <= rows <= 16:      # the byte-halving forms of round 6, each against its off state, in process (3 pairs); up to 6 rows also the paired QKV consumer
                 ab = []
-                for spec in ("att_p16=0:1", "hq=0:1"):
+                for spec in ("att_p16=0:1", "hq=0:1") + (("qkv_p8=1:2",) if rows <= 6 else ()):
                     try:
                         r = ab_block(wl.eng, lambda seed: wl.call(seed), spec, 3)
                         ab.append({k: r[k] for k in ("knob", "A", "B", "A_ms_median", "B_ms_median", "median_delta_pct", "spread_pct")})

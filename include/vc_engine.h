@@ -243,7 +243,7 @@ int vc_box_probe(long long bytes, int hops, float res[2], void* stream);
  * out-projection / FFN down-projection (1 one piece, 2 K in two halves, 0 = NOT LAUNCHABLE, -1 n/a); out[6] heads-1 folds finished
  * rows itself; out[7] the consumers' tile counts are even.
  * The default forms of rounds 5-6 (-1 where the row count does not take them): out[8] ONE row: the FFN down-projection finishes its row
- * (row_gemm_fr1_k launchable at this width); out[9] ... and the QKV projection runs in the same paired 8-channel form; out[10] 2..8
+ * (row_gemm_fr1_k launchable at this width); out[9] ... and the QKV projection runs in the same paired 8-channel form (2..8 finished rows: 2 = layers 1.. run it on rows_gemm_qp_k, 0 = on the 12-channel tiles); out[10] 2..8
  * finished rows: the FFN down-projection in the paired form (rows_gemm_frp_k); out[11] 17..64 rows: the layer runs on rows_gemm_wd_k
  * (1) or falls back to rows_gemm_mt_k (0); out[12] / out[13] its K slices for the out-projection / FFN down-projection; out[14] /
  * out[15] its k-tiles per wave for K = d / K = head_hidden.  tests/test_plan_cpu.py walks every model width with it. */

@@ -36,7 +36,10 @@ def test_every_planned_pass_is_launchable(dtype):
                 if dtype == _lib.VC_DTYPE_BF16:
                     assert fr1 == 1 and qkvp8 == 1, (d, h)
             else:
-                assert fr1 == -1 and qkvp8 == -1
+                # 2..8 finished rows: 2 = the paired QKV consumer of round 6 (rows_gemm_qp_k; vc_debug_plan asks the launcher's own predicate), 0 = 12-channel tiles
+                assert fr1 == -1 and (qkvp8 in (0, 2) if (form == 1 and rows <= 8) else qkvp8 == -1)
+                if qkvp8 == 2:
+                    assert (d * (2 if dtype == _lib.VC_DTYPE_BF16 else 4)) % 1024 == 0 and rows <= (6 if d >= 2048 else 8)
             if rows > 16:
                 assert form == 2 and nsplit == 1
                 # round 6: the wide-decode kernel has a form for the power-of-two widths (a wave owns 1, 2, 4, 8 or 16 k-tiles) in both
@@ -74,5 +77,9 @@ def test_the_benchmarked_shapes_take_the_forms_the_profiles_describe():
     assert plan(1024, 16, bf, 16)[:6] == [16, 1, 1, 4, 1, 1]         # giga330M: 16 rows x 8 KB still one piece
     assert plan(2048, 16, bf, 32)[1] == 2
     assert plan(2048, 16, bf, 1)[8:10] == [1, 1] and plan(2048, 16, bf, 8)[10] == 1              # round 5: finished row + paired QKV at one row, paired FFN-down at 8
+    # round 6: the paired QKV consumer of 2..8 finished rows - up to 6 rows at d = 2048 (8 rows measured slower), up to 8 below; not where the
+    # centred copy's rows are not whole 1 KB requests (d = 256 in bf16, d = 768)
+    assert [plan(2048, 16, bf, r)[9] for r in (2, 6, 7, 8, 9)] == [2, 2, 0, 0, -1]
+    assert plan(1024, 16, bf, 8)[9] == 2 and plan(512, 16, f32, 3)[9] == 2 and plan(256, 4, bf, 4)[9] == 0 and plan(768, 12, bf, 4)[9] == 0
     assert plan(2048, 16, bf, 64)[11:16] == [1, 4, 4, 8, 4]        # round 6: wide decode on rows_gemm_wd_k, 4 K slices for both producers (256 workgroups)
     assert plan(1024, 16, bf, 32)[11:16] == [1, 4, 4, 4, 4]

@@ -1113,6 +1113,8 @@ extern "C" int vc_debug_plan(const vc_model_cfg* c, int compute_dtype, int rows,
     out[9] = out[8] && vc_gemm_fr1_ok(3 * d, d, compute_dtype, 4) ? 1 : 0;                       // qkv_p8: the paired QKV projection behind it
   }
   if (fr && rows <= VC_FR_MAX_ROWS) out[10] = vc_gemm_frp_ok(rows, d, 4 * d, compute_dtype) ? 1 : 0;   // fr_pair
+  if (fr && rows <= VC_FR_MAX_ROWS)       // qkv_p8 = 2: layers 1.. run the QKV projection on the 8-channel image (rows_gemm_qp_k) - the image's packing rule, qp_on's row rule
+    out[9] = (hq_on(&e) && vc_gemm_fr1_ok(3 * d, d, compute_dtype, 4) && rows <= (d >= 2048 ? 6 : 8) && vc_gemm_qp_ok(rows, 3 * d, d, compute_dtype)) ? 2 : 0;
   if (rows > VC_ROWS) {
     e.P = c->head_hidden;
     const int ko = wd_ksplit(&e, d, d), kf = wd_ksplit(&e, d, 4 * d);
