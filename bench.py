@@ -119,7 +119,7 @@ def in_situ(kernel, args):
 
 
 # option name -> (key of the option-state text, positions of its values there)
-OPTION_STATE = {"graph_steps": ("g", (0,)), "nt": ("nt", (0,)), "attn_nt": ("nt", (1,)), "finished_rows": ("fr", (0,)), "fr_pair": ("fr", (1,)), "att_p16": ("fr", (2,)), "hq": ("fr", (3,)),
+OPTION_STATE = {"graph_steps": ("g", (0,)), "nt": ("nt", (0, 1)), "finished_rows": ("fr", (0,)), "fr_pair": ("fr", (1,)), "att_p16": ("fr", (2,)), "hq": ("fr", (3,)),
                 "tile_attn": ("ta", (0, 1)), "fr_one": ("r1", (0,)), "attn_fast": ("r1", (1,)), "qkv_p8": ("r1", (2,)), "qkv16": ("q16", (0,)),
                 "wide_heads": ("q16", (1,)), "wide_gemm": ("q16", (2,)), "wd_stage": ("q16", (3,)), "shrink": ("sh", (0,))}
 

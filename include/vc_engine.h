@@ -94,11 +94,12 @@ const char* vc_last_error(const vc_engine* e); /* e may be NULL: last vc_create 
 const char* vc_version(void);
 
 /* Run-time options of a finalized engine: launch-shape knobs of the decode step, the same ones the VC_* environment
- * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  Seventeen of them (round 6
- * pruned round 5's 22 to 15 - the prefetch roles and the knobs whose value every measurement had fixed are constants now - and added two
- * measurement arms, "att_p16" and "hq").  name / value:
- *   "nt"           bit mask of the weight matrices streamed with the non-temporal hint (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down, 16 / 32
- *                  heads); "attn_nt" 0 / 1 / 2 = the decode attention's K/V loads never / always / from two rows per step
+ * variables preset when the engine is created (no reference counterpart: the reference has no such knobs).  Sixteen of them (round 6
+ * pruned round 5's 22 to 14 - the prefetch roles and the knobs whose value every measurement had fixed are constants now, the K/V hint is a
+ * second value of "nt" - and added two measurement arms, "att_p16" and "hq").  name / value:
+ *   "nt"           "mask[,kv]"  mask: the weight matrices streamed with the non-temporal hint (1 QKV, 2 out-proj, 4 FFN-up, 8 FFN-down, 16 / 32
+ *                  heads); kv 0 / 1 / 2 = the decode attention's K/V loads carry it never / always / from two rows per step (the separate
+ *                  name "attn_nt" of rounds 4-5 is gone)
  *   "finished_rows" rows up to which a several-row decode step keeps whole residual rows instead of split-K slabs (0 = off, max 16);
  *                  "fr_pair" 1 = its FFN down-projection with two k-tiles per MFMA fragment at 2..8 rows;  "att_p16" 1 (default) = bf16 mode: the
  *                  split attention of 2..8-row steps leaves its partial outputs in bf16 for the out-projection's merge;  "hq" 1 (default) = the
@@ -123,7 +124,7 @@ const char* vc_version(void);
  * What an option may change: nothing in the exact fp32 mode's greedy tokens (tests/test_gpu_options.py, test_gpu_one_row.py); in bf16
  * mode the forms that re-order sums or round at another place ("finished_rows", "fr_pair", "att_p16", "hq", "fr_one", "qkv_p8", "attn_fast",
  * "qkv16", "wide_heads", "wide_gemm") move head logits by bf16 rounding (tests allow 0.25 absolute), so top-k SAMPLED tokens can differ between option
- * states; the cache-policy / data-path / host-side options ("nt", "attn_nt", "wd_stage", "graph_steps", "shrink") change no value.
+ * states; the cache-policy / data-path / host-side options ("nt", "wd_stage", "graph_steps", "shrink") change no value.
  * The non-temporal mask "nt" has no bit for the finished-row producers (rows_gemm_fr_k, rows_gemm_fr2_k, row_gemm_fr1_k) and the
  * wide-decode kernels: they always stream with the hint.  Captured decode graphs are kept per option state and step width, so an
  * in-process A/B (bench.py --ab) pays for capture once per state.  Unknown names / malformed values: VC_EINVAL.

@@ -54,8 +54,8 @@ def test_option_state_text_round_trips_through_the_bench_helpers():
     assert o["one_row"] == {"fr_one": 1, "attn_fast": 1, "qkv_p8": 2} and o["nt"] == {"weights_mask": 63, "attn_kv": 2}
     assert o["many_rows"] == {"qkv16": 1, "wide_heads": 1, "wide_gemm": 1, "wd_stage": 1} and o["shrink"] == 1 and o["finished_rows"] == {"max_rows": 16, "paired": 1, "bf16_partials": 1, "centred_copy": 1}
     assert bench.option_value(t, "tile_attn") == "2,768" and bench.option_value(t, "wide_gemm") == "1" and bench.option_value(t, "shrink") == "1"
-    assert bench.option_value(t, "fr_one") == "1" and bench.option_value(t, "attn_nt") == "2" and bench.option_value(t, "no_such") is None
-    assert len(bench.OPTION_STATE) + 1 == 17          # + prefill_rows, which shapes no captured decode step: the engine's seventeen options (two of them - att_p16, hq - measurement arms of round-6 forms)
+    assert bench.option_value(t, "fr_one") == "1" and bench.option_value(t, "nt") == "63,2" and bench.option_value(t, "no_such") is None
+    assert len(bench.OPTION_STATE) + 1 == 16          # + prefill_rows, which shapes no captured decode step: the engine's sixteen options (two of them - att_p16, hq - measurement arms of round 6; the K/V hint is the second value of "nt")
 
 
 def test_in_situ_figure_is_quoted_only_for_the_configuration_it_was_traced_on(tmp_path, monkeypatch):

@@ -123,7 +123,7 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
     x, xl, y = synth.random_prompt(a, 6, 21, seed=11)
     eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="fp32", max_seqs=2, max_positions=256)
     base = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
-    for name, value in [("attn_nt", "1"), ("attn_nt", "0"), ("nt", "28"), ("nt", "0"), ("nt", "63"), ("graph_steps", "3"), ("graph_steps", "8"),
+    for name, value in [("nt", "63,1"), ("nt", "63,0"), ("nt", "28"), ("nt", "0"), ("nt", "63"), ("graph_steps", "3"), ("graph_steps", "8"),
                         ("shrink", "0"), ("wide_gemm", "0"), ("wd_stage", "0"), ("tile_attn", "1")]:
         eng.set_option(name, value)
         got = eng.inference_tts(x.cuda(), xl.cuda(), y.cuda(), top_k=1, stop_repetition=3)[0].cpu().numpy()
@@ -136,6 +136,12 @@ def test_options_do_not_change_tokens_and_bad_options_are_refused():
         eng.set_option("attn_pf", "8")          # the prefetch roles of rounds 3-5 are gone
     with pytest.raises(AssertionError):
         eng.set_option("mt_tiles", "4")         # ... and the knobs whose measured best value became a constant
+    with pytest.raises(AssertionError):
+        eng.set_option("attn_nt", "1")          # ... and the K/V hint is the second value of "nt"
+    eng.set_option("nt", "63,1")
+    assert "|nt=63,1|" in eng.options()
+    eng.set_option("nt", "28")                  # one value: the K/V policy stays
+    assert "|nt=28,1|" in eng.options()
 
 
 @pytest.mark.parametrize("preset,B", [("tiny", 1), ("tiny_h16", 1), ("tiny128", 20)])

@@ -35,7 +35,7 @@ __device__ __forceinline__ void unpack16<bf16_t>(const uint4& u, float* f) {
 // ---------------------------------------------------------------- decode attention
 // NT: K/V rows are requested with the non-temporal hint (every cached row is read exactly once per step and never again before
 // the next step's 1.7 GB of weights have gone through the caches) - a template parameter so that the hint cannot be merged away
-// (vc_gemm.hip rows_gemm_k), chosen per launch from AttnArgs.nt (option "attn_nt").
+// (vc_gemm.hip rows_gemm_k), chosen per launch from AttnArgs.nt (option "nt", second value).
 // FAST (round 5; option "attn_fast", default on): the in-kernel stamps of round 4 put half of the one-row launch's in-kernel time
 // (3 916 of 8 016 clk) into "wave merge + block sync + final + store" - online-softmax bookkeeping, not K/V.  Here a wave takes the
 // MAXIMUM of a batch's scores over all of its lanes before any exponential, so every lane of the wave carries the same running

@@ -96,7 +96,7 @@ struct vc_engine {
   // Option "nt" (VC_NT).  Until round 4 the compiled QKV / out-projection / heads-2 kernels carried NO such load whatever this said (the
   // compiler merged the kernel's two load arms and dropped the hint): 28 reproduces that mix, 63 = every matrix (default), 0 = none.
   int nt_decode = 63;
-  // option "attn_nt": the decode attention's K/V loads carry the hint too - 0 never, 1 always, 2 (default) from two rows per step up
+  // option "nt", second value: the decode attention's K/V loads carry the hint too - 0 never, 1 always, 2 (default) from two rows per step up
   // (in-process A/Bs, profiles/r04d_bench_*attn_nt*: one row +0.3 % +- 0.09 - there the launch is latency-bound and carries the prefetch
   // role -, 8 rows -4.8 % +- 0.05, 32 rows -6.5 % +- 0.05: several caches stream 58-230 MB per layer through L2 otherwise)
   int attn_nt = 2;
@@ -1069,8 +1069,9 @@ int apply_option(vc_engine* e, const std::string& name, const char* value) {
   } else if (name == "attn_fast") { e->attn_fast = v0 ? 1 : 0;
   } else if (name == "att_p16") { e->att_p16 = v0 ? 1 : 0;
   } else if (name == "hq") { e->hq = v0 ? 1 : 0;
-  } else if (name == "nt") { e->nt_decode = v0 & 63;
-  } else if (name == "attn_nt") { e->attn_nt = std::max(0, std::min(v0, 2));
+  } else if (name == "nt") {      // "mask[,kv]": the weight matrices streamed with the hint, and the decode attention's K/V loads (0 never, 1 always, 2 from two rows up)
+    e->nt_decode = v0 & 63;
+    if (n >= 2) e->attn_nt = std::max(0, std::min(v1, 2));
   } else if (name == "prefill_rows") { e->prefill_rows_per_pass = std::max(VC_ROWS, std::min(VC_MAX_ROWS, v0 / VC_ROWS * VC_ROWS));   // 16: decode kernels only
   } else {
     return fail(e, VC_EINVAL, "unknown option '%s'", name.c_str());
@@ -1419,7 +1420,7 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
   for (const auto& kv : {std::make_pair("VC_NT", "nt"), std::make_pair("VC_PREFILL_ROWS", "prefill_rows"), 
                          std::make_pair("VC_GRAPH_STEPS", "graph_steps"),
                          
-                         std::make_pair("VC_FINISHED_ROWS", "finished_rows"), std::make_pair("VC_ATTN_NT", "attn_nt"),
+                         std::make_pair("VC_FINISHED_ROWS", "finished_rows"),
                          std::make_pair("VC_TILE_ATTN", "tile_attn"),
                          std::make_pair("VC_FR_ONE", "fr_one"), std::make_pair("VC_QKV_P8", "qkv_p8"), std::make_pair("VC_FR_PAIR", "fr_pair"), std::make_pair("VC_QKV16", "qkv16"), std::make_pair("VC_WIDE_HEADS", "wide_heads"), std::make_pair("VC_WIDE_GEMM", "wide_gemm"), std::make_pair("VC_WD_STAGE", "wd_stage"), std::make_pair("VC_SHRINK", "shrink"), std::make_pair("VC_ATTN_FAST", "attn_fast"), std::make_pair("VC_ATT_P16", "att_p16"), std::make_pair("VC_HQ", "hq")})
     if (const char* v = getenv(kv.first)) {
