@@ -14,5 +14,5 @@ print(f"{'kernel':58s} {'grid(blocks)':>16s} {'lds':>7s} {'vgpr':>5s} {'calls':>
 q = """select name, grid_x/workgroup_x, grid_y/workgroup_y, grid_z/workgroup_z, lds_size, vgpr_count, count(*), sum(duration), avg(duration), min(duration), max(duration)
        from kernels group by name, grid_x, grid_y, grid_z, lds_size order by sum(duration) desc"""
 for r in cur.execute(q):
-    n = re.sub(r"\(.*", "", r[0]).replace("void ", "")
+    n = re.sub(r"\(.*", "", r[0].replace("(anonymous namespace)::", "")).replace("void ", "")      # (the wide-decode kernels live in an anonymous namespace)
     print(f"{n[:58]:58s} {str((r[1], r[2], r[3])):>16s} {r[4]:7d} {r[5]:5d} {r[6]:7d} {r[7] / 1e6:9.3f} {100.0 * r[7] / tot:6.2f} {r[8] / 1e3:8.2f} {r[9] / 1e3:8.2f} {r[10] / 1e3:8.2f}", file=out)
