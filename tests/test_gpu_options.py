@@ -239,6 +239,35 @@ def test_wide_decode_33_to_64_rows_fp32_tokens_equal_the_oracle(preset, B):
 
 
 
+@pytest.mark.parametrize("preset,B,gsteps", [("tiny128", 24, 8), ("tiny_h16", 12, 3)])
+def test_sampled_tokens_of_a_shrinking_batch_are_the_same_in_every_run(preset, B, gsteps):
+    """bf16, top-k sampling, live terminators, a batch that shrinks: the width a step runs at decides which kernels round its logits, so the
+    step at which the host re-packs the batch must not depend on how far the device has run ahead of it.  The sampler leaves "sequences still
+    live" in the slot of its batch of graph_steps steps and the host reads the slot of a batch it has seen END (SampleArgs.step_ctr): six
+    runs of one seeded call, with the host disturbed differently before each, give the same tokens and the same number of re-packs."""
+    import time
+    from voicecraft_amd import synth
+    from voicecraft_amd.engine import VoiceCraftEngine
+    a = synth.make_args(preset)
+    sd = synth.make_state_dict(a, seed=4, mute_eos=False, boost=[(0, 2051, 0.45)])
+    prompts = [synth.random_prompt(a, 4 + (u % 5), 9 + 3 * (u % 7), seed=700 + u) for u in range(B)]
+    eng = VoiceCraftEngine(a, sd, device="cuda:0", dtype="bf16", max_seqs=B, max_positions=256)
+    eng.set_option("graph_steps", gsteps)
+    runs, repacks = [], []
+    for i in range(6):
+        if i % 2:
+            time.sleep(0.02 * i)                      # another phase between the host's loop and the device's
+        outs = eng.inference_tts_multi([p[0][0] for p in prompts], [p[2][0] for p in prompts], top_k=40, stop_repetition=3, _seed=11)
+        runs.append([res.cpu().numpy() for (res, gen) in outs])
+        repacks.append(int(eng.debug_read("host_ms", (8,), torch.float64)[6]))
+    assert repacks[0] >= 1 and len(set(repacks)) == 1, repacks
+    lens = [r.shape[2] for r in runs[0]]
+    assert len(set(lens)) > 1, lens                    # sequences really retire at different steps
+    for i in range(1, 6):
+        for u in range(B):
+            assert runs[i][u].shape == runs[0][u].shape and np.array_equal(runs[i][u], runs[0][u]), (i, u)
+
+
 _RAGGED_ORACLE = {}      # (preset, B) -> the oracle's outputs: shared by the graph / eager runs of a shape
 
 

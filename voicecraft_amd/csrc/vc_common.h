@@ -348,6 +348,9 @@ struct SampleArgs {         // engine-constant part (kernel argument)
   int* host_active;         // pinned host word (device-visible): set to 0 by the block that retires the last sequence
   int* host_live;           // pinned host word: sequences still live as the step's sampler launch found them (written by its first workgroup only:
                             // one writer, never out of order) - what the host's decode loop shrinks a wide batch by
+  int* step_ctr;            // device word: decode steps sampled so far in this call (first workgroup only).  host_live has TWO slots and a step writes
+  int graph_steps;          // slot (step_ctr / graph_steps) & 1: the host reads the slot of a batch of steps it has seen END, so what it re-packs by
+                            // does not depend on how far the device has run ahead (same seed, same widths, same tokens in every run)
   int* samp;                // scratch [B][K + 2]
   int* gen;                 // [B][gen_stride][K]
   // next-step rows

@@ -78,6 +78,7 @@ struct vc_engine {
   long long* dbg_ts = nullptr;
   int *one = nullptr;                   // device word holding 1: the "always active" flag of prefill launches
   int *share_len = nullptr;             // device word: text positions shared with sequence 0 (AttnArgs.share_len), 0 outside such calls
+  int *step_ctr = nullptr;              // SampleArgs.step_ctr
   int *n_active = nullptr, *samp = nullptr, *cond = nullptr, *amax = nullptr, *gen = nullptr, *err_flag = nullptr;
   int gen_cap = 0;
   // pinned host staging
@@ -841,7 +842,7 @@ SampleArgs make_sample_args(vc_engine* e, int B, int rps) {
   memset(&a, 0, sizeof a);
   a.logits = e->logits; a.B = B; a.K = e->K; a.V = e->V; a.d = e->d;
   a.empty_token = e->cfg.empty_token; a.gen_stride = e->gen_cap; a.dyn = e->d_dyn;
-  a.st = e->st; a.n_active = e->n_active; a.host_active = e->h_flag + 8; a.host_live = e->h_flag + 9; a.samp = e->samp;
+  a.st = e->st; a.n_active = e->n_active; a.host_active = e->h_flag + 8; a.host_live = e->h_flag + 9; a.step_ctr = e->step_ctr; a.graph_steps = std::max(1, e->steps_per_graph); a.samp = e->samp;
   a.gen = e->gen;
   a.rps = rps; a.dec_h = e->dec_h; a.row_seq = e->dec_row_seq; a.row_pos = e->dec_row_pos;
   a.logit_row = e->logit_row;
@@ -952,8 +953,9 @@ int decode_loop(vc_engine* e, const SampleArgs& sa0, int B0, int rps, bool group
     return rc0;
   }
   const double t1 = now_ms();
+  HIPCHK(e, hipMemsetAsync(e->step_ctr, 0, sizeof(int), s));      // the loop's first step is step 0 of batch 0 (SampleArgs.host_live slots)
   volatile int* live = e->h_flag + 8;
-  volatile int* live_n = e->h_flag + 9;                   // sequences still live, as the last finished step's sampler saw them
+  volatile int* live_n = e->h_flag + 9;                   // two slots: sequences still live as the LAST step of a batch of G steps found them
   int launched = 0, rc = VC_OK, batch = 0;
   while (launched < max_steps && rc == VC_OK) {
     if (batch >= 2) {   // pace: at most two batches in flight; the older one must have ended before a third is queued
@@ -961,7 +963,9 @@ int decode_loop(vc_engine* e, const SampleArgs& sa0, int B0, int rps, bool group
       if (we != hipSuccess) { rc = fail(e, VC_EHIP, "pacing event: %s", hipGetErrorString(we)); break; }
       if (*live <= 0) break;
       if (can_shrink) {
-        const int n_live = *live_n;                       // (only ever decreases; the steps already queued can only lower it further)
+        // the slot of the batch whose end has just been waited for (launched two iterations ago): the batch still in flight writes
+        // the other one, so the width schedule is the same in every run of the same call - and with it, in bf16, every sampled token
+        const int n_live = live_n[batch & 1];
         const int w = n_live >= 1 ? width_for(n_live) : B;
         if (w < B) {
           RepackArgs ra;
@@ -1392,6 +1396,8 @@ extern "C" int vc_finalize_weights(vc_engine* e, int compute_dtype) {
     HIPCHK(e, hipMemset(e->mu_zero, 0, VC_ROWS * 4));
   }
   if ((rc = dalloc(e, &e->n_active, (size_t)4))) return rc;
+  if ((rc = dalloc(e, &e->step_ctr, (size_t)4))) return rc;
+  HIPCHK(e, hipMemset(e->step_ctr, 0, 4));
   if ((rc = dalloc(e, &e->err_flag, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->one, (size_t)4))) return rc;
   if ((rc = dalloc(e, &e->share_len, (size_t)4))) return rc;
@@ -1517,7 +1523,7 @@ int tts_run(vc_engine* e, const std::vector<TtsJob>& jobs, int n_samples, const 
   HIPCHK(e, hipMemsetAsync(e->st_fin, 0, sizeof(SeqState) * B, s));
   e->h_flag[1] = B;
   e->h_flag[8] = B;
-  e->h_flag[9] = B;
+  e->h_flag[9] = B; e->h_flag[10] = B;        // the two slots of "sequences still live" (SampleArgs.host_live)
   e->host_ms[6] = 0;
   HIPCHK(e, hipMemcpyAsync(e->n_active, e->h_flag + 1, sizeof(int), hipMemcpyHostToDevice, s));
   int rc = push_sample_dyn(e, sc, forced, n_forced, logits_out, logit_steps, B, s);

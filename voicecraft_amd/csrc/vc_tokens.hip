@@ -604,7 +604,11 @@ __global__ __launch_bounds__(256) void sample_fused_k(const SampleArgs a) {
   const SampleDyn dy = *a.dyn;
   __builtin_amdgcn_sched_barrier(0);
   if (active == 0) return;
-  if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(a.host_live, active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x == 0 && threadIdx.x == 0) {      // (one writer per step, steps in order)
+    const int c = *a.step_ctr;
+    *a.step_ctr = c + 1;
+    __hip_atomic_store(a.host_live + ((c / a.graph_steps) & 1), active, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   VC_TS(0);
   if (dy.dbg_ts && b < 8 && threadIdx.x == 0) {   // diagnosis: entry / exit clock of every block
     dy.dbg_ts[16 + 2 * b] = t_entry;
