@@ -1,6 +1,5 @@
-# two-slot host_live (deterministic re-pack step): decode-path parity files + the ragged probe
+# The script of one `gpurun` call of round 6 (rewritten for every call; the outputs of each are under profiles/r06*).
+# Last state: the whole-state check of the final build.
 set -u
 export TMPDIR=/tmp
-O=gpurun_out
-echo "== tests"; timeout 1500 python -m pytest tests/test_gpu_options.py tests/test_gpu_model.py tests/test_gpu_scale.py -m gpu -q 2>&1 | tail -15 | tee $O/r06r_pytest.log
-echo "== ragged probe"; timeout 300 python tools/ragged_probe.py 8 2>&1 | grep -v amdgpu.ids | tee $O/r06r_ragged8.log
+TAG=${TAG:-r06s} SHORT=1 bash tools/round_check.sh
